@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures in tests/golden/*.json from the independent Python
+big-int model (oracle/pyref).  Run from the repo root:  python tests/golden/gen_golden.py
+
+Nothing here reads /root/reference (it is Rust and cannot be imported); the vectors pin the C oracle
+and the HIP product against a third, independent implementation.  All values are hex strings of
+STANDARD-form integers unless a key says "mont".
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+
+from pyref import bls12_377 as bls  # noqa: E402
+from pyref import marlin as M  # noqa: E402
+from pyref.bls12_377 import R, Q  # noqa: E402
+from pyref.poly import Domain, batch_inverse  # noqa: E402
+from pyref.prng import Xoshiro256ss  # noqa: E402
+from pyref import rng as prng_mod  # noqa: E402
+
+
+def hx(v):
+    return hex(v)
+
+
+def pt(P):
+    return None if P is None else [hx(P[0]), hx(P[1])]
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=0, separators=(",", ":"))
+    print("wrote", name, os.path.getsize(path), "bytes")
+
+
+def gen_fields():
+    g = Xoshiro256ss(1)
+    fr_cases = []
+    for _ in range(24):
+        a, b = g.fr(), g.fr()
+        fr_cases.append({"a": hx(a), "b": hx(b), "mul": hx(a * b % R), "add": hx((a + b) % R),
+                         "sub": hx((a - b) % R), "inv_a": hx(pow(a, -1, R))})
+    edge = [0, 1, 2, R - 1, R - 2, (1 << 252), bls.FR_MONT_R]
+    for a in edge:
+        for b in edge:
+            fr_cases.append({"a": hx(a), "b": hx(b), "mul": hx(a * b % R), "add": hx((a + b) % R),
+                             "sub": hx((a - b) % R), "inv_a": hx(pow(a, -1, R) if a else 0)})
+    fq_cases = []
+    for _ in range(24):
+        a = (g.fr() * g.fr() + g.fr()) % Q
+        b = (g.fr() * g.fr() + g.fr()) % Q
+        fq_cases.append({"a": hx(a), "b": hx(b), "mul": hx(a * b % Q)})
+    for a in (0, 1, Q - 1, Q - 2, 1 << 376, bls.FQ_MONT_R):
+        for b in (0, 1, Q - 1, 1 << 376):
+            fq_cases.append({"a": hx(a), "b": hx(b), "mul": hx(a * b % Q)})
+    dump("fields.json", {
+        "fr": {"modulus": hx(R), "mont_r": hx(bls.FR_MONT_R), "mont_r2": hx(bls.FR_MONT_R ** 2 % R),
+               "inv": hx((-pow(R, -1, 1 << 64)) % (1 << 64)), "root_2_47": hx(bls.FR_ROOT_2_47),
+               "generator": 22, "cases": fr_cases},
+        "fq": {"modulus": hx(Q), "mont_r": hx(bls.FQ_MONT_R), "mont_r2": hx(bls.FQ_MONT_R ** 2 % Q),
+               "inv": hx((-pow(Q, -1, 1 << 64)) % (1 << 64)), "cases": fq_cases},
+    })
+
+
+def srs_like_bases(n, tau):
+    out = []
+    p = 1
+    for _ in range(n):
+        out.append(bls.g1_mul_fast(bls.G1_GEN, p))
+        p = p * tau % R
+    return out
+
+
+def gen_g1_msm():
+    G = bls.G1_GEN
+    g = Xoshiro256ss(2)
+    muls = [{"k": hx(k), "p": pt(bls.g1_mul_fast(G, k))} for k in
+            [1, 2, 3, 4, 70, R - 1, g.fr(), g.fr(), bls.G1_COFACTOR]]
+    adds = []
+    for _ in range(6):
+        a, b = g.fr(), g.fr()
+        A, B = bls.g1_mul_fast(G, a), bls.g1_mul_fast(G, b)
+        adds.append({"a": pt(A), "b": pt(B), "sum": pt(bls.g1_add(A, B)), "dbl_a": pt(bls.g1_add(A, A))})
+    A = bls.g1_mul_fast(G, 5)
+    adds.append({"a": pt(A), "b": pt(bls.g1_neg(A)), "sum": None, "dbl_a": pt(bls.g1_add(A, A))})
+    dump("g1.json", {"generator": pt(G), "cofactor": hx(bls.G1_COFACTOR), "muls": muls, "adds": adds,
+                     "compressed_generator": M.ser_g1(G).hex()})
+
+    tau = Xoshiro256ss().fr()  # first draw of the SWMARLIN stream
+    t0 = time.time()
+    bases = srs_like_bases(300, tau)
+    print("bases", time.time() - t0)
+    cases = []
+
+    multiples = [bls.g1_mul_fast(G, i + 1) for i in range(4)]
+    cases.append({"name": "kat_70G", "n": 4, "bases": [pt(b) for b in multiples],
+                  "scalars": [hx(s) for s in (5, 6, 7, 8)], "result": pt(bls.g1_mul_fast(G, 70))})
+    for n in (1, 2, 31, 32, 33, 300):
+        sc = [g.fr() for _ in range(n)]
+        cases.append({"name": "uniform_%d" % n, "n": n, "bases": "srs", "scalars": [hx(s) for s in sc],
+                      "result": pt(bls.g1_msm_naive(bases[:n], sc))})
+        assert bls.g1_msm_naive(bases[:n], sc) == bls.g1_msm_pippenger(bases[:n], sc)
+    # structured: 25 % zeros, 25 % ones, 50 % uniform (bit-heavy witnesses)
+    n = 200
+    sc = [0 if i % 4 == 0 else 1 if i % 4 == 1 else g.fr() for i in range(n)]
+    cases.append({"name": "structured_200", "n": n, "bases": "srs", "scalars": [hx(s) for s in sc],
+                  "result": pt(bls.g1_msm_naive(bases[:n], sc))})
+    assert bls.g1_msm_naive(bases[:n], sc) == bls.g1_msm_pippenger(bases[:n], sc)
+    for name, sc in (("all_zero", [0] * 40), ("all_one", [1] * 40), ("all_rm1", [R - 1] * 40),
+                     ("all_equal", [0x1234567] * 40), ("edge_mix", [0, 1, R - 1, 2, R - 2, 1 << 252] * 6)):
+        cases.append({"name": name, "n": len(sc), "bases": "srs", "scalars": [hx(s) for s in sc],
+                      "result": pt(bls.g1_msm_naive(bases[:len(sc)], sc))})
+    # consecutive multiples of G: sums collide with later inputs (forces the doubling branch of adders)
+    mult = [bls.g1_mul_fast(G, i + 1) for i in range(64)]
+    sc = [(i % 7) + 1 for i in range(64)]
+    cases.append({"name": "collide_64", "n": 64, "bases": [pt(b) for b in mult], "scalars": [hx(s) for s in sc],
+                  "result": pt(bls.g1_msm_naive(mult, sc))})
+    dump("msm.json", {"tau": hx(tau), "srs_bases": [pt(b) for b in bases], "cases": cases})
+
+
+def gen_ntt():
+    g = Xoshiro256ss(3)
+    cases = [{"name": "kat4", "log_n": 2, "inverse": 0, "coset": 0, "in": [hx(v) for v in (1, 2, 3, 4)],
+              "out": [hx(v) for v in Domain(4).fft([1, 2, 3, 4])]}]
+    for log_n in range(0, 9):
+        n = 1 << log_n
+        d = Domain(n)
+        x = [g.fr() for _ in range(n)]
+        for inverse, coset, fn in ((0, 0, d.fft), (1, 0, d.ifft), (0, 1, d.coset_fft), (1, 1, d.coset_ifft)):
+            y = fn(x)
+            cases.append({"name": "n%d_i%d_c%d" % (n, inverse, coset), "log_n": log_n, "inverse": inverse,
+                          "coset": coset, "in": [hx(v) for v in x], "out": [hx(v) for v in y]})
+    # naive O(n^2) DFT cross-check of the model itself
+    d = Domain(16)
+    x = [g.fr() for _ in range(16)]
+    naive = [sum(x[j] * pow(d.gen, i * j, R) for j in range(16)) % R for i in range(16)]
+    assert naive == d.fft(x)
+    roots = {str(k): hx(bls.fr_root_of_unity(k)) for k in (2, 16, 20, 22, 24, 25)}
+    dump("ntt.json", {"roots": roots, "cases": cases})
+
+
+def gen_misc():
+    g = Xoshiro256ss(4)
+    v = [g.fr() for _ in range(37)]
+    v[5] = 0
+    v[0] = 0
+    v[36] = 0
+    binv = batch_inverse(v)
+    # SpMV: random sparsity, some coeff == 1, some empty rows
+    rows, cols = 23, 17
+    z = [g.fr() for _ in range(cols)]
+    rowptr, col, val = [0], [], []
+    for r in range(rows):
+        k = g.next_u64() % 4
+        for _ in range(k):
+            col.append(g.next_u64() % cols)
+            val.append(1 if g.next_u64() % 3 == 0 else g.fr())
+        rowptr.append(len(col))
+    out = [sum(val[k] * z[col[k]] for k in range(rowptr[r], rowptr[r + 1])) % R for r in range(rows)]
+    dump("misc.json", {"batch_inverse": {"in": [hx(x) for x in v], "out": [hx(x) for x in binv]},
+                       "spmv": {"rows": rows, "cols": cols, "rowptr": rowptr, "col": col,
+                                "val": [hx(x) for x in val], "z": [hx(x) for x in z], "out": [hx(x) for x in out]}})
+
+
+def gen_rng():
+    def ks(rounds, counter=0):
+        b = prng_mod.chacha_block([0] * 8, counter, 0, rounds)
+        return b"".join(w.to_bytes(4, "little") for w in b).hex()
+    r = prng_mod.test_rng()
+    u64s = [hx(r.next_u64()) for _ in range(70)]  # crosses the 64-word buffer boundary
+    r = prng_mod.test_rng()
+    frs = [hx(r.rand_fr()) for _ in range(5)]
+    fqv = hx(r.rand_fq())
+    bl = r.gen_bool()
+    u128 = hx(r.gen_u128())
+    fs = prng_mod.FiatShamirRng(b"MARLIN-2019" + bytes(range(40)))
+    fs_a = hx(fs.rand_fr())
+    fs.absorb(bytes(range(7)))
+    fs_b = hx(fs.rand_fr())
+    fs_c = hx(fs.gen_u128())
+    dump("rng.json", {"chacha20_zero_key_block0": ks(20), "chacha12_zero_key_block0": ks(12),
+                      "chacha8_zero_key_block0": ks(8), "chacha20_zero_key_block1": ks(20, 1),
+                      "blake2s_abc": prng_mod.blake2s(b"abc").hex(), "blake2s_empty": prng_mod.blake2s(b"").hex(),
+                      "blake2s_200": prng_mod.blake2s(bytes(i & 0xFF for i in range(200))).hex(),
+                      "test_rng_u64": u64s, "test_rng_fr": frs, "test_rng_then_fq": fqv,
+                      "test_rng_then_bool": bl, "test_rng_then_u128": u128,
+                      "fs_init_fr": fs_a, "fs_absorb_fr": fs_b, "fs_then_u128": fs_c})
+
+
+def gen_marlin():
+    out = {}
+
+    def run(name, cs, srs_sizes, public):
+        rng = M.generate_rand()
+        t = time.time()
+        srs = M.generate_universal_srs(*srs_sizes, rng)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        trace = {}
+        proof = M.prove(pk, cs, rng, trace)
+        pbytes = M.serialize_proof(proof)
+        assert M.verify_proof(vk, public, M.deserialize_proof(pbytes), rng)
+        keep = {k: hx(trace[k]) for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi")}
+        out[name] = {"srs": list(srs_sizes), "max_degree": srs.max_degree, "public_input": [hx(x) for x in public],
+                     "num_constraints": vk["num_constraints"], "num_variables": vk["num_variables"],
+                     "num_non_zero": vk["num_non_zero"], "challenges": keep,
+                     "z_a": [hx(x) for x in trace["z_a"]], "z_b": [hx(x) for x in trace["z_b"]],
+                     "proof": pbytes.hex(), "vk": M.serialize_verifying_key(vk).hex(),
+                     "srs_g": pt(srs.powers_of_g[0]), "srs_g1": pt(srs.powers_of_g[1]),
+                     "srs_gamma_g": pt(srs.powers_of_gamma_g[0])}
+        print(" marlin", name, "%.1fs" % (time.time() - t), len(pbytes))
+
+    # config #1: examples/manual-constraints.rs:86-100 (a = b = 1, SRS (100, 25, 300))
+    run("manual_constraints", M.manual_constraints_circuit(1, 1), (100, 25, 300), [1])
+    g = Xoshiro256ss(5)
+    for n in (8, 16, 32):
+        a, b = g.fr(), g.fr()
+        cs = M.synthetic_circuit(n, a, b)
+        out_name = "synthetic_%d" % n
+        run(out_name, cs, (n, n, n), cs.instance[1:])
+        out[out_name]["a"] = hx(a)
+        out[out_name]["b"] = hx(b)
+    dump("marlin.json", out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fields", "g1_msm", "ntt", "misc", "rng", "marlin"]
+    for w in which:
+        globals()["gen_" + w]()

@@ -1,0 +1,198 @@
+"""ctypes binding of oracle/_build/liboracle.so (the CPU checker).  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY — never by simpleworks_amd/."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+R = 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001
+Q = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+M64 = (1 << 64) - 1
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    sz = ctypes.c_size_t
+    for name, args in {
+        "oracle_fr_to_mont": [_u64p, _u64p, sz], "oracle_fr_from_mont": [_u64p, _u64p, sz],
+        "oracle_fq_to_mont": [_u64p, _u64p, sz], "oracle_fq_from_mont": [_u64p, _u64p, sz],
+        "oracle_fr_mul": [_u64p, _u64p, _u64p, sz], "oracle_fr_add": [_u64p, _u64p, _u64p, sz],
+        "oracle_fr_sub": [_u64p, _u64p, _u64p, sz], "oracle_fq_mul": [_u64p, _u64p, _u64p, sz],
+        "oracle_fr_inv": [_u64p, _u64p, sz], "oracle_batch_inverse_fr": [_u64p, sz],
+        "oracle_g1_add_mixed": [_u64p, _u64p, _u64p], "oracle_g1_double": [_u64p, _u64p],
+        "oracle_g1_add": [_u64p, _u64p, _u64p],
+        "oracle_g1_fixed_base_mul": [_u64p, _u64p, sz, _u64p, ctypes.c_int],
+        "oracle_msm_g1": [_u64p, _u64p, sz, _u64p, ctypes.c_int],
+        "oracle_ntt_fr": [_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int],
+        "oracle_spmv_fr": [_u32p, _u32p, _u64p, _u64p, _u64p, sz],
+    }.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = None
+    lib.oracle_g1_to_affine.argtypes = [_u64p, _u64p]
+    lib.oracle_g1_to_affine.restype = ctypes.c_int
+    lib.oracle_g1_is_on_curve.argtypes = [_u64p]
+    lib.oracle_g1_is_on_curve.restype = ctypes.c_int
+    lib.oracle_msm_window.argtypes = [sz]
+    lib.oracle_msm_window.restype = ctypes.c_uint
+    lib.oracle_max_threads.restype = ctypes.c_int
+    return lib
+
+
+def p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u32p)
+
+
+# ---- int <-> limb arrays
+def ints_to_limbs(vals, nlimbs):
+    out = np.empty((len(vals), nlimbs), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for k in range(nlimbs):
+            out[i, k] = (v >> (64 * k)) & M64
+    return out
+
+
+def limbs_to_ints(arr):
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, arr.shape[-1])
+    return [sum(int(arr[i, k]) << (64 * k) for k in range(arr.shape[1])) for i in range(arr.shape[0])]
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def h2i(s):
+    return int(s, 16)
+
+
+class Oracle:
+    """numpy-level convenience API over the C oracle."""
+
+    def __init__(self):
+        self.lib = load()
+
+    # Fr / Fq conversions
+    def fr_to_mont(self, std):
+        out = np.empty_like(std)
+        self.lib.oracle_fr_to_mont(p64(std), p64(out), std.shape[0])
+        return out
+
+    def fr_from_mont(self, m):
+        out = np.empty_like(m)
+        self.lib.oracle_fr_from_mont(p64(m), p64(out), m.shape[0])
+        return out
+
+    def fq_to_mont(self, std):
+        out = np.empty_like(std)
+        self.lib.oracle_fq_to_mont(p64(std), p64(out), std.shape[0])
+        return out
+
+    def fq_from_mont(self, m):
+        out = np.empty_like(m)
+        self.lib.oracle_fq_from_mont(p64(m), p64(out), m.shape[0])
+        return out
+
+    def fr_mont_from_ints(self, vals):
+        return self.fr_to_mont(ints_to_limbs(vals, 4))
+
+    def fr_ints_from_mont(self, m):
+        return limbs_to_ints(self.fr_from_mont(np.ascontiguousarray(m)))
+
+    # points: list of (x, y) ints or None -> (n, 12) Montgomery
+    def points_to_mont(self, pts):
+        std = np.zeros((len(pts) * 2, 6), dtype=np.uint64)
+        for i, P in enumerate(pts):
+            if P is not None:
+                std[2 * i] = ints_to_limbs([P[0]], 6)[0]
+                std[2 * i + 1] = ints_to_limbs([P[1]], 6)[0]
+        m = self.fq_to_mont(std)
+        return np.ascontiguousarray(m.reshape(len(pts), 12))
+
+    def points_from_mont(self, m):
+        m = np.ascontiguousarray(m).reshape(-1, 12)
+        std = self.fq_from_mont(np.ascontiguousarray(m.reshape(-1, 6)))
+        v = limbs_to_ints(std)
+        out = []
+        for i in range(m.shape[0]):
+            x, y = v[2 * i], v[2 * i + 1]
+            out.append(None if x == 0 and y == 0 else (x, y))
+        return out
+
+    def jac_to_affine_int(self, jac18):
+        aff = np.zeros(12, dtype=np.uint64)
+        inf = self.lib.oracle_g1_to_affine(p64(np.ascontiguousarray(jac18)), p64(aff))
+        if inf:
+            return None
+        return self.points_from_mont(aff.reshape(1, 12))[0]
+
+    def msm(self, bases_mont, scalars_std, threads=1):
+        n = scalars_std.shape[0]
+        out = np.zeros(18, dtype=np.uint64)
+        self.lib.oracle_msm_g1(p64(bases_mont), p64(scalars_std), n, p64(out), threads)
+        return out
+
+    def ntt(self, data_mont, log_n, inverse=0, coset=0, threads=1):
+        d = np.ascontiguousarray(data_mont).copy()
+        self.lib.oracle_ntt_fr(p64(d), log_n, inverse, coset, threads)
+        return d
+
+    def spmv(self, rowptr, col, val_mont, z_mont):
+        rows = len(rowptr) - 1
+        out = np.zeros((rows, 4), dtype=np.uint64)
+        self.lib.oracle_spmv_fr(p32(rowptr), p32(col), p64(val_mont), p64(z_mont), p64(out), rows)
+        return out
+
+    def fixed_base_mul(self, base_mont12, scalars_std, threads=None):
+        n = scalars_std.shape[0]
+        out = np.zeros((n, 12), dtype=np.uint64)
+        if threads is None:
+            threads = self.lib.oracle_max_threads()
+        self.lib.oracle_g1_fixed_base_mul(p64(base_mont12), p64(scalars_std), n, p64(out), threads)
+        return out
+
+    def srs_bases(self, n, tau, gen_mont12):
+        """P_i = [tau^i] G, i < n — the SRS shape KZG10::setup produces (bench/test inputs)."""
+        pw = np.empty((n, 4), dtype=np.uint64)
+        # powers of tau via the oracle's Fr arithmetic (Montgomery), then back to standard form
+        cur = self.fr_mont_from_ints([1])
+        t = self.fr_mont_from_ints([tau])
+        # doubling trick: pw[0:k] known -> pw[k:2k] = pw[0:k] * tau^k
+        pwm = np.empty((n, 4), dtype=np.uint64)
+        pwm[0] = cur[0]
+        k = 1
+        tk = t.copy()
+        while k < n:
+            m = min(k, n - k)
+            rep = np.ascontiguousarray(np.repeat(tk, m, axis=0))
+            seg = np.ascontiguousarray(pwm[:m])
+            out = np.empty((m, 4), dtype=np.uint64)
+            self.lib.oracle_fr_mul(p64(seg), p64(rep), p64(out), m)
+            pwm[k:k + m] = out
+            k += m
+            tk2 = np.empty_like(tk)
+            self.lib.oracle_fr_mul(p64(tk), p64(tk), p64(tk2), 1)
+            tk = tk2
+        pw = self.fr_from_mont(pwm)
+        return self.fixed_base_mul(gen_mont12, pw)
