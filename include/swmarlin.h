@@ -1,0 +1,123 @@
+/* swmarlin.h — C ABI of libswmarlin.so: the MI355X-native (gfx950 HIP) replacement for the arithmetic that
+ * simpleworks' Marlin wrapper delegates to arkworks.
+ *
+ * Drop-in boundary.  The reference's Rust surface
+ *     /root/reference/src/marlin/mod.rs:33-94            generate_rand, generate_universal_srs, generate_proof,
+ *                                                        verify_proof, generate_proving_and_verifying_keys
+ *     /root/reference/src/marlin/serialization.rs:5-45   (de)serialisers
+ * stays source compatible; a thin Rust shim copies arkworks values into packed limb buffers and
+ * binds exactly the entry points declared here.  No torch / C++ types cross this boundary: plain pointers, sizes
+ * and opaque handles only.
+ *
+ * Conventions
+ *   - every function returns an int status: SWM_OK (0) or a negative SWM_ERR_* code; swm_strerror() names it and
+ *     swm_last_error(ctx) carries detail.  Nothing throws or aborts across the ABI (src/lib.rs:28 forbids panics).
+ *   - Fr element  = 4 x uint64 little-endian limbs (ark-ff BigInteger256); Montgomery form unless stated.
+ *   - Fq element  = 6 x uint64 limbs, Montgomery form.  G1 affine = x,y (12 limbs), infinity encoded as x = y = 0.
+ *   - G1 Jacobian = X,Y,Z (18 limbs, Montgomery), infinity has Z = 0 — what ark-ec's G1Projective holds.
+ *   - the caller owns every host buffer for the duration of a call; the library never retains host pointers.
+ *   - functions suffixed _dev take DEVICE pointers (hipMalloc'd or a torch tensor's data_ptr) and enqueue on the
+ *     context's stream without a host copy of the bulk data; the plain forms take HOST pointers and stage.
+ *   - a context is bound to one GPU and one HIP stream; use one context per host thread.
+ *   - there is NO CPU fallback: every compute entry point fails with SWM_ERR_NO_DEVICE when no gfx950 GPU is usable.
+ */
+#ifndef SWMARLIN_H
+#define SWMARLIN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWM_OK 0
+#define SWM_ERR_INVALID_ARG (-1)
+#define SWM_ERR_NO_DEVICE (-2)
+#define SWM_ERR_HIP (-3)
+#define SWM_ERR_OOM (-4)
+#define SWM_ERR_UNSATISFIED (-5)      /* witness does not satisfy the constraint system (prove-time failure) */
+#define SWM_ERR_INDEX_TOO_LARGE (-6)  /* SRS too small for the circuit (ark-marlin Error::IndexTooLarge) */
+#define SWM_ERR_SERIALIZATION (-7)
+#define SWM_ERR_MISMATCH (-8)         /* instance does not match index / key */
+#define SWM_ERR_INTERNAL (-9)
+
+typedef struct swm_ctx swm_ctx;
+typedef struct swm_bases swm_bases;
+
+/* ---------------------------------------------------------------------------------------------- context */
+int swm_version(void);
+const char *swm_strerror(int code);
+/* Creates a context on HIP device `device` with its own stream. */
+int swm_init(int device, swm_ctx **out);
+void swm_destroy(swm_ctx *ctx);
+const char *swm_last_error(swm_ctx *ctx);
+/* Enqueue on an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own stream. */
+int swm_set_stream(swm_ctx *ctx, void *hip_stream);
+int swm_synchronize(swm_ctx *ctx);
+/* device memory helpers so that a caller without a HIP binding can keep operands resident in HBM */
+int swm_malloc(swm_ctx *ctx, size_t bytes, void **dptr);
+int swm_free(swm_ctx *ctx, void *dptr);
+int swm_memcpy_h2d(swm_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int swm_memcpy_d2h(swm_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------- K1: G1 MSM
+ * Replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) (ark-ec 0.3.0), reached from
+ * src/marlin/mod.rs:75 (prove) and :92 (index) through ark_poly_commit::kzg10::KZG10::commit / open.
+ * The result is the same group element arkworks computes (compare after affine normalisation). */
+/* Upload n affine bases (n x 12 limbs, Montgomery) once; they stay resident in HBM (SRS powers [tau^i]G). */
+int swm_srs_upload(swm_ctx *ctx, const uint64_t *xy, size_t n, swm_bases **out);
+int swm_srs_free(swm_ctx *ctx, swm_bases *bases);
+size_t swm_srs_len(const swm_bases *bases);
+/* out_jac = sum_i scalars[i] * bases[offset + i].  scalars: n x 4 limbs, STANDARD form (what arkworks passes:
+ * p.coeffs.map(|s| s.into_repr())), host memory. */
+int swm_msm_g1(swm_ctx *ctx, const swm_bases *bases, size_t offset, const uint64_t *scalars, size_t n,
+               uint64_t out_jac[18]);
+/* same with the scalars already in HBM; scalars_montgomery != 0 means they are Montgomery-form Fr (polynomial
+ * coefficients as the NTT leaves them) and are converted on the fly. */
+int swm_msm_g1_dev(swm_ctx *ctx, const swm_bases *bases, size_t offset, const void *d_scalars, size_t n,
+                   int scalars_montgomery, uint64_t out_jac[18]);
+/* Jacobian -> affine on the host (x = y = 0 for infinity); returns 1 in *is_inf for the identity. */
+int swm_g1_normalize(const uint64_t jac[18], uint64_t out_xy[12], int *is_inf);
+
+/* ---------------------------------------------------------------------------------------------- K2: Fr NTT
+ * Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (ark-poly 0.3.0):
+ * natural order in, natural order out, size 2^log_n, root = TWO_ADIC_ROOT^(2^(47-log_n)); inverse scales by 1/n;
+ * coset pre-scales coefficient i by 22^i (forward) / post-scales by 22^-i (inverse). */
+int swm_ntt_fr(swm_ctx *ctx, uint64_t *data, unsigned log_n, int inverse, int coset);
+int swm_ntt_fr_dev(swm_ctx *ctx, void *d_data, unsigned log_n, int inverse, int coset);
+
+/* ---------------------------------------------------------------------------------------------- K3: R1CS mat-vec
+ * Replaces the row-wise inner products of ark-marlin's prover_init (z_A = A z, z_B = B z) and the evaluation
+ * inside ConstraintSystem::is_satisfied (src/merkle_tree/simple_merkle_tree.rs:197-199).
+ * CSR: rowptr[rows+1], col[nnz] (uint32), val[nnz] (Fr Montgomery); z: dense Fr vector; out: rows Fr. */
+int swm_spmv_fr(swm_ctx *ctx, const uint32_t *rowptr, const uint32_t *col, const uint64_t *val, const uint64_t *z,
+                size_t z_len, uint64_t *out, size_t rows, size_t nnz);
+int swm_spmv_fr_dev(swm_ctx *ctx, const void *d_rowptr, const void *d_col, const void *d_val, const void *d_z,
+                    void *d_out, size_t rows);
+
+/* ---------------------------------------------------------------------------------------------- K4: support kernels
+ * ark_ff::batch_inversion (zeros stay zero) and pointwise products, on Montgomery Fr vectors. */
+int swm_batch_inverse_fr(swm_ctx *ctx, uint64_t *data, size_t n);
+int swm_batch_inverse_fr_dev(swm_ctx *ctx, void *d_data, size_t n);
+int swm_vec_mul_fr(swm_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int swm_vec_mul_fr_dev(swm_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+
+/* ---------------------------------------------------------------------------------------------- measurement
+ * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
+ * kernel launch is bracketed by hipEventRecord on the stream it is launched on.  swm_profile_json writes
+ * {"kernels":[{"name":..,"calls":..,"total_ms":..,"avg_ms":..}, ...]} into buf (NUL-terminated). */
+int swm_profile_enable(swm_ctx *ctx, int on);
+int swm_profile_reset(swm_ctx *ctx);
+int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);
+
+/* Device self-test of the field / curve primitives the kernels are built from: computes a[i]*b[i] in Fq (which = 0),
+ * or in Fr (which = 1), element-wise on the GPU.  Inputs/outputs are host buffers in Montgomery form. */
+int swm_selftest_mul(swm_ctx *ctx, int which, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* out[i] = jacobian(a[i] (+) b[i]) with a, b affine (n x 12 limbs): exercises the mixed/XYZZ adders incl. doubling. */
+int swm_selftest_g1_add(swm_ctx *ctx, const uint64_t *a_xy, const uint64_t *b_xy, uint64_t *out_jac, size_t n);
+/* Throughput probe: `iters` dependent Montgomery multiplications per thread on `threads` threads; returns ms. */
+int swm_selftest_mul_throughput(swm_ctx *ctx, int which, size_t threads, int iters, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,268 @@
+"""ctypes binding of libswmarlin.so (include/swmarlin.h).  The product path: every call here ends in a
+hand-written gfx950 kernel.  Missing library or missing GPU is an error, never a silent fallback."""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswmarlin.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+
+# name -> (restype, argtypes): every symbol include/swmarlin.h declares
+ABI = {
+    "swm_version": (_int, []),
+    "swm_strerror": (ctypes.c_char_p, [_int]),
+    "swm_init": (_int, [_int, ctypes.POINTER(_vp)]),
+    "swm_destroy": (None, [_vp]),
+    "swm_last_error": (ctypes.c_char_p, [_vp]),
+    "swm_set_stream": (_int, [_vp, _vp]),
+    "swm_synchronize": (_int, [_vp]),
+    "swm_malloc": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "swm_free": (_int, [_vp, _vp]),
+    "swm_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "swm_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "swm_srs_upload": (_int, [_vp, _u64p, _sz, ctypes.POINTER(_vp)]),
+    "swm_srs_free": (_int, [_vp, _vp]),
+    "swm_srs_len": (_sz, [_vp]),
+    "swm_msm_g1": (_int, [_vp, _vp, _sz, _u64p, _sz, _u64p]),
+    "swm_msm_g1_dev": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _u64p]),
+    "swm_g1_normalize": (_int, [_u64p, _u64p, ctypes.POINTER(_int)]),
+    "swm_ntt_fr": (_int, [_vp, _u64p, ctypes.c_uint, _int, _int]),
+    "swm_ntt_fr_dev": (_int, [_vp, _vp, ctypes.c_uint, _int, _int]),
+    "swm_spmv_fr": (_int, [_vp, _u32p, _u32p, _u64p, _u64p, _sz, _u64p, _sz, _sz]),
+    "swm_spmv_fr_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "swm_batch_inverse_fr": (_int, [_vp, _u64p, _sz]),
+    "swm_batch_inverse_fr_dev": (_int, [_vp, _vp, _sz]),
+    "swm_vec_mul_fr": (_int, [_vp, _u64p, _u64p, _u64p, _sz]),
+    "swm_vec_mul_fr_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "swm_profile_enable": (_int, [_vp, _int]),
+    "swm_profile_reset": (_int, [_vp]),
+    "swm_profile_json": (_int, [_vp, ctypes.c_char_p, _sz]),
+    "swm_selftest_mul": (_int, [_vp, _int, _u64p, _u64p, _u64p, _sz]),
+    "swm_selftest_g1_add": (_int, [_vp, _u64p, _u64p, _u64p, _sz]),
+    "swm_selftest_mul_throughput": (_int, [_vp, _int, _sz, _int, ctypes.POINTER(ctypes.c_float)]),
+}
+
+
+class SwmError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (what, _strerror(code), code, (": " + detail) if detail else ""))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libswmarlin.so and types every exported symbol.  Raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libswmarlin.so is not built (run __graft_entry__.build() or `make -C simpleworks_amd/csrc`); "
+                               "simpleworks_amd has no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _strerror(code):
+    try:
+        return load_library().swm_strerror(code).decode()
+    except Exception:
+        return "error"
+
+
+def _p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expected a C-contiguous uint64 array"
+    return a.ctypes.data_as(_u64p)
+
+
+def _p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"], "expected a C-contiguous uint32 array"
+    return a.ctypes.data_as(_u32p)
+
+
+class DeviceBuffer:
+    """An HBM allocation owned by a Context (freed with it or explicitly)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = _vp()
+        ctx._check(ctx.lib.swm_malloc(ctx.h, nbytes, ctypes.byref(p)), "swm_malloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.swm_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes), "swm_memcpy_h2d")
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.swm_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), "swm_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.swm_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Bases:
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.h, self.n = ctx, handle, n
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.swm_srs_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One GPU + one HIP stream (swm_ctx).  Raises SwmError(SWM_ERR_NO_DEVICE) when no MI355X is usable."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.swm_init(device, ctypes.byref(h))
+        if rc != 0:
+            raise SwmError(rc, "swm_init")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.swm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SwmError(rc, what, self.lib.swm_last_error(self.h).decode(errors="replace"))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.swm_set_stream(self.h, stream_ptr), "swm_set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.swm_synchronize(self.h), "swm_synchronize")
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 64)).upload(arr)
+
+    # ---- K1
+    def srs_upload(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 12)
+        h = _vp()
+        self._check(self.lib.swm_srs_upload(self.h, _p64(xy), xy.shape[0], ctypes.byref(h)), "swm_srs_upload")
+        return Bases(self, h, xy.shape[0])
+
+    def msm_g1(self, bases, scalars_std, offset=0):
+        sc = np.ascontiguousarray(scalars_std, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(18, dtype=np.uint64)
+        self._check(self.lib.swm_msm_g1(self.h, bases.h, offset, _p64(sc), sc.shape[0], _p64(out)), "swm_msm_g1")
+        return out
+
+    def msm_g1_dev(self, bases, d_scalars, n, montgomery, offset=0):
+        out = np.zeros(18, dtype=np.uint64)
+        ptr = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
+        self._check(self.lib.swm_msm_g1_dev(self.h, bases.h, offset, ptr, n, 1 if montgomery else 0, _p64(out)),
+                    "swm_msm_g1_dev")
+        return out
+
+    def g1_normalize(self, jac):
+        jac = np.ascontiguousarray(jac, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
+        inf = _int(0)
+        self._check(self.lib.swm_g1_normalize(_p64(jac), _p64(out), ctypes.byref(inf)), "swm_g1_normalize")
+        return out, bool(inf.value)
+
+    # ---- K2
+    def ntt_fr(self, data_mont, log_n, inverse=False, coset=False):
+        d = np.ascontiguousarray(data_mont, dtype=np.uint64).copy()
+        assert d.size == 4 << log_n
+        self._check(self.lib.swm_ntt_fr(self.h, _p64(d), log_n, int(inverse), int(coset)), "swm_ntt_fr")
+        return d
+
+    def ntt_fr_dev(self, dbuf, log_n, inverse=False, coset=False):
+        ptr = dbuf.ptr if isinstance(dbuf, DeviceBuffer) else int(dbuf)
+        self._check(self.lib.swm_ntt_fr_dev(self.h, ptr, log_n, int(inverse), int(coset)), "swm_ntt_fr_dev")
+
+    # ---- K3
+    def spmv_fr(self, rowptr, col, val_mont, z_mont):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        val = np.ascontiguousarray(val_mont, dtype=np.uint64).reshape(-1, 4)
+        z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(-1, 4)
+        rows = rowptr.shape[0] - 1
+        out = np.zeros((rows, 4), dtype=np.uint64)
+        self._check(self.lib.swm_spmv_fr(self.h, _p32(rowptr), _p32(col) if col.size else _p32(np.zeros(1, np.uint32)),
+                                         _p64(val) if val.size else _p64(np.zeros(4, np.uint64)), _p64(z), z.shape[0],
+                                         _p64(out), rows, col.shape[0]), "swm_spmv_fr")
+        return out
+
+    # ---- K4
+    def batch_inverse_fr(self, data_mont):
+        d = np.ascontiguousarray(data_mont, dtype=np.uint64).reshape(-1, 4).copy()
+        self._check(self.lib.swm_batch_inverse_fr(self.h, _p64(d), d.shape[0]), "swm_batch_inverse_fr")
+        return d
+
+    def vec_mul_fr(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty_like(a)
+        self._check(self.lib.swm_vec_mul_fr(self.h, _p64(a), _p64(b), _p64(out), a.shape[0]), "swm_vec_mul_fr")
+        return out
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self._check(self.lib.swm_profile_enable(self.h, int(on)), "swm_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.swm_profile_reset(self.h), "swm_profile_reset")
+
+    def profile(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.swm_profile_json(self.h, buf, len(buf)), "swm_profile_json")
+        return {k["name"]: k for k in json.loads(buf.value.decode())["kernels"]}
+
+    # ---- self tests
+    def selftest_mul(self, which, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.empty_like(a)
+        self._check(self.lib.swm_selftest_mul(self.h, which, _p64(a), _p64(b), _p64(out), a.shape[0]), "swm_selftest_mul")
+        return out
+
+    def selftest_g1_add(self, a_xy, b_xy):
+        a = np.ascontiguousarray(a_xy, dtype=np.uint64).reshape(-1, 12)
+        b = np.ascontiguousarray(b_xy, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros((a.shape[0], 18), dtype=np.uint64)
+        self._check(self.lib.swm_selftest_g1_add(self.h, _p64(a), _p64(b), _p64(out), a.shape[0]), "swm_selftest_g1_add")
+        return out
+
+    def selftest_mul_throughput(self, which, threads, iters):
+        ms = ctypes.c_float(0)
+        self._check(self.lib.swm_selftest_mul_throughput(self.h, which, threads, iters, ctypes.byref(ms)),
+                    "swm_selftest_mul_throughput")
+        return ms.value

@@ -1,0 +1,407 @@
+// capi.hip — the extern "C" boundary of libswmarlin.so (declared in include/swmarlin.h).
+// Host-side plumbing only: argument checks, staging of host buffers into HBM, status codes.  The kernels live in
+// msm.hip / ntt.hip / vec.hip.  Nothing here falls back to a CPU implementation: without a usable gfx950 device
+// swm_init fails with SWM_ERR_NO_DEVICE and every compute entry point needs a context.
+#include <stdarg.h>
+#include <string.h>
+#include <algorithm>
+#include "context.h"
+#include "g1.cuh"
+
+namespace swm {
+int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result);
+int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
+             size_t rows);
+int vec_mul_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+int batch_inverse_run(swm_ctx* ctx, void* d, size_t n);
+int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n);
+int selftest_chain_run(swm_ctx* ctx, int which, void* out, size_t threads, int iters);
+int selftest_g1_add_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+
+int set_err(swm_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
+    DevBuf& b = ctx->scratch[name];
+    if (b.cap < bytes) {
+        if (b.p) {
+            // in-flight kernels may still read the old buffer
+            SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SWM_HIP(ctx, hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t cap = bytes + bytes / 8 + 256;
+        SWM_HIP(ctx, hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return SWM_OK;
+}
+
+static hipEvent_t get_event(swm_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(swm_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return;
+    ProfPending p;
+    p.name = name;
+    p.e0 = get_event(ctx);
+    p.e1 = get_event(ctx);
+    (void)hipEventRecord(p.e0, ctx->stream);
+    ctx->pending.push_back(p);
+}
+void prof_end(swm_ctx* ctx) {
+    if (!ctx->profiling || ctx->pending.empty()) return;
+    (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
+    if (ctx->pending.size() > 4096) prof_flush(ctx);
+}
+void prof_flush(swm_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        (void)hipEventSynchronize(p.e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.e0, p.e1);
+        ProfAgg& a = ctx->prof[p.name];
+        a.calls++;
+        a.ms += ms;
+        ctx->event_pool.push_back(p.e0);
+        ctx->event_pool.push_back(p.e1);
+    }
+    ctx->pending.clear();
+}
+}  // namespace swm
+
+using namespace swm;
+
+extern "C" {
+
+int swm_version(void) { return 100; }
+
+const char* swm_strerror(int code) {
+    switch (code) {
+        case SWM_OK: return "ok";
+        case SWM_ERR_INVALID_ARG: return "invalid argument";
+        case SWM_ERR_NO_DEVICE: return "no usable gfx950 (MI355X) device: libswmarlin has no CPU fallback";
+        case SWM_ERR_HIP: return "HIP runtime error";
+        case SWM_ERR_OOM: return "out of device memory";
+        case SWM_ERR_UNSATISFIED: return "constraint system is not satisfied by the witness";
+        case SWM_ERR_INDEX_TOO_LARGE: return "universal SRS too small for this index";
+        case SWM_ERR_SERIALIZATION: return "serialization error";
+        case SWM_ERR_MISMATCH: return "instance does not match index";
+        case SWM_ERR_INTERNAL: return "internal error";
+        default: return "unknown error";
+    }
+}
+
+int swm_init(int device, swm_ctx** out) {
+    if (!out) return SWM_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return SWM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SWM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SWM_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SWM_ERR_NO_DEVICE;  // code objects are gfx950 only
+    swm_ctx* ctx = new swm_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return SWM_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return SWM_OK;
+}
+
+void swm_destroy(swm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_flush(ctx);
+    for (auto& kv : ctx->scratch)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->ntt_tables) {
+        (void)hipFree(kv.second.lo);
+        (void)hipFree(kv.second.hi);
+    }
+    for (auto& kv : ctx->ntt_small) (void)hipFree(kv.second);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* swm_last_error(swm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int swm_set_stream(swm_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SWM_OK;
+}
+int swm_synchronize(swm_ctx* ctx) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+int swm_malloc(swm_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipSetDevice(ctx->device));
+    SWM_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return SWM_OK;
+}
+int swm_free(swm_ctx* ctx, void* dptr) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SWM_HIP(ctx, hipFree(dptr));
+    return SWM_OK;
+}
+int swm_memcpy_h2d(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+int swm_memcpy_d2h(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) {
+    if (!ctx || !xy || !out || n == 0) return set_err(ctx, SWM_ERR_INVALID_ARG, "srs_upload: bad arguments");
+    swm_bases* b = new swm_bases();
+    b->n = n;
+    hipError_t e = hipMalloc(&b->d_points, n * sizeof(G1Affine));
+    if (e != hipSuccess) {
+        delete b;
+        return set_err(ctx, SWM_ERR_OOM, "srs_upload: %s", hipGetErrorString(e));
+    }
+    e = hipMemcpyAsync(b->d_points, xy, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(b->d_points);
+        delete b;
+        return set_err(ctx, SWM_ERR_HIP, "srs_upload: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return SWM_OK;
+}
+int swm_srs_free(swm_ctx* ctx, swm_bases* bases) {
+    if (!ctx || !bases) return SWM_ERR_INVALID_ARG;
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SWM_HIP(ctx, hipFree(bases->d_points));
+    delete bases;
+    return SWM_OK;
+}
+size_t swm_srs_len(const swm_bases* bases) { return bases ? bases->n : 0; }
+
+static void write_jac(const G1XYZZ& r, uint64_t out_jac[18]) {
+    G1Jac j = g1_to_jacobian(r);
+    memcpy(out_jac, &j, sizeof(j));
+}
+
+int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const void* d_scalars, size_t n,
+                   int scalars_montgomery, uint64_t out_jac[18]) {
+    if (!ctx || !bases || !out_jac || (n && !d_scalars)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: bad arguments");
+    if (offset > bases->n || n > bases->n - offset)
+        return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: %zu scalars at offset %zu exceed %zu bases", n, offset, bases->n);
+    G1XYZZ r;
+    SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset, d_scalars, n,
+                    scalars_montgomery, &r));
+    write_jac(r, out_jac);
+    return SWM_OK;
+}
+
+int swm_msm_g1(swm_ctx* ctx, const swm_bases* bases, size_t offset, const uint64_t* scalars, size_t n,
+               uint64_t out_jac[18]) {
+    if (!ctx || !bases || !out_jac || (n && !scalars)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: bad arguments");
+    void* d = nullptr;
+    SWM_TRY(scratch(ctx, "stage.scalars", n * 32 + 32, &d));
+    if (n) SWM_HIP(ctx, hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return swm_msm_g1_dev(ctx, bases, offset, d, n, 0, out_jac);
+}
+
+int swm_g1_normalize(const uint64_t jac[18], uint64_t out_xy[12], int* is_inf) {
+    if (!jac || !out_xy) return SWM_ERR_INVALID_ARG;
+    G1Jac j;
+    memcpy(&j, jac, sizeof(j));
+    G1Affine a = g1_to_affine(g1_from_jacobian(j));
+    memcpy(out_xy, &a, sizeof(a));
+    if (is_inf) *is_inf = g1_is_inf(a) ? 1 : 0;
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+int swm_ntt_fr_dev(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
+    if (!ctx || !d_data) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");
+    return ntt_run(ctx, d_data, log_n, inverse, coset);
+}
+int swm_ntt_fr(swm_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
+    if (!ctx || !data || log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");
+    size_t bytes = (size_t)32 << log_n;
+    void* d = nullptr;
+    SWM_TRY(scratch(ctx, "stage.ntt", bytes, &d));
+    SWM_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SWM_TRY(ntt_run(ctx, d, log_n, inverse, coset));
+    SWM_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+int swm_spmv_fr_dev(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z,
+                    void* d_out, size_t rows) {
+    if (!ctx || !d_rowptr || !d_out) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: bad arguments");
+    return spmv_run(ctx, d_rowptr, d_col, d_val, d_z, d_out, rows);
+}
+int swm_spmv_fr(swm_ctx* ctx, const uint32_t* rowptr, const uint32_t* col, const uint64_t* val, const uint64_t* z,
+                size_t z_len, uint64_t* out, size_t rows, size_t nnz) {
+    if (!ctx || !rowptr || !out || (nnz && (!col || !val || !z)))
+        return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: bad arguments");
+    if (rowptr[rows] != nnz) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: rowptr[rows] != nnz");
+    for (size_t k = 0; k < nnz; k++)
+        if (col[k] >= z_len) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: column index out of range");
+    char* d = nullptr;
+    size_t o_rowptr = 0, o_col = (rows + 1) * 4, o_val = o_col + nnz * 4;
+    o_val = (o_val + 31) & ~(size_t)31;
+    size_t o_z = o_val + nnz * 32, o_out = o_z + z_len * 32, total = o_out + rows * 32;
+    SWM_TRY(scratch(ctx, "stage.spmv", total + 64, (void**)&d));
+    SWM_HIP(ctx, hipMemcpyAsync(d + o_rowptr, rowptr, (rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+        SWM_HIP(ctx, hipMemcpyAsync(d + o_col, col, nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+        SWM_HIP(ctx, hipMemcpyAsync(d + o_val, val, nnz * 32, hipMemcpyHostToDevice, ctx->stream));
+        SWM_HIP(ctx, hipMemcpyAsync(d + o_z, z, z_len * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SWM_TRY(spmv_run(ctx, d + o_rowptr, d + o_col, d + o_val, d + o_z, d + o_out, rows));
+    SWM_HIP(ctx, hipMemcpyAsync(out, d + o_out, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+int swm_batch_inverse_fr_dev(swm_ctx* ctx, void* d_data, size_t n) {
+    if (!ctx || (n && !d_data)) return set_err(ctx, SWM_ERR_INVALID_ARG, "batch_inverse: bad arguments");
+    return batch_inverse_run(ctx, d_data, n);
+}
+int swm_batch_inverse_fr(swm_ctx* ctx, uint64_t* data, size_t n) {
+    if (!ctx || (n && !data)) return set_err(ctx, SWM_ERR_INVALID_ARG, "batch_inverse: bad arguments");
+    void* d = nullptr;
+    SWM_TRY(scratch(ctx, "stage.a", n * 32 + 32, &d));
+    SWM_HIP(ctx, hipMemcpyAsync(d, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    SWM_TRY(batch_inverse_run(ctx, d, n));
+    SWM_HIP(ctx, hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+int swm_vec_mul_fr_dev(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    if (!ctx || (n && (!a || !b || !out))) return set_err(ctx, SWM_ERR_INVALID_ARG, "vec_mul: bad arguments");
+    return vec_mul_run(ctx, a, b, out, n);
+}
+int swm_vec_mul_fr(swm_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx || (n && (!a || !b || !out))) return set_err(ctx, SWM_ERR_INVALID_ARG, "vec_mul: bad arguments");
+    char *da = nullptr, *db = nullptr;
+    SWM_TRY(scratch(ctx, "stage.a", n * 32 + 32, (void**)&da));
+    SWM_TRY(scratch(ctx, "stage.b", n * 32 + 32, (void**)&db));
+    SWM_HIP(ctx, hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    SWM_TRY(vec_mul_run(ctx, da, db, da, n));
+    SWM_HIP(ctx, hipMemcpyAsync(out, da, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+int swm_profile_enable(swm_ctx* ctx, int on) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    if (!on) prof_flush(ctx);
+    ctx->profiling = on != 0;
+    return SWM_OK;
+}
+int swm_profile_reset(swm_ctx* ctx) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    prof_flush(ctx);
+    ctx->prof.clear();
+    return SWM_OK;
+}
+int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || buflen < 32) return SWM_ERR_INVALID_ARG;
+    prof_flush(ctx);
+    std::string s = "{\"kernels\":[";
+    bool first = true;
+    for (auto& kv : ctx->prof) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s{\"name\":\"%s\",\"calls\":%d,\"total_ms\":%.6f,\"avg_ms\":%.6f}",
+                 first ? "" : ",", kv.first.c_str(), kv.second.calls, kv.second.ms,
+                 kv.second.calls ? kv.second.ms / kv.second.calls : 0.0);
+        s += line;
+        first = false;
+    }
+    s += "]}";
+    if (s.size() + 1 > buflen) return set_err(ctx, SWM_ERR_INVALID_ARG, "profile_json: buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return SWM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ self-tests
+int swm_selftest_mul(swm_ctx* ctx, int which, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx || !a || !b || !out) return SWM_ERR_INVALID_ARG;
+    size_t es = which == 0 ? 48 : 32;
+    char *da = nullptr, *db = nullptr;
+    SWM_TRY(scratch(ctx, "stage.a", n * es + 64, (void**)&da));
+    SWM_TRY(scratch(ctx, "stage.b", n * es + 64, (void**)&db));
+    SWM_HIP(ctx, hipMemcpyAsync(da, a, n * es, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync(db, b, n * es, hipMemcpyHostToDevice, ctx->stream));
+    SWM_TRY(selftest_mul_run(ctx, which, da, db, da, n));
+    SWM_HIP(ctx, hipMemcpyAsync(out, da, n * es, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+int swm_selftest_g1_add(swm_ctx* ctx, const uint64_t* a_xy, const uint64_t* b_xy, uint64_t* out_jac, size_t n) {
+    if (!ctx || !a_xy || !b_xy || !out_jac) return SWM_ERR_INVALID_ARG;
+    char *da = nullptr, *db = nullptr, *dc = nullptr;
+    SWM_TRY(scratch(ctx, "stage.a", n * 96 + 64, (void**)&da));
+    SWM_TRY(scratch(ctx, "stage.b", n * 96 + 64, (void**)&db));
+    SWM_TRY(scratch(ctx, "stage.c", n * 144 + 64, (void**)&dc));
+    SWM_HIP(ctx, hipMemcpyAsync(da, a_xy, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync(db, b_xy, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    SWM_TRY(selftest_g1_add_run(ctx, da, db, dc, n));
+    SWM_HIP(ctx, hipMemcpyAsync(out_jac, dc, n * 144, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+int swm_selftest_mul_throughput(swm_ctx* ctx, int which, size_t threads, int iters, float* ms) {
+    if (!ctx || !ms || threads % 256) return SWM_ERR_INVALID_ARG;
+    void* d = nullptr;
+    SWM_TRY(scratch(ctx, "stage.a", threads * 48 + 64, &d));
+    SWM_TRY(selftest_chain_run(ctx, which, d, threads, 8));  // warm-up
+    hipEvent_t e0, e1;
+    SWM_HIP(ctx, hipEventCreate(&e0));
+    SWM_HIP(ctx, hipEventCreate(&e1));
+    SWM_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    SWM_TRY(selftest_chain_run(ctx, which, d, threads, iters));
+    SWM_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    SWM_HIP(ctx, hipEventSynchronize(e1));
+    SWM_HIP(ctx, hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SWM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// context.h — swm_ctx: one GPU, one HIP stream, a growable HBM workspace, cached NTT twiddle tables and the
+// per-kernel HIP-event log behind swm_profile_*.  Internal to libswmarlin.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/swmarlin.h"
+
+namespace swm {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct NttTables {
+    // two-level powers of a base b: lo[i] = b^i (i < 1024), hi[i] = b^(1024 i)
+    void* lo = nullptr;
+    void* hi = nullptr;
+    size_t hi_len = 0;
+};
+
+struct ProfAgg {
+    int calls = 0;
+    double ms = 0;
+};
+struct ProfPending {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace swm
+
+struct swm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // named scratch buffers, grown on demand and reused between calls (kept resident: 288 GB of HBM)
+    std::map<std::string, swm::DevBuf> scratch;
+    // NTT root tables keyed by (log_n << 1 | inverse); coset tables keyed by inverse flag
+    std::map<uint64_t, swm::NttTables> ntt_tables;
+    std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
+    bool profiling = false;
+    std::map<std::string, swm::ProfAgg> prof;
+    std::vector<swm::ProfPending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct swm_bases {
+    void* d_points = nullptr;  // n x G1Affine (96 B, Montgomery)
+    size_t n = 0;
+};
+
+namespace swm {
+
+int set_err(swm_ctx* ctx, int code, const char* fmt, ...);
+// returns device pointer of a scratch buffer with at least `bytes` capacity (contents undefined)
+int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out);
+void prof_begin(swm_ctx* ctx, const char* name);
+void prof_end(swm_ctx* ctx);
+void prof_flush(swm_ctx* ctx);
+
+#define SWM_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return swm::set_err(ctx, e__ == hipErrorOutOfMemory ? SWM_ERR_OOM : SWM_ERR_HIP, "%s: %s",  \
+                                #call, hipGetErrorString(e__));                                         \
+    } while (0)
+
+#define SWM_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != SWM_OK) return rc__; \
+    } while (0)
+
+// launch wrapper: bracket with events when profiling is on
+#define SWM_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                      \
+    do {                                                                            \
+        swm::prof_begin(ctx, name);                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+        swm::prof_end(ctx);                                                         \
+        SWM_HIP(ctx, hipGetLastError());                                            \
+    } while (0)
+
+}  // namespace swm

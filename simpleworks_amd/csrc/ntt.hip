@@ -1,0 +1,250 @@
+// ntt.hip — K2: radix-2 NTT / iNTT over BLS12-377 Fr for gfx950 (MI355X).
+//
+// Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (ark-poly 0.3.0,
+// SURVEY.md A.3), reached from /root/reference/src/marlin/mod.rs:75,92.  Semantics kept: natural order in and
+// out, root = TWO_ADIC_ROOT^(2^(47-log n)), inverse scales by 1/n, coset variants scale coefficient i by 22^i
+// (before a forward transform) or 22^-i (after an inverse one).
+//
+// MI355X design: Stockham autosort in ceil(log n / 8) passes.  A workgroup stages a tile of R = 2^r strided
+// rows x 8 contiguous columns (256-B coalesced runs of 32-B elements, 64 KB of LDS at r = 8) and runs all r
+// butterfly levels of that tile in LDS; the inter-pass twiddle w_n^(k t), the coset scaling and the 1/n factor
+// are fused into the tile load / store, so each pass reads and writes every element exactly once
+// (2 x 32 B x n HBM bytes per pass; algorithmic bytes 64 B per element per transform).
+// Twiddles are not streamed from HBM: w^e is rebuilt from two small L2-resident tables (w^(e mod 1024),
+// w^(1024 (e div 1024))) with one extra multiply.
+#include "context.h"
+#include "ff.cuh"
+
+namespace swm {
+
+static constexpr int NTT_J = 8;         // contiguous columns per tile
+static constexpr int NTT_THREADS = 256;
+static constexpr unsigned NTT_MAX_LOG_R = 8;
+
+struct NttPassArgs {
+    const Fr* src;
+    Fr* dst;
+    unsigned log_n, log_r, log_ns;
+    const Fr* tw_small;   // w_R^e, e < R/2
+    const Fr* tw_lo;      // w_n^i, i < 1024
+    const Fr* tw_hi;      // w_n^(1024 i)
+    const Fr* cs_lo;      // g^i (or g^-i)
+    const Fr* cs_hi;
+    int coset_in;         // multiply input i by g^i while loading (first pass of a forward coset transform)
+    int scale_out;        // multiply output by n_inv (last pass of an inverse transform)
+    int coset_out;        // ... and by g^-i
+    Fr n_inv;
+};
+
+__device__ __forceinline__ Fr two_level_pow(const Fr* lo, const Fr* hi, uint64_t e) {
+    Fr a = lo[e & 1023];
+    uint64_t h = e >> 10;
+    if (h) a = fp_mul(a, hi[h]);
+    return a;
+}
+
+__device__ __forceinline__ unsigned bitrev_u(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+template <int J>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Fr* tile = reinterpret_cast<Fr*>(smem_raw);  // [R][J]
+    const unsigned R = 1u << a.log_r;
+    const uint64_t n = 1ull << a.log_n;
+    const uint64_t stride = n >> a.log_r;  // n / R
+    const uint64_t j0 = (uint64_t)blockIdx.x * J;
+    const uint64_t ns_mask = (1ull << a.log_ns) - 1;
+    const unsigned tw_shift = a.log_n - a.log_ns - a.log_r;  // w_{Ns R} = w_n^(2^tw_shift)
+    // ---- load (+ inter-pass twiddle, + coset scaling)
+    for (unsigned e = threadIdx.x; e < R * J; e += NTT_THREADS) {
+        unsigned jj = e % J, t = e / J;
+        uint64_t idx = j0 + jj + (uint64_t)t * stride;
+        Fr x = a.src[idx];
+        if (a.coset_in) x = fp_mul(x, two_level_pow(a.cs_lo, a.cs_hi, idx));
+        if (a.log_ns != 0 && t != 0) {
+            uint64_t k = (j0 + jj) & ns_mask;
+            if (k) x = fp_mul(x, two_level_pow(a.tw_lo, a.tw_hi, (k * t) << tw_shift));
+        }
+        tile[t * J + jj] = x;
+    }
+    __syncthreads();
+    // ---- r radix-2 DIF levels in LDS (natural in, bit-reversed rows out)
+    for (unsigned h = R >> 1; h >= 1; h >>= 1) {
+        unsigned tw_step = (R >> 1) / h;  // w_{2h}^pos = w_R^(pos * R/(2h))
+        for (unsigned bq = threadIdx.x; bq < (R >> 1) * J; bq += NTT_THREADS) {
+            unsigned jj = bq % J, q = bq / J;
+            unsigned pos = q & (h - 1), blk = q / h;
+            unsigned i0 = blk * 2 * h + pos, i1 = i0 + h;
+            Fr u = tile[i0 * J + jj], v = tile[i1 * J + jj];
+            tile[i0 * J + jj] = fp_add(u, v);
+            Fr d = fp_sub(u, v);
+            if (pos) d = fp_mul(d, a.tw_small[pos * tw_step]);
+            tile[i1 * J + jj] = d;
+        }
+        __syncthreads();
+    }
+    // ---- store (Stockham index map; + 1/n, + coset unscaling)
+    for (unsigned e = threadIdx.x; e < R * J; e += NTT_THREADS) {
+        unsigned jj, u;
+        if (a.log_ns == 0) {  // out[(j0+jj) R + u]: runs of R contiguous elements
+            u = e % R;
+            jj = e / R;
+        } else {              // out[(j/Ns) Ns R + k + u Ns]: runs of J contiguous elements
+            jj = e % J;
+            u = e / J;
+        }
+        uint64_t j = j0 + jj;
+        uint64_t k = j & ns_mask;
+        uint64_t o = ((j - k) << a.log_r) + k + ((uint64_t)u << a.log_ns);
+        Fr x = tile[bitrev_u(u, a.log_r) * J + jj];
+        if (a.scale_out) {
+            Fr s = a.n_inv;
+            if (a.coset_out) s = fp_mul(s, two_level_pow(a.cs_lo, a.cs_hi, o));
+            x = fp_mul(x, s);
+        }
+        a.dst[o] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- tables (host built)
+static Fr host_root_of_unity(unsigned log_n, bool inverse) {
+    Fr w;
+    const uint32_t root[8] = SWM_FR_ROOT47_MONT;
+    for (int i = 0; i < 8; i++) w.v[i] = root[i];
+    for (unsigned i = log_n; i < 47; i++) w = fp_sqr(w);
+    if (inverse) w = fp_inv(w);
+    return w;
+}
+
+static int upload_powers(swm_ctx* ctx, const Fr& base, size_t count, void** out) {
+    std::vector<Fr> h(count);
+    Fr cur = fp_one<Fr>();
+    for (size_t i = 0; i < count; i++) {
+        h[i] = cur;
+        cur = fp_mul(cur, base);
+    }
+    SWM_HIP(ctx, hipMalloc(out, count * sizeof(Fr)));
+    SWM_HIP(ctx, hipMemcpy(*out, h.data(), count * sizeof(Fr), hipMemcpyHostToDevice));
+    return SWM_OK;
+}
+
+static int two_level_tables(swm_ctx* ctx, const Fr& base, size_t max_exp, NttTables* t) {
+    SWM_TRY(upload_powers(ctx, base, 1024, &t->lo));
+    Fr b1024 = base;
+    for (int i = 0; i < 10; i++) b1024 = fp_sqr(b1024);
+    t->hi_len = (max_exp >> 10) + 1;
+    SWM_TRY(upload_powers(ctx, b1024, t->hi_len, &t->hi));
+    return SWM_OK;
+}
+
+static int get_root_tables(swm_ctx* ctx, unsigned log_n, int inverse, NttTables** out) {
+    uint64_t key = ((uint64_t)log_n << 1) | (inverse ? 1 : 0);
+    auto it = ctx->ntt_tables.find(key);
+    if (it == ctx->ntt_tables.end()) {
+        NttTables t;
+        SWM_TRY(two_level_tables(ctx, host_root_of_unity(log_n, inverse), 1ull << log_n, &t));
+        it = ctx->ntt_tables.emplace(key, t).first;
+    }
+    *out = &it->second;
+    return SWM_OK;
+}
+
+static int get_coset_tables(swm_ctx* ctx, unsigned log_n, int inverse, NttTables** out) {
+    uint64_t key = (1ull << 40) | (inverse ? 1 : 0);
+    auto it = ctx->ntt_tables.find(key);
+    if (it != ctx->ntt_tables.end() && it->second.hi_len < ((1ull << log_n) >> 10) + 1) {
+        (void)hipFree(it->second.lo);
+        (void)hipFree(it->second.hi);
+        ctx->ntt_tables.erase(it);
+        it = ctx->ntt_tables.end();
+    }
+    if (it == ctx->ntt_tables.end()) {
+        Fr g;
+        const uint32_t gm[8] = SWM_FR_GEN_MONT, gi[8] = SWM_FR_GEN_INV_MONT;
+        for (int i = 0; i < 8; i++) g.v[i] = inverse ? gi[i] : gm[i];
+        NttTables t;
+        unsigned cap = log_n < 20 ? 20 : log_n;  // build for at least 2^20 so that it is rarely rebuilt
+        SWM_TRY(two_level_tables(ctx, g, 1ull << cap, &t));
+        it = ctx->ntt_tables.emplace(key, t).first;
+    }
+    *out = &it->second;
+    return SWM_OK;
+}
+
+static int get_small_table(swm_ctx* ctx, unsigned log_r, int inverse, const Fr** out) {
+    uint64_t key = ((uint64_t)log_r << 1) | (inverse ? 1 : 0);
+    auto it = ctx->ntt_small.find(key);
+    if (it == ctx->ntt_small.end()) {
+        void* d = nullptr;
+        size_t cnt = log_r ? (1u << (log_r - 1)) : 1;
+        SWM_TRY(upload_powers(ctx, host_root_of_unity(log_r, inverse), cnt, &d));
+        it = ctx->ntt_small.emplace(key, d).first;
+    }
+    *out = reinterpret_cast<const Fr*>(it->second);
+    return SWM_OK;
+}
+
+// In-place (from the caller's view) transform of 2^log_n Montgomery Fr elements resident in HBM.
+int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
+    if (log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: log_n > 30 unsupported");
+    const uint64_t n = 1ull << log_n;
+    Fr* data = reinterpret_cast<Fr*>(d_data);
+    NttTables *rt = nullptr, *ct = nullptr;
+    SWM_TRY(get_root_tables(ctx, log_n, inverse, &rt));
+    if (coset) SWM_TRY(get_coset_tables(ctx, log_n, inverse, &ct));
+    Fr n_inv = fp_one<Fr>();
+    if (inverse) n_inv = fp_inv(fp_from_u64<Fr>(n));
+    // pass plan
+    unsigned npass = log_n <= NTT_MAX_LOG_R ? 1 : (log_n + NTT_MAX_LOG_R - 1) / NTT_MAX_LOG_R;
+    unsigned radices[8];
+    {
+        unsigned rem = log_n;
+        for (unsigned p = 0; p < npass; p++) {
+            unsigned r = (rem + (npass - p) - 1) / (npass - p);
+            radices[p] = r;
+            rem -= r;
+        }
+    }
+    Fr* tmp = nullptr;
+    SWM_TRY(scratch(ctx, "ntt.tmp", n * sizeof(Fr), (void**)&tmp));
+    // ping-pong so that the last pass lands in `data`
+    Fr* bufs[2] = {data, tmp};
+    int cur = 0;
+    if (npass % 2 == 1 && npass > 0) {
+        // odd number of passes: first pass data -> tmp would end in tmp; copy data to tmp first and start there
+        SWM_HIP(ctx, hipMemcpyAsync(tmp, data, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+        cur = 1;
+    }
+    unsigned log_ns = 0;
+    for (unsigned p = 0; p < npass; p++) {
+        NttPassArgs a;
+        a.src = bufs[cur];
+        a.dst = bufs[cur ^ 1];
+        a.log_n = log_n;
+        a.log_r = radices[p];
+        a.log_ns = log_ns;
+        SWM_TRY(get_small_table(ctx, a.log_r, inverse, &a.tw_small));
+        a.tw_lo = reinterpret_cast<const Fr*>(rt->lo);
+        a.tw_hi = reinterpret_cast<const Fr*>(rt->hi);
+        a.cs_lo = ct ? reinterpret_cast<const Fr*>(ct->lo) : nullptr;
+        a.cs_hi = ct ? reinterpret_cast<const Fr*>(ct->hi) : nullptr;
+        a.coset_in = (coset && !inverse && p == 0) ? 1 : 0;
+        a.scale_out = (inverse && p == npass - 1) ? 1 : 0;
+        a.coset_out = (coset && inverse && p == npass - 1) ? 1 : 0;
+        a.n_inv = n_inv;
+        uint64_t cols = n >> a.log_r;
+        if (npass == 1) {
+            size_t shmem = sizeof(Fr) << a.log_r;
+            if (shmem < 64) shmem = 64;
+            SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<1>, dim3((unsigned)cols), dim3(NTT_THREADS), shmem, a);
+        } else {
+            size_t shmem = (sizeof(Fr) * NTT_J) << a.log_r;
+            SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<NTT_J>, dim3((unsigned)(cols / NTT_J)), dim3(NTT_THREADS), shmem, a);
+        }
+        log_ns += a.log_r;
+        cur ^= 1;
+    }
+    return SWM_OK;
+}
+
+}  // namespace swm

@@ -1,0 +1,143 @@
+// vec.hip — K3 (R1CS sparse mat-vec) and K4 (batch inversion, pointwise products) over BLS12-377 Fr, plus the
+// device self-tests of the field / curve primitives.
+//
+// K3 replaces the row-wise inner products of ark-marlin's AHPForR1CS::prover_init (z_A = A z, z_B = B z; SURVEY.md
+// A.4) and ConstraintSystem::is_satisfied (/root/reference/src/merkle_tree/simple_merkle_tree.rs:197-199).
+// K4 replaces ark_ff::batch_inversion and the cfg_iter pointwise loops of ark-marlin's prover rounds.
+// All of it is HBM-bound integer work: one lane per row / element, 16-B vector loads, no LDS, no MFMA.
+// Algorithmic bytes: SpMV 68 B per non-zero + 36 B per row; vec_mul 96 B per element.
+#include "context.h"
+#include "g1.cuh"
+
+namespace swm {
+
+// CSR row-per-lane.  R1CS rows hold 0-3 non-zeros (gadget rows of shape 0*0 = a-b, booleanity rows, ...), so a
+// row-per-wave scheme would idle 60 lanes; lanes of a wave read consecutive rowptr/col/val ranges instead.
+__global__ void __launch_bounds__(256) spmv_rows(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
+                                                 const Fr* __restrict__ val, const Fr* __restrict__ z,
+                                                 Fr* __restrict__ out, size_t rows) {
+    size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t k = rowptr[r], e = rowptr[r + 1];
+    Fr acc = fp_zero<Fr>();
+    for (; k < e; k++) {
+        Fr c = val[k];
+        Fr zv = z[col[k]];
+        acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));  // coeff.is_one() shortcut as in prover_init
+    }
+    out[r] = acc;
+}
+
+__global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b,
+                                                      Fr* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = fp_mul(a[i], b[i]);
+}
+
+// Montgomery-trick inversion of BINV_CHUNK elements per lane (zeros stay zero, like ark_ff::batch_inversion).
+static constexpr int BINV_CHUNK = 16;
+__global__ void __launch_bounds__(256) batch_inverse_kernel(Fr* __restrict__ v, size_t n) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t lo = t * BINV_CHUNK;
+    if (lo >= n) return;
+    size_t hi = lo + BINV_CHUNK < n ? lo + BINV_CHUNK : n;
+    Fr pref[BINV_CHUNK];
+    Fr acc = fp_one<Fr>();
+#pragma unroll
+    for (int i = 0; i < BINV_CHUNK; i++) {
+        pref[i] = acc;
+        if (lo + i < hi) {
+            Fr x = v[lo + i];
+            if (!fp_is_zero(x)) acc = fp_mul(acc, x);
+        }
+    }
+    Fr inv = fp_inv(acc);
+#pragma unroll
+    for (int i = BINV_CHUNK - 1; i >= 0; i--) {
+        if (lo + i < hi) {
+            Fr x = v[lo + i];
+            if (!fp_is_zero(x)) {
+                v[lo + i] = fp_mul(inv, pref[i]);
+                inv = fp_mul(inv, x);
+            }
+        }
+    }
+}
+
+int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
+             size_t rows) {
+    if (rows == 0) return SWM_OK;
+    SWM_LAUNCH(ctx, "spmv_rows", spmv_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+               (const uint32_t*)d_rowptr, (const uint32_t*)d_col, (const Fr*)d_val, (const Fr*)d_z, (Fr*)d_out, rows);
+    return SWM_OK;
+}
+int vec_mul_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    if (n == 0) return SWM_OK;
+    unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    SWM_LAUNCH(ctx, "vec_mul", vec_mul_kernel, dim3(grid), dim3(256), 0, (const Fr*)a, (const Fr*)b, (Fr*)out, n);
+    return SWM_OK;
+}
+int batch_inverse_run(swm_ctx* ctx, void* d, size_t n) {
+    if (n == 0) return SWM_OK;
+    size_t threads = (n + BINV_CHUNK - 1) / BINV_CHUNK;
+    SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+               (Fr*)d, n);
+    return SWM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- self-tests
+template <class F>
+__global__ void __launch_bounds__(256) selftest_mul_kernel(const F* a, const F* b, F* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fp_mul(a[i], b[i]);
+}
+template <class F>
+__global__ void __launch_bounds__(256) selftest_mul_chain(F* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F a = fp_one<F>(), b = fp_one<F>();
+    a.v[0] ^= (uint32_t)i;
+    b.v[1] ^= (uint32_t)(i * 2654435761u);
+    for (int k = 0; k < iters; k++) {
+        a = fp_mul(a, b);
+        b = fp_mul(b, a);
+    }
+    out[i] = fp_add(a, b);
+}
+__global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a, const G1Affine* b, G1Jac* out,
+                                                              size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // exercise both adders: mixed (acc from a, += b) and full XYZZ add of (a + b) + (a + b), then - (a + b)
+    G1XYZZ acc = g1_from_affine(a[i]);
+    g1_add_mixed(acc, b[i]);
+    G1XYZZ twice = acc;
+    g1_add(twice, acc);           // doubling branch of the full adder
+    g1_add(twice, g1_neg(acc));   // back to a + b through the generic branch
+    out[i] = g1_to_jacobian(twice);
+}
+
+int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n) {
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (which == 0)
+        SWM_LAUNCH(ctx, "selftest_mul_fq", selftest_mul_kernel<Fq>, dim3(grid), dim3(256), 0, (const Fq*)a,
+                   (const Fq*)b, (Fq*)out, n);
+    else
+        SWM_LAUNCH(ctx, "selftest_mul_fr", selftest_mul_kernel<Fr>, dim3(grid), dim3(256), 0, (const Fr*)a,
+                   (const Fr*)b, (Fr*)out, n);
+    return SWM_OK;
+}
+int selftest_chain_run(swm_ctx* ctx, int which, void* out, size_t threads, int iters) {
+    unsigned grid = (unsigned)(threads / 256);
+    if (which == 0)
+        SWM_LAUNCH(ctx, "selftest_chain_fq", selftest_mul_chain<Fq>, dim3(grid), dim3(256), 0, (Fq*)out, iters);
+    else
+        SWM_LAUNCH(ctx, "selftest_chain_fr", selftest_mul_chain<Fr>, dim3(grid), dim3(256), 0, (Fr*)out, iters);
+    return SWM_OK;
+}
+int selftest_g1_add_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    SWM_LAUNCH(ctx, "selftest_g1_add", selftest_g1_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+               (const G1Affine*)a, (const G1Affine*)b, (G1Jac*)out, n);
+    return SWM_OK;
+}
+
+}  // namespace swm

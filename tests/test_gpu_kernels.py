@@ -1,0 +1,223 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every K1-K4 entry point of libswmarlin.so, called through the
+C ABI, against (a) the committed Python big-int fixtures and (b) the C oracle on seeded inputs.  Bit-exact: all
+arithmetic on this path is integer."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, golden, h2i, ints_to_limbs, limbs_to_ints, R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import simpleworks_amd as swm
+    c = swm.Context(0)
+    yield c
+    c.close()
+
+
+def _pt(p):
+    return None if p is None else (h2i(p[0]), h2i(p[1]))
+
+
+def _affine_of(ctx, orc, jac):
+    xy, inf = ctx.g1_normalize(jac)
+    if inf:
+        return None
+    return orc.points_from_mont(xy.reshape(1, 12))[0]
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+def test_device_field_mul_matches_golden_and_oracle(ctx, orc):
+    g = golden("fields.json")
+    cases = g["fq"]["cases"]
+    a = orc.fq_to_mont(ints_to_limbs([h2i(c["a"]) for c in cases], 6))
+    b = orc.fq_to_mont(ints_to_limbs([h2i(c["b"]) for c in cases], 6))
+    out = ctx.selftest_mul(0, a, b)
+    assert limbs_to_ints(orc.fq_from_mont(out)) == [h2i(c["mul"]) for c in cases]
+    cases = g["fr"]["cases"]
+    a = orc.fr_mont_from_ints([h2i(c["a"]) for c in cases])
+    b = orc.fr_mont_from_ints([h2i(c["b"]) for c in cases])
+    out = ctx.selftest_mul(1, a, b)
+    assert orc.fr_ints_from_mont(out) == [h2i(c["mul"]) for c in cases]
+    # bulk random against the C oracle
+    from pyref.prng import fr_array
+    x = fr_array(20000, 11)
+    y = fr_array(20000, 12)
+    from oracle_lib import p64
+    ref = np.empty_like(x)
+    orc.lib.oracle_fr_mul(p64(x), p64(y), p64(ref), x.shape[0])
+    assert np.array_equal(ctx.selftest_mul(1, x, y), ref)
+    # Fq bulk: build 6-limb values < q from Fr draws
+    xa = np.concatenate([fr_array(6000, 13), fr_array(6000, 14)[:, :2] >> np.uint64(8)], axis=1).copy()
+    xb = np.concatenate([fr_array(6000, 15), fr_array(6000, 16)[:, :2] >> np.uint64(8)], axis=1).copy()
+    xa[:, 5] &= np.uint64((1 << 56) - 1)
+    xb[:, 5] &= np.uint64((1 << 56) - 1)
+    ref = np.empty_like(xa)
+    orc.lib.oracle_fq_mul(p64(xa), p64(xb), p64(ref), xa.shape[0])
+    assert np.array_equal(ctx.selftest_mul(0, xa, xb), ref)
+
+
+def test_device_group_law(ctx, orc):
+    g = golden("g1.json")
+    a_pts = [_pt(c["a"]) for c in g["adds"]] + [_pt(c["a"]) for c in g["adds"]]
+    b_pts = [_pt(c["b"]) for c in g["adds"]] + [_pt(c["a"]) for c in g["adds"]]  # second half: P + P (doubling)
+    exp = [_pt(c["sum"]) for c in g["adds"]] + [_pt(c["dbl_a"]) for c in g["adds"]]
+    out = ctx.selftest_g1_add(orc.points_to_mont(a_pts), orc.points_to_mont(b_pts))
+    got = [_affine_of(ctx, orc, out[i]) for i in range(len(exp))]
+    assert got == exp
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def test_msm_golden(ctx, orc):
+    g = golden("msm.json")
+    srs = [_pt(p) for p in g["srs_bases"]]
+    srs_h = ctx.srs_upload(orc.points_to_mont(srs))
+    for c in g["cases"]:
+        if c["bases"] == "srs":
+            bases = srs_h
+        else:
+            bases = ctx.srs_upload(orc.points_to_mont([_pt(p) for p in c["bases"]]))
+        sc = ints_to_limbs([h2i(s) for s in c["scalars"]], 4)
+        res = _affine_of(ctx, orc, ctx.msm_g1(bases, sc))
+        assert res == _pt(c["result"]), c["name"]
+        if bases is not srs_h:
+            bases.free()
+    # offset into the resident SRS: sum_i s_i * P_{7+i}
+    c = g["cases"][3]  # uniform_31
+    sc = ints_to_limbs([h2i(s) for s in c["scalars"]], 4)
+    ref = orc.jac_to_affine_int(orc.msm(orc.points_to_mont(srs[7:7 + 31]), sc))
+    assert _affine_of(ctx, orc, ctx.msm_g1(srs_h, sc, offset=7)) == ref
+    srs_h.free()
+
+
+@pytest.mark.parametrize("log_n", [10, 13, 16])
+def test_msm_vs_oracle(ctx, orc, log_n):
+    from pyref.prng import fr_array
+    n = 1 << log_n
+    g = golden("msm.json")
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(g["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    sc = fr_array(n, 100 + log_n)
+    ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=8))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref
+    # Montgomery-form scalars resident in HBM (what the prover feeds after an iNTT)
+    d = ctx.to_device(orc.fr_to_mont(sc))
+    assert _affine_of(ctx, orc, ctx.msm_g1_dev(bh, d, n, True)) == ref
+    d.free()
+    # structured scalars: 25 % zeros, 25 % ones, 50 % uniform (bit-heavy witnesses, src/gadgets/traits.rs:150-164)
+    st = sc.copy()
+    st[0::4] = 0
+    st[1::4] = 0
+    st[1::4, 0] = 1
+    ref = orc.jac_to_affine_int(orc.msm(bases, st, threads=8))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, st)) == ref
+    if log_n <= 13:
+        ones = np.zeros_like(sc)
+        ones[:, 0] = 1
+        ref = orc.jac_to_affine_int(orc.msm(bases, ones, threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, ones)) == ref
+    bh.free()
+
+
+def test_msm_linearity_2_20(ctx, orc):
+    """Full-size property check (BASELINE config: 2^20 points): MSM(s) + MSM(t) == MSM(s + t mod r)."""
+    from pyref.prng import fr_array
+    from oracle_lib import p64
+    n = 1 << 20
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    s, t = fr_array(n, 201), fr_array(n, 202)
+    sm, tm = orc.fr_to_mont(s), orc.fr_to_mont(t)
+    um = np.empty_like(sm)
+    orc.lib.oracle_fr_add(p64(sm), p64(tm), p64(um), n)
+    u = orc.fr_from_mont(um)
+    js, jt, ju = ctx.msm_g1(bh, s), ctx.msm_g1(bh, t), ctx.msm_g1(bh, u)
+    ssum = np.zeros(18, dtype=np.uint64)
+    orc.lib.oracle_g1_add(p64(js), p64(jt), p64(ssum))
+    assert orc.jac_to_affine_int(ssum) == orc.jac_to_affine_int(ju)
+    assert orc.jac_to_affine_int(ju) is not None
+    bh.free()
+
+
+# ------------------------------------------------------------------------------------------------ K2
+def test_ntt_golden(ctx, orc):
+    g = golden("ntt.json")
+    for c in g["cases"]:
+        x = orc.fr_mont_from_ints([h2i(v) for v in c["in"]])
+        y = ctx.ntt_fr(x, c["log_n"], c["inverse"], c["coset"])
+        assert orc.fr_ints_from_mont(y) == [h2i(v) for v in c["out"]], c["name"]
+
+
+@pytest.mark.parametrize("log_n", [9, 10, 12, 15, 16, 17, 18, 20])
+def test_ntt_vs_oracle(ctx, orc, log_n):
+    from pyref.prng import fr_array
+    x = orc.fr_to_mont(fr_array(1 << log_n, 300 + log_n))
+    for inverse in (0, 1):
+        for coset in (0, 1):
+            ref = orc.ntt(x, log_n, inverse, coset, threads=8)
+            assert np.array_equal(ctx.ntt_fr(x, log_n, inverse, coset), ref), (log_n, inverse, coset)
+
+
+def test_ntt_roundtrip_2_22(ctx, orc):
+    from pyref.prng import fr_array
+    log_n = 22
+    x = fr_array(1 << log_n, 322)  # any reduced limbs are valid Montgomery residues
+    d = ctx.to_device(x)
+    ctx.ntt_fr_dev(d, log_n, False, True)
+    y = d.download(x.shape)
+    assert not np.array_equal(x, y)
+    ctx.ntt_fr_dev(d, log_n, True, True)
+    assert np.array_equal(d.download(x.shape), x)
+    d.free()
+
+
+# ------------------------------------------------------------------------------------------------ K3 / K4
+def test_spmv_golden_and_random(ctx, orc):
+    s = golden("misc.json")["spmv"]
+    rowptr, col = np.array(s["rowptr"], dtype=np.uint32), np.array(s["col"], dtype=np.uint32)
+    val, z = orc.fr_mont_from_ints([h2i(x) for x in s["val"]]), orc.fr_mont_from_ints([h2i(x) for x in s["z"]])
+    assert orc.fr_ints_from_mont(ctx.spmv_fr(rowptr, col, val, z)) == [h2i(x) for x in s["out"]]
+    # random sparsity (nnz/row ~ Poisson(3)), empty and ragged rows, coefficients equal to one
+    from pyref.prng import fr_array
+    rng = np.random.default_rng(5)
+    rows, cols = 50000, 40000
+    cnt = rng.poisson(3, rows).astype(np.uint32)
+    cnt[::7] = 0
+    rowptr = np.zeros(rows + 1, dtype=np.uint32)
+    rowptr[1:] = np.cumsum(cnt)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, cols, nnz, dtype=np.uint32)
+    val = orc.fr_to_mont(fr_array(nnz, 41))
+    one = orc.fr_mont_from_ints([1])[0]
+    val[::3] = one
+    z = orc.fr_to_mont(fr_array(cols, 42))
+    assert np.array_equal(ctx.spmv_fr(rowptr, col, val, z), orc.spmv(rowptr, col, val, z))
+    # empty matrix
+    assert ctx.spmv_fr(np.zeros(5, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros((0, 4), np.uint64), z).sum() == 0
+
+
+def test_batch_inverse_and_vec_mul(ctx, orc):
+    from oracle_lib import p64
+    g = golden("misc.json")["batch_inverse"]
+    v = orc.fr_mont_from_ints([h2i(x) for x in g["in"]])
+    assert orc.fr_ints_from_mont(ctx.batch_inverse_fr(v)) == [h2i(x) for x in g["out"]]
+    from pyref.prng import fr_array
+    x = orc.fr_to_mont(fr_array(100003, 51))
+    x[17] = 0
+    x[100002] = 0
+    ref = x.copy()
+    orc.lib.oracle_batch_inverse_fr(p64(ref), ref.shape[0])
+    assert np.array_equal(ctx.batch_inverse_fr(x), ref)
+    y = orc.fr_to_mont(fr_array(100003, 52))
+    ref = np.empty_like(x)
+    orc.lib.oracle_fr_mul(p64(x), p64(y), p64(ref), x.shape[0])
+    assert np.array_equal(ctx.vec_mul_fr(x, y), ref)
