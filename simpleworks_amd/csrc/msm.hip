@@ -76,7 +76,7 @@ __device__ __forceinline__ void for_each_digit(const Fr& s, unsigned c, unsigned
         uint32_t d = (v & mask) + carry;
         if (d > half) {
             carry = 1;
-            f(w, (1u << c) - d - 1, true);  // digit d - 2^c < 0, |digit| - 1
+            if (d != (1u << c)) f(w, (1u << c) - d - 1, true);  // digit d - 2^c < 0 (0 when d == 2^c), |digit| - 1
         } else {
             carry = 0;
             if (d != 0) f(w, d - 1, false);
