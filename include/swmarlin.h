@@ -77,6 +77,9 @@ int swm_msm_g1_dev(swm_ctx *ctx, const swm_bases *bases, size_t offset, const vo
                    int scalars_montgomery, uint64_t out_jac[18]);
 /* Jacobian -> affine on the host (x = y = 0 for infinity); returns 1 in *is_inf for the identity. */
 int swm_g1_normalize(const uint64_t jac[18], uint64_t out_xy[12], int *is_inf);
+/* out = a + b on the host (Jacobian in/out): folds the per-GPU partial sums of a point-range-sharded MSM after the
+ * all-gather (EC addition is not an RCCL reduction op). */
+int swm_g1_add_jac(const uint64_t a[18], const uint64_t b[18], uint64_t out[18]);
 
 /* ---------------------------------------------------------------------------------------------- K2: Fr NTT
  * Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (ark-poly 0.3.0):

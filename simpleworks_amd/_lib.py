@@ -34,6 +34,7 @@ ABI = {
     "swm_msm_g1": (_int, [_vp, _vp, _sz, _u64p, _sz, _u64p]),
     "swm_msm_g1_dev": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _u64p]),
     "swm_g1_normalize": (_int, [_u64p, _u64p, ctypes.POINTER(_int)]),
+    "swm_g1_add_jac": (_int, [_u64p, _u64p, _u64p]),
     "swm_ntt_fr": (_int, [_vp, _u64p, ctypes.c_uint, _int, _int]),
     "swm_ntt_fr_dev": (_int, [_vp, _vp, ctypes.c_uint, _int, _int]),
     "swm_spmv_fr": (_int, [_vp, _u32p, _u32p, _u64p, _u64p, _sz, _u64p, _sz, _sz]),
@@ -196,6 +197,13 @@ class Context:
         inf = _int(0)
         self._check(self.lib.swm_g1_normalize(_p64(jac), _p64(out), ctypes.byref(inf)), "swm_g1_normalize")
         return out, bool(inf.value)
+
+    def g1_add_jac(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros(18, dtype=np.uint64)
+        self._check(self.lib.swm_g1_add_jac(_p64(a), _p64(b), _p64(out)), "swm_g1_add_jac")
+        return out
 
     # ---- K2
     def ntt_fr(self, data_mont, log_n, inverse=False, coset=False):

@@ -248,6 +248,17 @@ int swm_g1_normalize(const uint64_t jac[18], uint64_t out_xy[12], int* is_inf) {
     return SWM_OK;
 }
 
+int swm_g1_add_jac(const uint64_t a[18], const uint64_t b[18], uint64_t out[18]) {
+    if (!a || !b || !out) return SWM_ERR_INVALID_ARG;
+    G1Jac ja, jb;
+    memcpy(&ja, a, sizeof(ja));
+    memcpy(&jb, b, sizeof(jb));
+    G1XYZZ acc = g1_from_jacobian(ja);
+    g1_add(acc, g1_from_jacobian(jb));
+    write_jac(acc, out);
+    return SWM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ K2
 int swm_ntt_fr_dev(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
     if (!ctx || !d_data) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");

@@ -5,43 +5,55 @@
 // with one rayon task per window; the MI355X design is different on purpose (the sum is a canonical group element,
 // so only the result has to agree):
 //
-//   1. msm_count    one thread per scalar: Montgomery -> standard form if needed, signed-digit recoding into
-//                   W = ceil(254/c) windows (digits in [-2^(c-1), 2^(c-1)] halve the bucket count), histogram
-//                   with global atomics.                                                       HBM: n x 32 B read
-//   2. msm_scan     single-workgroup exclusive scan of the W*2^(c-1) bucket counts -> bucket offsets, plus a
-//                   balanced split of every bucket into segments of <= SEG points (huge buckets: ~sqrt(count)
-//                   segments) -> segment offsets.  Keeps lanes of a wave on equal-length work and bounds the
-//                   serial chain for structured scalars (all-ones witnesses).
-//   3. msm_scatter  recompute digits, counting-sort (point index | sign) by bucket.              HBM: n*W*4 B write
-//   4. msm_accumulate  one lane per segment: gather 96-B affine bases through L2 / Infinity Cache, XYZZ mixed
+//   1. msm_digits   one lane per scalar: Montgomery -> standard form if needed, signed-digit recoding into
+//                   W = ceil(254/c) windows (digits in [-2^(c-1), 2^(c-1)] halve the bucket count), written
+//                   window-major so that the sort streams them coalesced.           HBM: 32 B read + 4W B write / point
+//   2. msm_hist / msm_scan / msm_scatter   counting sort of (point index | sign) by (window, bucket): 64K-digit
+//                   tiles histogram in LDS (LDS atomics), one global atomic per non-empty LDS bin, single-workgroup
+//                   exclusive scan, then each tile reserves its run per bucket and ranks with LDS atomics.
+//                   Every bucket is split into balanced segments of <= 32 points.
+//   3. msm_accumulate  one lane per segment: gather 96-B affine bases through L2 / Infinity Cache, XYZZ mixed
 //                   additions (8M+2S, carry-chain integer VALU, no MFMA) -> one partial per segment.
 //                   This is the dominant kernel: n*W mixed adds.
-//   5. msm_bucket_sum  one lane per bucket: fold that bucket's segment partials.
-//   6. msm_window_reduce  per window sum_b (b+1)*S_b: lanes take 8 consecutive buckets (local running sum +
+//   4. msm_bucket_sum / msm_big_bucket_sum   fold a bucket's segment partials: one lane per ordinary bucket, a
+//                   whole workgroup (strided sums + LDS tree) per bucket with > 16 segments, so structured scalars
+//                   (all-ones witnesses) and a short top window do not serialise on one lane.
+//   5. msm_window_reduce  per window sum_b (b+1)*S_b: lanes take 8 consecutive buckets (local running sum +
 //                   small scalar multiple for the chunk offset), LDS tree across the workgroup.
-//   7. host         sums the per-workgroup partials and does the W-term Horner fold (c doublings per window):
+//   6. host         sums the per-workgroup partials and does the W-term Horner fold (c doublings per window):
 //                   a 250-step serial dependency chain belongs on a CPU core, not on a 64-wide SIMD.
 //
 // Algorithmic bytes per point: 96 B base + 32 B scalar = 128 B.
+#include <stdlib.h>
+#include <algorithm>
 #include "context.h"
 #include "g1.cuh"
 
 namespace swm {
 
 // ---------------------------------------------------------------------------------------------- parameters
-static constexpr int SEG = 32;        // target points per accumulation segment
-static constexpr int RED_CHUNK = 8;   // buckets per lane in the window reduction
+static constexpr int SEG = 32;          // points per accumulation segment (upper bound)
+static constexpr int BIG_NSEG = 16;     // buckets with more segments than this are folded by a whole workgroup
+static constexpr int RED_CHUNK = 8;     // buckets per lane in the window reduction
 static constexpr int RED_BLOCK = 256;
+static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
+static constexpr int SORT_THREADS = 1024;
 
-struct MsmPlan {
-    unsigned c;       // window bits
-    unsigned nwin;    // number of windows
-    uint32_t B;       // buckets per window = 2^(c-1)
-    uint32_t NB;      // total buckets
+static constexpr int MAX_WIN = 64;
+// Window layout: the 254 recoding bits (253 scalar bits + 1 for the carry) are spread over nwin windows whose
+// widths differ by at most one, so that no window is degenerate (a short top window would put n/2 points in two
+// buckets).  boff[w] = first bucket of window w in the flat bucket array; window w has 2^(c[w]-1) buckets.
+struct WinLayout {
+    uint32_t nwin;
+    uint32_t NB;
+    uint32_t maxB;
+    uint8_t c[MAX_WIN];
+    uint16_t bit[MAX_WIN];
+    uint32_t boff[MAX_WIN + 1];
 };
 
-MsmPlan msm_plan(size_t n) {
-    // Window choice for the GPU schedule (NOT arkworks' ln-based rule): large enough that the n*W accumulate
+WinLayout msm_plan(size_t n) {
+    // Target window size for the GPU schedule (NOT arkworks' ln-based rule): large enough that the n*W accumulate
     // adds dominate the fixed-latency bucket reduction, small enough that buckets stay populated.
     unsigned c;
     if (n <= (1u << 8)) c = 6;
@@ -49,138 +61,246 @@ MsmPlan msm_plan(size_t n) {
     else if (n <= (1u << 14)) c = 10;
     else if (n <= (1u << 16)) c = 12;
     else if (n <= (1u << 18)) c = 13;
-    else if (n <= (1u << 20)) c = 14;
-    else if (n <= (1u << 22)) c = 15;
+    else if (n <= (1u << 20)) c = 15;
     else c = 16;
-    MsmPlan p;
-    p.c = c;
-    p.nwin = (254 + c - 1) / c;
-    p.B = 1u << (c - 1);
-    p.NB = p.nwin * p.B;
-    return p;
+    if (const char* e = getenv("SWM_MSM_C")) {
+        int v = atoi(e);
+        if (v >= 2 && v <= 16) c = (unsigned)v;
+    }
+    WinLayout L;
+    L.nwin = (254 + c - 1) / c;
+    unsigned base = 254 / L.nwin, extra = 254 % L.nwin;
+    unsigned bit = 0;
+    L.NB = 0;
+    L.maxB = 0;
+    for (unsigned w = 0; w < L.nwin; w++) {
+        unsigned cw = base + (w < extra ? 1 : 0);
+        L.c[w] = (uint8_t)cw;
+        L.bit[w] = (uint16_t)bit;
+        L.boff[w] = L.NB;
+        bit += cw;
+        uint32_t B = 1u << (cw - 1);
+        L.NB += B;
+        if (B > L.maxB) L.maxB = B;
+    }
+    L.boff[L.nwin] = L.NB;
+    return L;
 }
 
 // ---------------------------------------------------------------------------------------------- digits
 // Signed-digit recoding of a 253-bit standard-form scalar; calls f(window, bucket_index, negative) for every
 // non-zero digit.  Digit d in [-2^(c-1), 2^(c-1)]; bucket index |d| - 1.
 template <class Fn>
-__device__ __forceinline__ void for_each_digit(const Fr& s, unsigned c, unsigned nwin, Fn f) {
+__device__ __forceinline__ void for_each_digit(const Fr& s, const WinLayout& L, Fn f) {
     uint32_t carry = 0;
-    const uint32_t mask = (1u << c) - 1;
-    const uint32_t half = 1u << (c - 1);
-    for (unsigned w = 0; w < nwin; w++) {
-        unsigned bit = w * c;
+    for (unsigned w = 0; w < L.nwin; w++) {
+        const unsigned c = L.c[w], bit = L.bit[w];
+        const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
         unsigned limb = bit >> 5, off = bit & 31;
         uint32_t v = limb < 8 ? (s.v[limb] >> off) : 0;
         if (off + c > 32 && limb + 1 < 8) v |= s.v[limb + 1] << (32 - off);
         uint32_t d = (v & mask) + carry;
+        uint32_t code = 0;  // 0 = zero digit, else ((bucket << 1) | negative) + 1
         if (d > half) {
             carry = 1;
-            if (d != (1u << c)) f(w, (1u << c) - d - 1, true);  // digit d - 2^c < 0 (0 when d == 2^c), |digit| - 1
+            if (d != (1u << c)) code = ((((1u << c) - d - 1) << 1) | 1u) + 1;  // digit d - 2^c < 0
         } else {
             carry = 0;
-            if (d != 0) f(w, d - 1, false);
+            if (d != 0) code = ((d - 1) << 1) + 1;
+        }
+        f(w, code);
+    }
+}
+
+// digits[w * n + i] = code of window w of scalar i (coalesced over i).            HBM: 32 B read + 4 W B written / point
+__global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
+                                                  uint32_t* __restrict__ digits) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr s = scalars[i];
+        if (mont) s = fp_to_std(s);
+        for_each_digit(s, L, [&](unsigned w, uint32_t code) { digits[(size_t)w * n + i] = code; });
+    }
+}
+
+// Counting sort, pass 1: per-(tile, window) histogram in LDS, one global atomic per non-empty LDS bin.
+__global__ void __launch_bounds__(SORT_THREADS) msm_hist(const uint32_t* __restrict__ digits, size_t n, WinLayout L,
+                                                         uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t w = blockIdx.y;
+    const uint32_t B = 1u << (L.c[w] - 1), boff = L.boff[w];
+    const size_t lo = (size_t)blockIdx.x * SORT_TILE, hi = min(lo + (size_t)SORT_TILE, n);
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lh[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code) atomicAdd(&lh[(code - 1) >> 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        uint32_t v = lh[b];
+        if (v) atomicAdd(&hist[boff + b], v);
+    }
+}
+
+// Counting sort, pass 2: the tile reserves a contiguous run in every bucket it touches (one returning global
+// atomic per non-empty bin), then ranks its digits with LDS atomics and writes (point index | sign).
+__global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __restrict__ digits, size_t n, WinLayout L,
+                                                            const uint32_t* __restrict__ bucket_off,
+                                                            uint32_t* __restrict__ cursor,
+                                                            uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t w = blockIdx.y;
+    const uint32_t B = 1u << (L.c[w] - 1), boff = L.boff[w];
+    const size_t lo = (size_t)blockIdx.x * SORT_TILE, hi = min(lo + (size_t)SORT_TILE, n);
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lh[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code) atomicAdd(&lh[(code - 1) >> 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
+        uint32_t v = lh[b];
+        if (v) lh[b] = bucket_off[boff + b] + atomicAdd(&cursor[boff + b], v);
+    }
+    __syncthreads();
+    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        uint32_t code = d[i];
+        if (code) {
+            uint32_t pos = atomicAdd(&lh[(code - 1) >> 1], 1u);
+            sorted[pos] = (uint32_t)i | (((code - 1) & 1u) << 31);
         }
     }
 }
 
-__device__ __forceinline__ Fr load_scalar(const Fr* scalars, size_t i, int mont) {
-    Fr s = scalars[i];
-    if (mont) s = fp_to_std(s);
-    return s;
-}
+__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt) { return (cnt + SEG - 1) / SEG; }
 
-__global__ void __launch_bounds__(256) msm_count(const Fr* __restrict__ scalars, size_t n, int mont, unsigned c,
-                                                 unsigned nwin, uint32_t B, uint32_t* __restrict__ hist) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = load_scalar(scalars, i, mont);
-        if (fp_is_zero(s)) continue;
-        for_each_digit(s, c, nwin, [&](unsigned w, uint32_t b, bool) { atomicAdd(&hist[w * B + b], 1u); });
-    }
-}
+// Exclusive scans of the bucket counts and of the per-bucket segment counts, in three launches:
+// per-workgroup totals, a single-workgroup scan of those totals, per-workgroup scan + offset.
+static constexpr int SCAN_BLOCK = 256;
+static constexpr int SCAN_ITEMS = 8;  // consecutive buckets per lane
+static constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
-__global__ void __launch_bounds__(256) msm_scatter(const Fr* __restrict__ scalars, size_t n, int mont, unsigned c,
-                                                   unsigned nwin, uint32_t B, const uint32_t* __restrict__ bucket_off,
-                                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = load_scalar(scalars, i, mont);
-        if (fp_is_zero(s)) continue;
-        for_each_digit(s, c, nwin, [&](unsigned w, uint32_t b, bool neg) {
-            uint32_t g = w * B + b;
-            uint32_t pos = bucket_off[g] + atomicAdd(&cursor[g], 1u);
-            sorted[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
-        });
-    }
-}
-
-__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt) {
-    if (cnt == 0) return 0;
-    if (cnt <= (uint32_t)SEG * SEG) return (cnt + SEG - 1) / SEG;
-    // ~sqrt(cnt) segments of ~sqrt(cnt) points: bounds the serial chain of a pathological bucket
-    uint32_t r = (uint32_t)sqrtf((float)cnt);
-    while ((uint64_t)r * r < cnt) r++;
-    return r;
-}
-
-// Single workgroup (1024 lanes): exclusive scans of bucket counts and of per-bucket segment counts.
-__global__ void __launch_bounds__(1024) msm_scan(const uint32_t* __restrict__ hist, uint32_t NB,
-                                                 uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ seg_off) {
-    __shared__ uint32_t s_cnt[1024];
-    __shared__ uint32_t s_seg[1024];
+__device__ __forceinline__ void block_inclusive_scan2(uint32_t& a, uint32_t& b, uint32_t* sa, uint32_t* sb) {
+    // Hillis-Steele over SCAN_BLOCK lanes (values returned in place: inclusive prefix)
     uint32_t tid = threadIdx.x;
-    uint32_t per = (NB + 1023) / 1024;
-    uint32_t lo = tid * per, hi = min(lo + per, NB);
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (uint32_t d = 1; d < SCAN_BLOCK; d <<= 1) {
+        uint32_t va = tid >= d ? sa[tid - d] : 0, vb = tid >= d ? sb[tid - d] : 0;
+        __syncthreads();
+        sa[tid] += va;
+        sb[tid] += vb;
+        __syncthreads();
+    }
+    a = sa[tid];
+    b = sb[tid];
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_totals(const uint32_t* __restrict__ hist, uint32_t NB,
+                                                             uint32_t* __restrict__ tot_cnt,
+                                                             uint32_t* __restrict__ tot_seg) {
+    __shared__ uint32_t sa[SCAN_BLOCK], sb[SCAN_BLOCK];
+    uint32_t lo = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t a = 0, b = 0;
+    for (uint32_t i = lo; i < min(lo + SCAN_ITEMS, NB); i++) {
+        a += hist[i];
+        b += nseg_of(hist[i]);
+    }
+    block_inclusive_scan2(a, b, sa, sb);
+    if (threadIdx.x == SCAN_BLOCK - 1) {
+        tot_cnt[blockIdx.x] = a;
+        tot_seg[blockIdx.x] = b;
+    }
+}
+
+// one workgroup: exclusive scan of the tile totals, in place; grand totals to tot[ntiles]
+__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_mid(uint32_t* __restrict__ tot_cnt, uint32_t* __restrict__ tot_seg,
+                                                          uint32_t ntiles) {
+    __shared__ uint32_t sa[SCAN_BLOCK], sb[SCAN_BLOCK];
+    uint32_t per = (ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    uint32_t lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    uint32_t a = 0, b = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        a += tot_cnt[i];
+        b += tot_seg[i];
+    }
+    uint32_t la = a, lb = b;
+    block_inclusive_scan2(a, b, sa, sb);
+    uint32_t ra = a - la, rb = b - lb;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t ca = tot_cnt[i], cb = tot_seg[i];
+        tot_cnt[i] = ra;
+        tot_seg[i] = rb;
+        ra += ca;
+        rb += cb;
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) {
+        tot_cnt[ntiles] = a;
+        tot_seg[ntiles] = b;
+    }
+}
+
+// Also appends buckets with > BIG_NSEG segments to the big list.
+__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __restrict__ hist, uint32_t NB,
+                                                            const uint32_t* __restrict__ tot_cnt,
+                                                            const uint32_t* __restrict__ tot_seg, uint32_t ntiles,
+                                                            uint32_t* __restrict__ bucket_off,
+                                                            uint32_t* __restrict__ seg_off,
+                                                            uint32_t* __restrict__ big_count,
+                                                            uint32_t* __restrict__ big_list) {
+    __shared__ uint32_t sa[SCAN_BLOCK], sb[SCAN_BLOCK];
+    uint32_t lo = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t hi = min(lo + SCAN_ITEMS, NB);
     uint32_t a = 0, b = 0;
     for (uint32_t i = lo; i < hi; i++) {
         a += hist[i];
         b += nseg_of(hist[i]);
     }
-    s_cnt[tid] = a;
-    s_seg[tid] = b;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t va = tid >= d ? s_cnt[tid - d] : 0, vb = tid >= d ? s_seg[tid - d] : 0;
-        __syncthreads();
-        s_cnt[tid] += va;
-        s_seg[tid] += vb;
-        __syncthreads();
-    }
-    uint32_t ra = s_cnt[tid] - a, rb = s_seg[tid] - b;  // exclusive prefix of this lane's chunk
+    uint32_t la = a, lb = b;
+    block_inclusive_scan2(a, b, sa, sb);
+    uint32_t ra = tot_cnt[blockIdx.x] + a - la, rb = tot_seg[blockIdx.x] + b - lb;
     for (uint32_t i = lo; i < hi; i++) {
+        uint32_t h = hist[i], ns = nseg_of(h);
         bucket_off[i] = ra;
         seg_off[i] = rb;
-        ra += hist[i];
-        rb += nseg_of(hist[i]);
+        ra += h;
+        rb += ns;
+        if (ns > BIG_NSEG) big_list[atomicAdd(big_count, 1u)] = i;
     }
-    if (tid == 1023) {
-        bucket_off[NB] = s_cnt[1023];
-        seg_off[NB] = s_seg[1023];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        bucket_off[NB] = tot_cnt[ntiles];
+        seg_off[NB] = tot_seg[ntiles];
     }
 }
 
-__global__ void __launch_bounds__(256) msm_segdesc(const uint32_t* __restrict__ bucket_off,
-                                                   const uint32_t* __restrict__ seg_off, uint32_t NB,
-                                                   uint32_t* __restrict__ seg_start, uint32_t* __restrict__ seg_end) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= NB) return;
-    uint32_t s0 = seg_off[b], ns = seg_off[b + 1] - s0;
-    uint32_t o = bucket_off[b], cnt = bucket_off[b + 1] - o;
-    for (uint32_t s = 0; s < ns; s++) {
-        seg_start[s0 + s] = o + (uint32_t)(((uint64_t)cnt * s) / ns);
-        seg_end[s0 + s] = o + (uint32_t)(((uint64_t)cnt * (s + 1)) / ns);
+// bucket that owns segment `seg`: largest b with seg_off[b] <= seg (empty buckets share offsets; skip them)
+__device__ __forceinline__ uint32_t bucket_of_segment(const uint32_t* __restrict__ seg_off, uint32_t NB, uint32_t seg) {
+    uint32_t lo = 0, hi = NB;  // invariant: seg_off[lo] <= seg < seg_off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= seg) lo = mid;
+        else hi = mid;
     }
+    return lo;
 }
 
 // Dominant kernel: one lane per segment, XYZZ accumulator in registers, affine bases gathered from HBM/L2.
 __global__ void __launch_bounds__(256) msm_accumulate(const G1Affine* __restrict__ bases,
                                                       const uint32_t* __restrict__ sorted,
-                                                      const uint32_t* __restrict__ seg_start,
-                                                      const uint32_t* __restrict__ seg_end, uint32_t nseg,
+                                                      const uint32_t* __restrict__ bucket_off,
+                                                      const uint32_t* __restrict__ seg_off, uint32_t NB,
                                                       G1XYZZ* __restrict__ partial) {
     uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= nseg) return;
-    uint32_t k = seg_start[seg], e = seg_end[seg];
+    if (seg >= seg_off[NB]) return;
+    // balanced split of the owning bucket into its segments
+    uint32_t b = bucket_of_segment(seg_off, NB, seg);
+    uint32_t s = seg - seg_off[b], ns = seg_off[b + 1] - seg_off[b];
+    uint32_t o = bucket_off[b], cnt = bucket_off[b + 1] - o;
+    uint32_t k = o + (uint32_t)(((uint64_t)cnt * s) / ns), e = o + (uint32_t)(((uint64_t)cnt * (s + 1)) / ns);
     G1XYZZ acc = g1_xyzz_identity();
     if (k < e) {
         uint32_t ent = sorted[k];
@@ -198,39 +318,86 @@ __global__ void __launch_bounds__(256) msm_accumulate(const G1Affine* __restrict
     partial[seg] = acc;
 }
 
+// kept out of line: these kernels are latency-bound and otherwise inline ~10 copies of the 14-multiplication adder
+__device__ __noinline__ void g1_add_ool(G1XYZZ& acc, const G1XYZZ& q) { g1_add(acc, q); }
+
 __global__ void __launch_bounds__(256) msm_bucket_sum(const G1XYZZ* __restrict__ partial,
                                                       const uint32_t* __restrict__ seg_off, uint32_t NB,
                                                       G1XYZZ* __restrict__ buckets) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
     uint32_t s = seg_off[b], e = seg_off[b + 1];
+    if (e - s > BIG_NSEG) return;  // folded by msm_big_bucket_sum
     G1XYZZ acc = g1_xyzz_identity();
     if (s < e) acc = partial[s++];
-    for (; s < e; s++) g1_add(acc, partial[s]);
+    for (; s < e; s++) {
+        G1XYZZ q = partial[s];
+        g1_add_ool(acc, q);
+    }
     buckets[b] = acc;
 }
 
+// One workgroup per big bucket (structured scalars, short top window): strided partial sums + LDS tree.
+__global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(const G1XYZZ* __restrict__ partial,
+                                                                const uint32_t* __restrict__ seg_off,
+                                                                const uint32_t* __restrict__ big_count,
+                                                                const uint32_t* __restrict__ big_list,
+                                                                G1XYZZ* __restrict__ buckets) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
+    const uint32_t nbig = *big_count;
+    for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
+        uint32_t b = big_list[j];
+        uint32_t s = seg_off[b], e = seg_off[b + 1];
+        G1XYZZ acc = g1_xyzz_identity();
+        for (uint32_t k = s + threadIdx.x; k < e; k += RED_BLOCK) {
+            G1XYZZ q = partial[k];
+            g1_add_ool(acc, q);
+        }
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
+            if (threadIdx.x < stride) {
+                G1XYZZ a = sm[threadIdx.x];
+                G1XYZZ q = sm[threadIdx.x + stride];
+                g1_add_ool(a, q);
+                sm[threadIdx.x] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) buckets[b] = sm[0];
+        __syncthreads();
+    }
+}
+
 // grid = (ceil(B / RED_CHUNK / RED_BLOCK), nwin).  out[w * gridDim.x + blockIdx.x] = partial of sum_b (b+1) S_b.
-__global__ void __launch_bounds__(RED_BLOCK) msm_window_reduce(const G1XYZZ* __restrict__ buckets, uint32_t B,
+__global__ void __launch_bounds__(RED_BLOCK) msm_window_reduce(const G1XYZZ* __restrict__ buckets, WinLayout L,
                                                                G1XYZZ* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
     uint32_t w = blockIdx.y;
+    const uint32_t B = 1u << (L.c[w] - 1);
     uint32_t chunk = blockIdx.x * RED_BLOCK + threadIdx.x;
     uint32_t lo = chunk * RED_CHUNK;
     G1XYZZ acc = g1_xyzz_identity();
     if (lo < B) {
-        const G1XYZZ* base = buckets + (size_t)w * B;
+        const G1XYZZ* base = buckets + L.boff[w];
         uint32_t hi = min(lo + RED_CHUNK, B);
         G1XYZZ run = g1_xyzz_identity();
         for (uint32_t b = hi; b-- > lo;) {
-            g1_add(run, base[b]);
-            g1_add(acc, run);
+            G1XYZZ q = base[b];
+            g1_add_ool(run, q);
+            g1_add_ool(acc, run);
         }
-        // acc = sum (b - lo + 1) S_b ; add lo * sum S_b
-        if (lo) {
-            G1XYZZ t = g1_mul_small(run, lo);
-            g1_add(acc, t);
+        // acc = sum (b - lo + 1) S_b ; add lo * sum S_b  (double-and-add on the chunk offset)
+        if (lo && !g1_is_inf(run)) {
+            G1XYZZ t = g1_xyzz_identity();
+            int top = 31 - __clz(lo);
+            for (int i = top; i >= 0; i--) {
+                t = g1_dbl(t);
+                if ((lo >> i) & 1) g1_add_ool(t, run);
+            }
+            g1_add_ool(acc, t);
         }
     }
     sm[threadIdx.x] = acc;
@@ -238,7 +405,8 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_window_reduce(const G1XYZZ* __r
     for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
         if (threadIdx.x < stride) {
             G1XYZZ a = sm[threadIdx.x];
-            g1_add(a, sm[threadIdx.x + stride]);
+            G1XYZZ q = sm[threadIdx.x + stride];
+            g1_add_ool(a, q);
             sm[threadIdx.x] = a;
         }
         __syncthreads();
@@ -247,53 +415,70 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_window_reduce(const G1XYZZ* __r
 }
 
 // ---------------------------------------------------------------------------------------------- host driver
-// d_scalars: n Fr in HBM.  Result: XYZZ on the host.
+static int allow_big_lds(swm_ctx* ctx, const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) SWM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SWM_OK;
+}
+
+// d_scalars: n Fr in HBM.  Result: XYZZ on the host.  Everything up to the final 17-point download is enqueued
+// without host synchronisation (segment counts are bounded, not read back).
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result) {
     *result = g1_xyzz_identity();
     if (n == 0) return SWM_OK;
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
-    MsmPlan pl = msm_plan(n);
+    WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
-    uint32_t *hist, *bucket_off, *seg_off, *cursor, *sorted, *seg_start, *seg_end;
-    SWM_TRY(scratch(ctx, "msm.hist", (pl.NB + 1) * 4ull * 2, (void**)&hist));
+    const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
+    uint32_t *hist, *cursor, *big_count, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4;
+    SWM_TRY(scratch(ctx, "msm.hist", zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
+    big_count = cursor + pl.NB + 1;
     SWM_TRY(scratch(ctx, "msm.bucket_off", (pl.NB + 1) * 4ull, (void**)&bucket_off));
     SWM_TRY(scratch(ctx, "msm.seg_off", (pl.NB + 1) * 4ull, (void**)&seg_off));
+    SWM_TRY(scratch(ctx, "msm.digits", total * 4, (void**)&digits));
     SWM_TRY(scratch(ctx, "msm.sorted", total * 4, (void**)&sorted));
-    SWM_HIP(ctx, hipMemsetAsync(hist, 0, (pl.NB + 1) * 4ull * 2, ctx->stream));
+    const unsigned scan_tiles = (pl.NB + SCAN_TILE - 1) / SCAN_TILE;
+    SWM_TRY(scratch(ctx, "msm.scan_tot", (size_t)(scan_tiles + 1) * 8, (void**)&tot_cnt));
+    tot_seg = tot_cnt + scan_tiles + 1;
+    SWM_TRY(scratch(ctx, "msm.big_list", (size_t)pl.NB * 4, (void**)&big_list));
+    G1XYZZ *partial, *buckets, *wpart;
+    SWM_TRY(scratch(ctx, "msm.partial", nseg_max * sizeof(G1XYZZ), (void**)&partial));
+    SWM_TRY(scratch(ctx, "msm.buckets", (size_t)pl.NB * sizeof(G1XYZZ), (void**)&buckets));
+    unsigned red_blocks = (pl.maxB + RED_CHUNK * RED_BLOCK - 1) / (RED_CHUNK * RED_BLOCK);
+    SWM_TRY(scratch(ctx, "msm.wpart", (size_t)pl.nwin * red_blocks * sizeof(G1XYZZ), (void**)&wpart));
+
+    SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
-    SWM_LAUNCH(ctx, "msm_count", msm_count, dim3(grid_n), dim3(256), 0, sc, n, mont, pl.c, pl.nwin, pl.B, hist);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan, dim3(1), dim3(1024), 0, hist, pl.NB, bucket_off, seg_off);
-    SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(grid_n), dim3(256), 0, sc, n, mont, pl.c, pl.nwin, pl.B,
+    SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits);
+    unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    size_t lds_sort = (size_t)pl.maxB * 4;
+    SWM_TRY(allow_big_lds(ctx, (const void*)msm_hist, lds_sort));
+    SWM_TRY(allow_big_lds(ctx, (const void*)msm_scatter, lds_sort));
+    SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, hist);
+    SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, tot_cnt, tot_seg);
+    SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
+    SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, tot_cnt, tot_seg,
+               scan_tiles, bucket_off, seg_off, big_count, big_list);
+    SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
                bucket_off, cursor, sorted);
-    uint32_t nseg = 0;
-    SWM_HIP(ctx, hipMemcpyAsync(&nseg, seg_off + pl.NB, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    G1XYZZ *partial, *buckets, *wpart;
-    SWM_TRY(scratch(ctx, "msm.seg_start", (size_t)(nseg + 1) * 8, (void**)&seg_start));
-    seg_end = seg_start + nseg + 1;
-    SWM_TRY(scratch(ctx, "msm.partial", (size_t)(nseg + 1) * sizeof(G1XYZZ), (void**)&partial));
-    SWM_TRY(scratch(ctx, "msm.buckets", (size_t)pl.NB * sizeof(G1XYZZ), (void**)&buckets));
     unsigned grid_b = (pl.NB + 255) / 256;
-    SWM_LAUNCH(ctx, "msm_segdesc", msm_segdesc, dim3(grid_b), dim3(256), 0, bucket_off, seg_off, pl.NB, seg_start,
-               seg_end);
-    if (nseg)
-        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((nseg + 255) / 256), dim3(256), 0, d_bases, sorted,
-                   seg_start, seg_end, nseg, partial);
+    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
+               sorted, bucket_off, seg_off, pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_bucket_sum", msm_bucket_sum, dim3(grid_b), dim3(256), 0, partial, seg_off, pl.NB, buckets);
-    unsigned red_blocks = (pl.B + RED_CHUNK * RED_BLOCK - 1) / (RED_CHUNK * RED_BLOCK);
-    SWM_TRY(scratch(ctx, "msm.wpart", (size_t)pl.nwin * red_blocks * sizeof(G1XYZZ), (void**)&wpart));
+    SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
+               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, buckets);
     SWM_LAUNCH(ctx, "msm_window_reduce", msm_window_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
-               RED_BLOCK * sizeof(G1XYZZ), buckets, pl.B, wpart);
+               RED_BLOCK * sizeof(G1XYZZ), buckets, pl, wpart);
     std::vector<G1XYZZ> h((size_t)pl.nwin * red_blocks);
     SWM_HIP(ctx, hipMemcpyAsync(h.data(), wpart, h.size() * sizeof(G1XYZZ), hipMemcpyDeviceToHost, ctx->stream));
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // host: fold workgroup partials, then Horner over windows (high -> low, c doublings each)
     G1XYZZ total_pt = g1_xyzz_identity();
     for (unsigned w = pl.nwin; w-- > 0;) {
-        for (unsigned k = 0; k < pl.c; k++) total_pt = g1_dbl(total_pt);
+        for (unsigned k = 0; k < pl.c[w]; k++) total_pt = g1_dbl(total_pt);
         G1XYZZ ws = g1_xyzz_identity();
         for (unsigned j = 0; j < red_blocks; j++) g1_add(ws, h[(size_t)w * red_blocks + j]);
         g1_add(total_pt, ws);
