@@ -104,6 +104,77 @@ int swm_batch_inverse_fr_dev(swm_ctx *ctx, void *d_data, size_t n);
 int swm_vec_mul_fr(swm_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 int swm_vec_mul_fr_dev(swm_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 
+/* ---------------------------------------------------------------------------------------------- Marlin surface
+ * The functions of /root/reference/src/marlin/mod.rs:33-94 and src/marlin/serialization.rs:5-45, one entry point
+ * each.  Keys are opaque handles (the proving key owns device-resident matrices, index polynomials and SRS powers);
+ * proofs and verifying keys cross the boundary in the ark-serialize wire format the reference's serialisers emit. */
+typedef struct swm_rng swm_rng; /* rand::rngs::StdRng as produced by generate_rand(): ChaCha12, fixed test seed */
+typedef struct swm_srs swm_srs; /* Box<UniversalSRS> */
+typedef struct swm_pk swm_pk;   /* ProvingKey  = IndexProverKey */
+typedef struct swm_vk swm_vk;   /* VerifyingKey = IndexVerifierKey */
+
+/* generate_rand() (src/marlin/mod.rs:33-35): ark_std::test_rng() */
+int swm_rng_test_new(swm_rng **out);
+/* StdRng::from_seed(seed) for callers that want their own randomness */
+int swm_rng_from_seed(const uint8_t seed[32], swm_rng **out);
+void swm_rng_free(swm_rng *rng);
+int swm_rng_next_u64(swm_rng *rng, uint64_t *out);
+int swm_rng_rand_fr(swm_rng *rng, uint64_t out_mont[4]); /* ark_ff UniformRand for Fr (Montgomery limbs) */
+
+/* A synthesised constraint system (what ConstraintSystemRef<Fr> holds after generate_constraints): instance
+ * assignment (instance[0] must be one), witness assignment, and A, B, C as CSR over columns
+ * [instance..., witness...] with Montgomery coefficients.  Padding (public input to a power of two, square
+ * matrices) is applied inside index/prove exactly as ark-marlin does. */
+typedef struct swm_r1cs {
+    size_t num_instance, num_witness, num_constraints;
+    const uint64_t *instance; /* num_instance x 4 */
+    const uint64_t *witness;  /* num_witness x 4 */
+    const uint32_t *a_rowptr, *a_col; const uint64_t *a_val;
+    const uint32_t *b_rowptr, *b_col; const uint64_t *b_val;
+    const uint32_t *c_rowptr, *c_col; const uint64_t *c_val;
+} swm_r1cs;
+
+/* generate_universal_srs (src/marlin/mod.rs:45-55): MarlinInst::universal_setup(nc, nv, nnz, rng) */
+int swm_generate_universal_srs(swm_ctx *ctx, size_t num_constraints, size_t num_variables, size_t num_non_zero,
+                               swm_rng *rng, swm_srs **out);
+void swm_srs_destroy(swm_ctx *ctx, swm_srs *srs);
+size_t swm_srs_max_degree(const swm_srs *srs);
+/* i-th power of g (affine Montgomery x,y) — test hook */
+int swm_srs_power_of_g(swm_ctx *ctx, const swm_srs *srs, size_t i, uint64_t out_xy[12]);
+
+/* generate_proving_and_verifying_keys (src/marlin/mod.rs:88-94): MarlinInst::index_from_constraint_system */
+int swm_generate_proving_and_verifying_keys(swm_ctx *ctx, const swm_srs *srs, const swm_r1cs *cs, swm_pk **pk,
+                                            swm_vk **vk);
+void swm_pk_destroy(swm_ctx *ctx, swm_pk *pk);
+void swm_vk_destroy(swm_vk *vk);
+
+/* generate_proof (src/marlin/mod.rs:70-77): MarlinInst::prove_from_constraint_system(&pk, cs, rng).
+ * Writes the CanonicalSerialize bytes of the proof (<= 1024 B).  SWM_ERR_UNSATISFIED when the witness does not
+ * satisfy the constraints (the reference panics on a debug assertion inside ark-marlin at this point). */
+int swm_generate_proof(swm_ctx *ctx, const swm_pk *pk, const swm_r1cs *cs, swm_rng *rng, uint8_t *proof_out,
+                       size_t cap, size_t *len);
+
+/* verify_proof (src/marlin/mod.rs:79-86).  public_inputs: n x 4 Montgomery limbs (without the leading one).
+ * Host-only (two pairings); needs no GPU and no context. */
+int swm_verify_proof(const swm_vk *vk, const uint64_t *public_inputs, size_t n, const uint8_t *proof, size_t len,
+                     swm_rng *rng, int *ok);
+
+/* serialization.rs: serialize_/deserialize_verifying_key, deserialize_proof (validation of the byte string) */
+int swm_vk_serialize(const swm_vk *vk, uint8_t *out, size_t cap, size_t *len);
+int swm_vk_deserialize(const uint8_t *bytes, size_t len, swm_vk **out);
+int swm_proof_validate(const uint8_t *bytes, size_t len);
+/* serialize_proving_key / deserialize_proving_key: round-trip of the key material through host bytes */
+int swm_pk_serialize(swm_ctx *ctx, const swm_pk *pk, uint8_t *out, size_t cap, size_t *len);
+int swm_pk_deserialize(swm_ctx *ctx, const uint8_t *bytes, size_t len, swm_pk **out);
+
+/* K3 as the reference exercises it: ConstraintSystem::is_satisfied (src/merkle_tree/simple_merkle_tree.rs:197-199):
+ * A z o B z == C z on the GPU.  *ok = 1 when satisfied, else *first_bad = index of the first unsatisfied row. */
+int swm_r1cs_is_satisfied(swm_ctx *ctx, const swm_r1cs *cs, int *ok, size_t *first_bad);
+
+/* transcript primitives, exposed for known-answer tests */
+int swm_blake2s(const uint8_t *data, size_t len, uint8_t out[32]);
+int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_t out[64]);
+
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
  * kernel launch is bracketed by hipEventRecord on the stream it is launched on.  swm_profile_json writes

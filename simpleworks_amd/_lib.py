@@ -43,6 +43,28 @@ ABI = {
     "swm_batch_inverse_fr_dev": (_int, [_vp, _vp, _sz]),
     "swm_vec_mul_fr": (_int, [_vp, _u64p, _u64p, _u64p, _sz]),
     "swm_vec_mul_fr_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "swm_rng_test_new": (_int, [ctypes.POINTER(_vp)]),
+    "swm_rng_from_seed": (_int, [ctypes.c_void_p, ctypes.POINTER(_vp)]),
+    "swm_rng_free": (None, [_vp]),
+    "swm_rng_next_u64": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "swm_rng_rand_fr": (_int, [_vp, _u64p]),
+    "swm_generate_universal_srs": (_int, [_vp, _sz, _sz, _sz, _vp, ctypes.POINTER(_vp)]),
+    "swm_srs_destroy": (None, [_vp, _vp]),
+    "swm_srs_max_degree": (_sz, [_vp]),
+    "swm_srs_power_of_g": (_int, [_vp, _vp, _sz, _u64p]),
+    "swm_generate_proving_and_verifying_keys": (_int, [_vp, _vp, ctypes.c_void_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "swm_pk_destroy": (None, [_vp, _vp]),
+    "swm_vk_destroy": (None, [_vp]),
+    "swm_generate_proof": (_int, [_vp, _vp, ctypes.c_void_p, _vp, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
+    "swm_verify_proof": (_int, [_vp, _u64p, _sz, ctypes.c_void_p, _sz, _vp, ctypes.POINTER(_int)]),
+    "swm_vk_serialize": (_int, [_vp, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
+    "swm_vk_deserialize": (_int, [ctypes.c_void_p, _sz, ctypes.POINTER(_vp)]),
+    "swm_proof_validate": (_int, [ctypes.c_void_p, _sz]),
+    "swm_pk_serialize": (_int, [_vp, _vp, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
+    "swm_pk_deserialize": (_int, [_vp, ctypes.c_void_p, _sz, ctypes.POINTER(_vp)]),
+    "swm_r1cs_is_satisfied": (_int, [_vp, ctypes.c_void_p, ctypes.POINTER(_int), ctypes.POINTER(_sz)]),
+    "swm_blake2s": (_int, [ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "swm_chacha_block": (_int, [ctypes.c_void_p, ctypes.c_uint64, _int, ctypes.c_void_p]),
     "swm_profile_enable": (_int, [_vp, _int]),
     "swm_profile_reset": (_int, [_vp]),
     "swm_profile_json": (_int, [_vp, ctypes.c_char_p, _sz]),

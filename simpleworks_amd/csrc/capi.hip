@@ -47,6 +47,31 @@ int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
     return SWM_OK;
 }
 
+int pool_alloc(swm_ctx* ctx, size_t bytes, void** out, size_t* cap) {
+    if (bytes < 256) bytes = 256;
+    auto it = ctx->pool.lower_bound(bytes);
+    if (it != ctx->pool.end() && it->first <= bytes + bytes / 4) {
+        *out = it->second;
+        *cap = it->first;
+        ctx->pool.erase(it);
+        return SWM_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        // release cached blocks and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+        ctx->pool.clear();
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) return set_err(ctx, SWM_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    *cap = bytes;
+    return SWM_OK;
+}
+void pool_free(swm_ctx* ctx, void* p, size_t cap) {
+    if (p) ctx->pool.emplace(cap, p);
+}
+
 static hipEvent_t get_event(swm_ctx* ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
@@ -140,6 +165,7 @@ void swm_destroy(swm_ctx* ctx) {
         (void)hipFree(kv.second.hi);
     }
     for (auto& kv : ctx->ntt_small) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -44,6 +44,7 @@ struct swm_ctx {
     // NTT root tables keyed by (log_n << 1 | inverse); coset tables keyed by inverse flag
     std::map<uint64_t, swm::NttTables> ntt_tables;
     std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
+    std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     bool profiling = false;
     std::map<std::string, swm::ProfAgg> prof;
     std::vector<swm::ProfPending> pending;
@@ -60,6 +61,11 @@ namespace swm {
 int set_err(swm_ctx* ctx, int code, const char* fmt, ...);
 // returns device pointer of a scratch buffer with at least `bytes` capacity (contents undefined)
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out);
+// pooled device allocations for the prover's polynomial temporaries
+int pool_alloc(swm_ctx* ctx, size_t bytes, void** out, size_t* cap);
+void pool_free(swm_ctx* ctx, void* p, size_t cap);
+// two-level power tables of the 2^log_n-th root of unity (lo[i] = w^i, i < 1024; hi[i] = w^(1024 i))
+int get_root_tables(swm_ctx* ctx, unsigned log_n, int inverse, NttTables** out);
 void prof_begin(swm_ctx* ctx, const char* name);
 void prof_end(swm_ctx* ctx);
 void prof_flush(swm_ctx* ctx);

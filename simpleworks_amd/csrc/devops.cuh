@@ -1,0 +1,391 @@
+// devops.cuh — device-resident Fr vectors and the polynomial plumbing of the Marlin prover (SURVEY.md §8f rank 1:
+// "KZG open + polynomial plumbing on device"): pointwise kernels, Horner evaluation, division by (X^m - z) as a
+// blocked linear recurrence, strided vanishing-polynomial division, and bulk ark_ff::UniformRand sampling from a
+// ChaCha keystream.  Everything here is HBM-bound integer work: one lane per element (or per short chunk),
+// 32-B elements, no LDS staging needed, no MFMA.
+// Replaces the cfg_iter!/rayon loops of ark-marlin's ahp/prover.rs and ark-poly's DensePolynomial helpers that
+// /root/reference/src/marlin/mod.rs:75 reaches (sources not vendored; behaviour from SURVEY.md A.3, A.5-A.7).
+#pragma once
+#include <utility>
+#include "context.h"
+#include "ff.cuh"
+#include "host/chacha.h"
+#include "host/marlin_types.h"
+
+namespace swm {
+
+int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
+             size_t rows);
+int batch_inverse_run(swm_ctx* ctx, void* d, size_t n);
+
+inline void hip_check(swm_ctx* ctx, hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        set_err(ctx, SWM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        throw MarlinError(e == hipErrorOutOfMemory ? SWM_ERR_OOM : SWM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+inline void rc_check(swm_ctx* ctx, int rc) {
+    if (rc != SWM_OK) throw MarlinError(rc, ctx->err);
+}
+
+// ------------------------------------------------------------------------------------------------ device vectors
+template <class T>
+struct DBuf {
+    swm_ctx* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    DBuf() {}
+    DBuf(swm_ctx* c, size_t count) : ctx(c), n(count) {
+        void* q = nullptr;
+        rc_check(c, pool_alloc(c, (count ? count : 1) * sizeof(T), &q, &cap));
+        p = (T*)q;
+    }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept { *this = std::move(o); }
+    DBuf& operator=(DBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            ctx = o.ctx; p = o.p; n = o.n; cap = o.cap;
+            o.p = nullptr; o.n = 0; o.cap = 0;
+        }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void release() {
+        if (p) pool_free(ctx, p, cap);
+        p = nullptr;
+    }
+    void zero() { hip_check(ctx, hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream), "memset"); }
+    void upload(const T* h, size_t count) {
+        hip_check(ctx, hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream), "h2d");
+        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    }
+    std::vector<T> download(size_t off, size_t count) const {
+        std::vector<T> h(count);
+        hip_check(ctx, hipMemcpyAsync(h.data(), p + off, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        return h;
+    }
+};
+typedef DBuf<Fr> DVec;
+
+inline DVec dv_zeros(swm_ctx* ctx, size_t n) {
+    DVec v(ctx, n);
+    v.zero();
+    return v;
+}
+// copy of src[0..len) zero-extended to n elements
+inline DVec dv_copy_padded(swm_ctx* ctx, const Fr* src, size_t len, size_t n) {
+    DVec v(ctx, n);
+    if (len > n) len = n;
+    if (len) hip_check(ctx, hipMemcpyAsync(v.p, src, len * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
+    if (n > len) hip_check(ctx, hipMemsetAsync(v.p + len, 0, (n - len) * sizeof(Fr), ctx->stream), "memset");
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise launcher
+template <class F>
+__global__ void __launch_bounds__(256) ew_kernel(size_t n, F f) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) f(i);
+}
+template <class F>
+inline void ew(swm_ctx* ctx, const char* name, size_t n, F f) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    prof_begin(ctx, name);
+    hipLaunchKernelGGL(ew_kernel<F>, dim3(grid), dim3(256), 0, ctx->stream, n, f);
+    prof_end(ctx);
+    hip_check(ctx, hipGetLastError(), name);
+}
+
+// w^e from the two-level tables (lo: e mod 1024, hi: e div 1024)
+struct PowTable {
+    const Fr* lo;
+    const Fr* hi;
+    __device__ __forceinline__ Fr at(uint64_t e) const {
+        Fr a = lo[e & 1023];
+        uint64_t h = e >> 10;
+        if (h) a = fp_mul(a, hi[h]);
+        return a;
+    }
+};
+inline PowTable root_pow_table(swm_ctx* ctx, unsigned log_n, bool inverse = false) {
+    NttTables* t = nullptr;
+    rc_check(ctx, get_root_tables(ctx, log_n, inverse ? 1 : 0, &t));
+    return PowTable{(const Fr*)t->lo, (const Fr*)t->hi};
+}
+
+inline void dv_ntt(swm_ctx* ctx, DVec& v, unsigned log_n, bool inverse, bool coset = false) {
+    if (v.n != ((size_t)1 << log_n)) throw MarlinError(SWM_ERR_INTERNAL, "dv_ntt: size mismatch");
+    rc_check(ctx, ntt_run(ctx, v.p, log_n, inverse ? 1 : 0, coset ? 1 : 0));
+}
+
+// ------------------------------------------------------------------------------------------------ suffix recurrence
+// In place: a[k] <- a[k] + z * a[k + m] (k descending), i.e. a[k] = sum_{i >= 0} z^i a_old[k + i m].
+// m = 1, z = point: synthetic division (quotient of p / (X - z) = a[1..], p(z) = a[0]).
+// z = 1, stride m:  quotient of p / (X^m - 1) = a[m..]  (DensePolynomial::divide_by_vanishing_poly).
+static constexpr int REC_T = 64;  // rows per lane
+
+__global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z, Fr* head, size_t nblk) {
+    // lane = (block of REC_T rows, column); rows = ceil(n / m)
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nblk * m) return;
+    size_t blk = t / m, col = t % m;
+    size_t rows = (n + m - 1) / m;
+    size_t r_hi = (blk + 1) * REC_T < rows ? (blk + 1) * REC_T : rows;
+    Fr acc = fp_zero<Fr>();
+    for (size_t r = r_hi; r-- > blk * REC_T;) {
+        size_t k = r * m + col;
+        if (k >= n) continue;
+        acc = fp_add(a[k], fp_mul(acc, z));
+        a[k] = acc;
+    }
+    head[blk * m + col] = acc;
+}
+__global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m, Fr z, const Fr* head, size_t nblk) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nblk * m) return;
+    size_t blk = t / m, col = t % m;
+    if (blk + 1 >= nblk) return;  // last block has no incoming carry
+    Fr carry = head[(blk + 1) * m + col];  // true value at the first row of the next block
+    size_t rows = (n + m - 1) / m;
+    size_t r_hi = (blk + 1) * REC_T < rows ? (blk + 1) * REC_T : rows;
+    Fr pw = z;
+    for (size_t r = r_hi; r-- > blk * REC_T;) {
+        size_t k = r * m + col;
+        if (k < n) a[k] = fp_add(a[k], fp_mul(pw, carry));
+        pw = fp_mul(pw, z);
+    }
+}
+__global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
+    size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (col >= m) return;
+    size_t rows = (n + m - 1) / m;
+    Fr acc = fp_zero<Fr>();
+    for (size_t r = rows; r-- > 0;) {
+        size_t k = r * m + col;
+        if (k >= n) continue;
+        acc = fp_add(a[k], fp_mul(acc, z));
+        a[k] = acc;
+    }
+}
+inline void suffix_recurrence(swm_ctx* ctx, Fr* a, size_t n, size_t m, const Fr& z) {
+    if (n == 0) return;
+    size_t rows = (n + m - 1) / m;
+    if (rows <= REC_T) {
+        prof_begin(ctx, "rec_serial");
+        hipLaunchKernelGGL(rec_serial, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, a, n, m, z);
+        prof_end(ctx);
+        hip_check(ctx, hipGetLastError(), "rec_serial");
+        return;
+    }
+    size_t nblk = (rows + REC_T - 1) / REC_T;
+    DVec head(ctx, nblk * m);
+    unsigned grid = (unsigned)((nblk * m + 255) / 256);
+    prof_begin(ctx, "rec_local");
+    hipLaunchKernelGGL(rec_local, dim3(grid), dim3(256), 0, ctx->stream, a, n, m, z, head.p, nblk);
+    prof_end(ctx);
+    hip_check(ctx, hipGetLastError(), "rec_local");
+    // heads obey the same recurrence with multiplier z^REC_T
+    Fr zt = z;
+    for (int i = 0; i < 6; i++) zt = fp_sqr(zt);  // REC_T = 64
+    static_assert(REC_T == 64, "zt exponent");
+    suffix_recurrence(ctx, head.p, nblk * m, m, zt);
+    prof_begin(ctx, "rec_fix");
+    hipLaunchKernelGGL(rec_fix, dim3(grid), dim3(256), 0, ctx->stream, a, n, m, z, head.p, nblk);
+    prof_end(ctx);
+    hip_check(ctx, hipGetLastError(), "rec_fix");
+}
+
+// p(x) for a device polynomial: copy + recurrence, value at index 0.  (Also yields the quotient by (X - x).)
+struct DivResult {
+    DVec work;  // work[0] = p(x); work[1..n) = quotient of p / (X - x)
+};
+inline DivResult div_linear(swm_ctx* ctx, const Fr* p, size_t n, const Fr& x) {
+    DivResult r;
+    r.work = dv_copy_padded(ctx, p, n, n ? n : 1);
+    if (n == 0) r.work.zero();
+    suffix_recurrence(ctx, r.work.p, n, 1, x);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ Horner evaluation
+static constexpr int EVAL_CHUNK = 64;
+__global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x, Fr* __restrict__ out,
+                                                   size_t nchunks) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    size_t lo = t * EVAL_CHUNK, hi = lo + EVAL_CHUNK < n ? lo + EVAL_CHUNK : n;
+    Fr acc = fp_zero<Fr>();
+    for (size_t k = hi; k-- > lo;) acc = fp_add(fp_mul(acc, x), c[k]);
+    out[t] = acc;
+}
+// returns p(x) on the host (synchronises)
+inline Fr poly_eval(swm_ctx* ctx, const Fr* p, size_t n, Fr x) {
+    if (n == 0) return fp_zero<Fr>();
+    DVec cur;
+    const Fr* src = p;
+    size_t len = n;
+    while (len > 1) {
+        size_t nchunks = (len + EVAL_CHUNK - 1) / EVAL_CHUNK;
+        DVec next(ctx, nchunks);
+        prof_begin(ctx, "poly_eval");
+        hipLaunchKernelGGL(eval_chunks, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream, src, len, x,
+                           next.p, nchunks);
+        prof_end(ctx);
+        hip_check(ctx, hipGetLastError(), "poly_eval");
+        for (int i = 0; i < 6; i++) x = fp_sqr(x);  // x^64
+        static_assert(EVAL_CHUNK == 64, "x exponent");
+        cur = std::move(next);
+        src = cur.p;
+        len = nchunks;
+    }
+    Fr out;
+    hip_check(ctx, hipMemcpyAsync(&out, src, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ u32 exclusive scan
+static constexpr int SC_BLOCK = 256, SC_ITEMS = 8, SC_TILE = SC_BLOCK * SC_ITEMS;
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* sm) {
+    uint32_t tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < SC_BLOCK; d <<= 1) {
+        uint32_t t = tid >= d ? sm[tid - d] : 0;
+        __syncthreads();
+        sm[tid] += t;
+        __syncthreads();
+    }
+    return sm[tid];
+}
+__global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* in, size_t n, uint32_t* tot) {
+    __shared__ uint32_t sm[SC_BLOCK];
+    size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t a = 0;
+    for (size_t i = lo; i < lo + SC_ITEMS && i < n; i++) a += in[i];
+    uint32_t inc = block_scan_incl(a, sm);
+    if (threadIdx.x == SC_BLOCK - 1) tot[blockIdx.x] = inc;
+}
+__global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint32_t ntiles) {
+    __shared__ uint32_t sm[SC_BLOCK];
+    uint32_t per = (ntiles + SC_BLOCK - 1) / SC_BLOCK;
+    uint32_t lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    uint32_t a = 0;
+    for (uint32_t i = lo; i < hi; i++) a += tot[i];
+    uint32_t inc = block_scan_incl(a, sm);
+    uint32_t run = inc - a;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t c = tot[i];
+        tot[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == SC_BLOCK - 1) tot[ntiles] = inc;
+}
+__global__ void __launch_bounds__(SC_BLOCK) scan_final(const uint32_t* in, size_t n, const uint32_t* tot, uint32_t* out) {
+    __shared__ uint32_t sm[SC_BLOCK];
+    size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    uint32_t a = 0;
+    for (size_t i = lo; i < lo + SC_ITEMS && i < n; i++) a += in[i];
+    uint32_t inc = block_scan_incl(a, sm);
+    uint32_t run = tot[blockIdx.x] + inc - a;
+    for (size_t i = lo; i < lo + SC_ITEMS && i < n; i++) {
+        out[i] = run;
+        run += in[i];
+    }
+}
+// out[i] = sum_{j < i} in[j]; *total (device word at tot[ntiles]) is returned through `total_out` on the host
+inline uint32_t scan_exclusive_u32(swm_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n) {
+    unsigned ntiles = (unsigned)((n + SC_TILE - 1) / SC_TILE);
+    DBuf<uint32_t> tot(ctx, ntiles + 1);
+    hipLaunchKernelGGL(scan_totals, dim3(ntiles), dim3(SC_BLOCK), 0, ctx->stream, in, n, tot.p);
+    hipLaunchKernelGGL(scan_mid, dim3(1), dim3(SC_BLOCK), 0, ctx->stream, tot.p, ntiles);
+    hipLaunchKernelGGL(scan_final, dim3(ntiles), dim3(SC_BLOCK), 0, ctx->stream, in, n, tot.p, out);
+    hip_check(ctx, hipGetLastError(), "scan");
+    return tot.download(ntiles, 1)[0];
+}
+
+// ------------------------------------------------------------------------------------------------ bulk Fr sampling
+// Candidate j = keystream words [pos + 8 j, pos + 8 j + 8) as 4 little-endian u64 limbs with the top 3 bits
+// cleared; accepted when < r (ark_ff UniformRand for Fp256).  The accepted limbs are the Montgomery
+// representation, so they are written to the coefficient vector as they are.
+struct ChaChaKey {
+    uint32_t k[8];
+};
+__global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, int rounds, uint64_t pos, size_t m,
+                                                         Fr* __restrict__ cand, uint32_t* __restrict__ flag) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    uint64_t w0 = pos + 8 * j;
+    uint32_t blk[16], blk2[16];
+    chacha_block(key.k, w0 >> 4, rounds, blk);
+    unsigned off = (unsigned)(w0 & 15);
+    bool two = off + 8 > 16;
+    if (two) chacha_block(key.k, (w0 >> 4) + 1, rounds, blk2);
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        unsigned idx = off + i;
+        r.v[i] = idx < 16 ? blk[idx & 15] : blk2[idx & 15];
+    }
+    r.v[7] &= 0xffffffffu >> 3;
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (!decided && r.v[i] != FrParams::P[i]) {
+            lt = r.v[i] < FrParams::P[i];
+            decided = true;
+        }
+    }
+    cand[j] = r;
+    flag[j] = lt ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) sample_compact(const Fr* __restrict__ cand, const uint32_t* __restrict__ flag,
+                                                      const uint32_t* __restrict__ rank, size_t m, size_t need,
+                                                      Fr* __restrict__ out, uint32_t* __restrict__ last_idx) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= m || !flag[j]) return;
+    uint32_t r = rank[j];
+    if (r < need) {
+        out[r] = cand[j];
+        if (r + 1 == need) *last_idx = (uint32_t)j;
+    }
+}
+// Draws `need` field elements from rng's stream into out[0..need) (device), advancing rng exactly as `need`
+// successive Fr::rand(rng) calls would.
+inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need) {
+    size_t done = 0;
+    while (done < need) {
+        size_t want = need - done;
+        size_t m = (size_t)((double)want / 0.58 * 1.02) + 2048;
+        DVec cand(ctx, m);
+        DBuf<uint32_t> flag(ctx, m), rank(ctx, m), last(ctx, 1);
+        ChaChaKey key;
+        for (int i = 0; i < 8; i++) key.k[i] = rng.key[i];
+        unsigned grid = (unsigned)((m + 255) / 256);
+        prof_begin(ctx, "sample_fr");
+        hipLaunchKernelGGL(sample_candidates, dim3(grid), dim3(256), 0, ctx->stream, key, rng.rounds, rng.pos, m, cand.p,
+                           flag.p);
+        prof_end(ctx);
+        uint32_t accepted = scan_exclusive_u32(ctx, flag.p, rank.p, m);
+        size_t take = accepted < want ? accepted : want;
+        if (take) {
+            hipLaunchKernelGGL(sample_compact, dim3(grid), dim3(256), 0, ctx->stream, cand.p, flag.p, rank.p, m, take,
+                               out + done, last.p);
+            hip_check(ctx, hipGetLastError(), "sample_compact");
+        }
+        if (accepted >= want) {
+            uint32_t li = last.download(0, 1)[0];
+            rng.pos += 8ull * ((uint64_t)li + 1);
+        } else {
+            rng.pos += 8ull * m;
+        }
+        rng.have = false;
+        done += take;
+    }
+}
+
+}  // namespace swm

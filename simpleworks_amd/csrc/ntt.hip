@@ -137,7 +137,7 @@ static int two_level_tables(swm_ctx* ctx, const Fr& base, size_t max_exp, NttTab
     return SWM_OK;
 }
 
-static int get_root_tables(swm_ctx* ctx, unsigned log_n, int inverse, NttTables** out) {
+int get_root_tables(swm_ctx* ctx, unsigned log_n, int inverse, NttTables** out) {
     uint64_t key = ((uint64_t)log_n << 1) | (inverse ? 1 : 0);
     auto it = ctx->ntt_tables.find(key);
     if (it == ctx->ntt_tables.end()) {

@@ -1,0 +1,297 @@
+"""Mirror of /root/reference/src/marlin/mod.rs: the same free functions, argument meaning and error behaviour,
+implemented on top of libswmarlin.so (HIP kernels on MI355X).  No CPU fallback: setup, indexing and proving need
+the GPU; verify_proof is host arithmetic in the reference as well and runs without one.
+
+    reference (Rust)                                            here (Python over the C ABI)
+    generate_rand() -> StdRng                                   generate_rand() -> Rng
+    generate_universal_srs(nc, nv, nnz, &mut rng)               generate_universal_srs(nc, nv, nnz, rng)
+    generate_proving_and_verifying_keys(&srs, cs)               generate_proving_and_verifying_keys(srs, cs)
+    generate_proof(cs, proving_key, &mut rng) -> MarlinProof    generate_proof(cs, proving_key, rng) -> MarlinProof
+    verify_proof(vk, &public_inputs, &proof, &mut rng)          verify_proof(vk, public_inputs, proof, rng) -> bool
+Errors surface as MarlinError (the reference returns anyhow::Error built from the arkworks error's Debug string).
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import SwmError, load_library, _p64, _p32, _vp, Context
+
+R_MODULUS = 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001
+_MONT_R = (1 << 256) % R_MODULUS
+_M64 = (1 << 64) - 1
+
+
+class MarlinError(SwmError):
+    pass
+
+
+def _to_mont_limbs(values):
+    """ints (standard form) -> (n, 4) uint64 Montgomery limbs (ark-ff Fp256 layout)."""
+    out = np.empty((len(values), 4), dtype=np.uint64)
+    for i, v in enumerate(values):
+        m = (int(v) % R_MODULUS) * _MONT_R % R_MODULUS
+        for k in range(4):
+            out[i, k] = (m >> (64 * k)) & _M64
+    return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """The process-wide GPU context (one GPU, one stream).  Raises SwmError when no MI355X is usable."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class Rng:
+    """rand::rngs::StdRng handle (ChaCha12)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().swm_rng_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def next_u64(self):
+        v = ctypes.c_uint64(0)
+        _check(load_library().swm_rng_next_u64(self.h, ctypes.byref(v)), "swm_rng_next_u64")
+        return v.value
+
+    def rand_fr_mont(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(load_library().swm_rng_rand_fr(self.h, _p64(out)), "swm_rng_rand_fr")
+        return out
+
+
+def _check(rc, what, ctx=None):
+    if rc != 0:
+        detail = ctx.lib.swm_last_error(ctx.h).decode(errors="replace") if ctx is not None else ""
+        raise MarlinError(rc, what, detail)
+
+
+def generate_rand():
+    """src/marlin/mod.rs:33-35 — ark_std::test_rng()."""
+    h = _vp()
+    _check(load_library().swm_rng_test_new(ctypes.byref(h)), "swm_rng_test_new")
+    return Rng(h)
+
+
+def rng_from_seed(seed32):
+    h = _vp()
+    buf = (ctypes.c_uint8 * 32)(*bytes(seed32))
+    _check(load_library().swm_rng_from_seed(buf, ctypes.byref(h)), "swm_rng_from_seed")
+    return Rng(h)
+
+
+class ConstraintSystem:
+    """What a ConstraintSystemRef<Fr> (src/marlin/mod.rs:16) holds once a ConstraintSynthesizer has run:
+    variables with their assignment and the rows a * b = c.  Same builder vocabulary as ark-relations:
+    new_input_variable / new_witness_variable / enforce_constraint(a, b, c) with linear combinations given as
+    lists of (coefficient, variable); ConstraintSystem.one() is the constant."""
+
+    def __init__(self):
+        self.instance = [1]
+        self.witness = []
+        self.rows = ([], [], [])
+
+    @staticmethod
+    def one():
+        return ("i", 0)
+
+    def new_input_variable(self, value):
+        self.instance.append(int(value) % R_MODULUS)
+        return ("i", len(self.instance) - 1)
+
+    def new_witness_variable(self, value):
+        self.witness.append(int(value) % R_MODULUS)
+        return ("w", len(self.witness) - 1)
+
+    def enforce_constraint(self, a, b, c):
+        for dst, lc in zip(self.rows, (a, b, c)):
+            dst.append(list(lc))
+
+    @property
+    def num_constraints(self):
+        return len(self.rows[0])
+
+    def num_instance_variables(self):
+        return len(self.instance)
+
+    def num_witness_variables(self):
+        return len(self.witness)
+
+    def _csr(self, rows):
+        ninst = len(self.instance)
+        rowptr = np.zeros(len(rows) + 1, dtype=np.uint32)
+        cols, vals = [], []
+        for r, lc in enumerate(rows):
+            acc = {}
+            for coeff, (kind, k) in lc:
+                col = k if kind == "i" else ninst + k
+                acc[col] = (acc.get(col, 0) + int(coeff)) % R_MODULUS
+            for col in sorted(acc):
+                if acc[col]:
+                    cols.append(col)
+                    vals.append(acc[col])
+            rowptr[r + 1] = len(cols)
+        return rowptr, np.array(cols, dtype=np.uint32), _to_mont_limbs(vals)
+
+    def pack(self):
+        """Flat arrays in the layout of struct swm_r1cs (kept alive by the returned object)."""
+        return PackedR1cs(_to_mont_limbs(self.instance), _to_mont_limbs(self.witness), *[self._csr(r) for r in self.rows])
+
+    def is_satisfied(self, ctx=None):
+        """ConstraintSystem::is_satisfied on the GPU (K3): A z o B z == C z."""
+        return self.pack().is_satisfied(ctx)
+
+
+class _R1csStruct(ctypes.Structure):
+    _fields_ = [("num_instance", ctypes.c_size_t), ("num_witness", ctypes.c_size_t), ("num_constraints", ctypes.c_size_t),
+                ("instance", ctypes.c_void_p), ("witness", ctypes.c_void_p),
+                ("a_rowptr", ctypes.c_void_p), ("a_col", ctypes.c_void_p), ("a_val", ctypes.c_void_p),
+                ("b_rowptr", ctypes.c_void_p), ("b_col", ctypes.c_void_p), ("b_val", ctypes.c_void_p),
+                ("c_rowptr", ctypes.c_void_p), ("c_col", ctypes.c_void_p), ("c_val", ctypes.c_void_p)]
+
+
+class PackedR1cs:
+    """A synthesised constraint system as flat numpy arrays (instance/witness Montgomery limbs + CSR of A, B, C)."""
+
+    def __init__(self, instance, witness, a, b, c):
+        self.instance = np.ascontiguousarray(instance, dtype=np.uint64).reshape(-1, 4)
+        self.witness = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+        self.mats = []
+        for rowptr, col, val in (a, b, c):
+            self.mats.append((np.ascontiguousarray(rowptr, dtype=np.uint32), np.ascontiguousarray(col, dtype=np.uint32),
+                              np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 4)))
+        self.num_constraints = self.mats[0][0].shape[0] - 1
+
+    def struct(self):
+        s = _R1csStruct()
+        s.num_instance = self.instance.shape[0]
+        s.num_witness = self.witness.shape[0]
+        s.num_constraints = self.num_constraints
+        s.instance = self.instance.ctypes.data
+        s.witness = self.witness.ctypes.data if self.witness.size else None
+        for name, (rowptr, col, val) in zip("abc", self.mats):
+            setattr(s, name + "_rowptr", rowptr.ctypes.data)
+            setattr(s, name + "_col", col.ctypes.data if col.size else None)
+            setattr(s, name + "_val", val.ctypes.data if val.size else None)
+        return s
+
+    def pack(self):
+        return self
+
+    def is_satisfied(self, ctx=None):
+        ctx = ctx or default_context()
+        ok = ctypes.c_int(0)
+        bad = ctypes.c_size_t(0)
+        s = self.struct()
+        _check(ctx.lib.swm_r1cs_is_satisfied(ctx.h, ctypes.byref(s), ctypes.byref(ok), ctypes.byref(bad)),
+               "swm_r1cs_is_satisfied", ctx)
+        return bool(ok.value)
+
+
+class UniversalSRS:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def max_degree(self):
+        return self.ctx.lib.swm_srs_max_degree(self.h)
+
+    def power_of_g(self, i):
+        out = np.zeros(12, dtype=np.uint64)
+        _check(self.ctx.lib.swm_srs_power_of_g(self.ctx.h, self.h, i, _p64(out)), "swm_srs_power_of_g", self.ctx)
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.swm_srs_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class ProvingKey:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.swm_pk_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class VerifyingKey:
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().swm_vk_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class MarlinProof:
+    """ark_marlin::Proof, held in its CanonicalSerialize byte form."""
+
+    def __init__(self, data):
+        self.data = bytes(data)
+
+
+def generate_universal_srs(num_constraints, num_variables, num_non_zero, rng, ctx=None):
+    """src/marlin/mod.rs:45-55."""
+    ctx = ctx or default_context()
+    h = _vp()
+    _check(ctx.lib.swm_generate_universal_srs(ctx.h, num_constraints, num_variables, num_non_zero, rng.h, ctypes.byref(h)),
+           "swm_generate_universal_srs", ctx)
+    return UniversalSRS(ctx, h)
+
+
+def generate_proving_and_verifying_keys(universal_srs, constraint_system):
+    """src/marlin/mod.rs:88-94."""
+    ctx = universal_srs.ctx
+    packed = constraint_system.pack()
+    s = packed.struct()
+    pk, vk = _vp(), _vp()
+    _check(ctx.lib.swm_generate_proving_and_verifying_keys(ctx.h, universal_srs.h, ctypes.byref(s), ctypes.byref(pk),
+                                                           ctypes.byref(vk)), "swm_generate_proving_and_verifying_keys", ctx)
+    return ProvingKey(ctx, pk), VerifyingKey(vk)
+
+
+def generate_proof(constraint_system, proving_key, rng):
+    """src/marlin/mod.rs:70-77.  Raises MarlinError(SWM_ERR_UNSATISFIED) for an unsatisfied witness."""
+    ctx = proving_key.ctx
+    packed = constraint_system.pack()
+    s = packed.struct()
+    buf = (ctypes.c_uint8 * 2048)()
+    n = ctypes.c_size_t(0)
+    _check(ctx.lib.swm_generate_proof(ctx.h, proving_key.h, ctypes.byref(s), rng.h, buf, len(buf), ctypes.byref(n)),
+           "swm_generate_proof", ctx)
+    return MarlinProof(bytes(buf[: n.value]))
+
+
+def verify_proof(verifying_key, public_inputs, proof, rng):
+    """src/marlin/mod.rs:79-86.  public_inputs: field elements as ints (e.g. the bit-expanded inputs of
+    src/merkle_tree/simple_merkle_tree.rs:129-143)."""
+    lib = load_library()
+    pi = _to_mont_limbs(list(public_inputs))
+    data = (ctypes.c_uint8 * len(proof.data)).from_buffer_copy(proof.data)
+    ok = ctypes.c_int(0)
+    _check(lib.swm_verify_proof(verifying_key.h, _p64(pi) if len(pi) else None, len(pi), data, len(proof.data), rng.h,
+                                ctypes.byref(ok)), "swm_verify_proof")
+    return bool(ok.value)

@@ -1,0 +1,128 @@
+"""GPU parity tests of the Marlin surface (setup / index / prove through the C ABI on an MI355X):
+  * byte-for-byte against the golden vectors produced by the independent pure-Python prover (tests/golden/marlin.json)
+    for the reference's own plumbing case (examples/manual-constraints.rs:86-100) and synthetic circuits;
+  * prove -> verify == true, tampered -> false, unsatisfied witness -> prove-time error (the reference's test
+    strategy) at sizes the Python model cannot reach."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, golden, h2i
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    from simpleworks_amd import marlin
+    return marlin
+
+
+@pytest.fixture(scope="module")
+def S():
+    from simpleworks_amd import serialization
+    return serialization
+
+
+@pytest.fixture(scope="module")
+def W():
+    from simpleworks_amd import workloads
+    return workloads
+
+
+def _affine(orc, xy):
+    return orc.points_from_mont(np.ascontiguousarray(xy).reshape(1, 12))[0]
+
+
+@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32"])
+def test_golden_proof_bytes(M, S, W, name):
+    case = golden("marlin.json")[name]
+    orc = Oracle()
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*case["srs"], rng)
+    assert srs.max_degree == case["max_degree"]
+    assert _affine(orc, srs.power_of_g(0)) == (h2i(case["srs_g"][0]), h2i(case["srs_g"][1]))
+    assert _affine(orc, srs.power_of_g(1)) == (h2i(case["srs_g1"][0]), h2i(case["srs_g1"][1]))
+    if name == "manual_constraints":
+        cs = W.manual_constraints_circuit(1, 1)
+    else:
+        cs = W.synthetic_circuit(case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
+    assert cs.is_satisfied()
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]
+    proof = M.generate_proof(cs, pk, rng)
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert M.verify_proof(vk, [h2i(x) for x in case["public_input"]], proof, rng)
+    pk.free()
+    srs.free()
+
+
+def test_unsatisfied_witness_fails_at_prove_time(M, W):
+    """examples/schnorr-signature/main.rs:214-217 expects proving an unsatisfied circuit to fail (panic) at prove time."""
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(100, 25, 300, rng)
+    good = W.manual_constraints_circuit(1, 1)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, good)
+    bad = W.manual_constraints_circuit(1, 2)
+    assert not bad.is_satisfied()
+    with pytest.raises(M.MarlinError) as e:
+        M.generate_proof(bad, pk, rng)
+    assert e.value.code == -5
+    # SRS too small for the circuit
+    small = M.generate_universal_srs(2, 2, 2, M.generate_rand())
+    with pytest.raises(M.MarlinError) as e:
+        M.generate_proving_and_verifying_keys(small, W.synthetic_circuit(32, 3, 5))
+    assert e.value.code == -6
+    pk.free()
+    srs.free()
+    small.free()
+
+
+@pytest.mark.parametrize("log_n", [10, 14, 16])
+def test_prove_verify_roundtrip(M, S, W, log_n):
+    n = 1 << log_n
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 0x1234567 + log_n, 0x7654321)
+    assert cs.is_satisfied()
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    proof = M.generate_proof(cs, pk, rng)
+    assert len(proof.data) == 951
+    vk2 = S.deserialize_verifying_key(S.serialize_verifying_key(vk))
+    assert M.verify_proof(vk2, public, S.deserialize_proof(S.serialize_proof(proof)), M.generate_rand())
+    assert not M.verify_proof(vk, [public[0], (public[1] + 1) % M.R_MODULUS], proof, M.generate_rand())
+    t = bytearray(proof.data)
+    t[569 + 8 + 32 * 3] ^= 0x10
+    assert not M.verify_proof(vk, public, M.MarlinProof(bytes(t)), M.generate_rand())
+    # a second proof from the same key uses fresh blinding: different bytes, still valid
+    proof2 = M.generate_proof(cs, pk, rng)
+    assert proof2.data != proof.data
+    assert M.verify_proof(vk, public, proof2, M.generate_rand())
+    # unsatisfied witness at this size
+    bad, _ = W.synthetic_r1cs(n, 3, 5)
+    bad.witness[0, 0] ^= np.uint64(1)
+    assert not bad.is_satisfied()
+    with pytest.raises(M.MarlinError) as e:
+        M.generate_proof(bad, pk, rng)
+    assert e.value.code == -5
+    pk.free()
+    srs.free()
+
+
+def test_proving_key_roundtrip(M, S, W):
+    n = 1 << 10
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 11, 13)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    blob = S.serialize_proving_key(pk)
+    pk2 = S.deserialize_proving_key(blob)
+    seed = bytes(range(32))
+    p1 = M.generate_proof(cs, pk, M.rng_from_seed(seed))
+    p2 = M.generate_proof(cs, pk2, M.rng_from_seed(seed))
+    assert p1.data == p2.data
+    assert M.verify_proof(vk, public, p2, M.generate_rand())
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proving_key(blob[:-5])
+    pk.free()
+    pk2.free()
+    srs.free()

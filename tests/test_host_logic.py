@@ -1,0 +1,115 @@
+"""CPU tests of the host logic inside libswmarlin.so (no GPU needed): transcript primitives against RFC /
+published vectors and the committed fixtures, the ark-serialize codecs, and the pairing-based verifier against
+the golden proofs produced by the independent pure-Python prover (tests/golden/marlin.json)."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle_lib import golden, h2i
+
+import simpleworks_amd._lib as L
+from simpleworks_amd import marlin as M
+from simpleworks_amd import serialization as S
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load_library()
+
+
+def test_blake2s_vectors(lib):
+    g = golden("rng.json")
+    for data, key in ((b"abc", "blake2s_abc"), (b"", "blake2s_empty"), (bytes(i & 0xFF for i in range(200)), "blake2s_200")):
+        out = (ctypes.c_uint8 * 32)()
+        buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        assert lib.swm_blake2s(buf, len(data), out) == 0
+        assert bytes(out).hex() == g[key] == hashlib.blake2s(data).hexdigest()
+    # RFC 7693 Appendix B
+    assert g["blake2s_abc"] == "508c5e8c327c14e2e1a72ba34eeb452f37458b209ed63a294d999b4c86675982"
+    for n in (63, 64, 65, 127, 128, 129, 1000):
+        data = bytes((7 * i + n) & 0xFF for i in range(n))
+        out = (ctypes.c_uint8 * 32)()
+        buf = (ctypes.c_uint8 * n).from_buffer_copy(data)
+        lib.swm_blake2s(buf, n, out)
+        assert bytes(out) == hashlib.blake2s(data).digest(), n
+
+
+def test_chacha_keystream_vectors(lib):
+    g = golden("rng.json")
+    key = (ctypes.c_uint8 * 32)()
+    for rounds, ctr, name in ((20, 0, "chacha20_zero_key_block0"), (12, 0, "chacha12_zero_key_block0"),
+                              (8, 0, "chacha8_zero_key_block0"), (20, 1, "chacha20_zero_key_block1")):
+        out = (ctypes.c_uint8 * 64)()
+        assert lib.swm_chacha_block(key, ctr, rounds, out) == 0
+        assert bytes(out).hex() == g[name]
+    # djb / RFC 7539 zero-key keystream
+    assert g["chacha20_zero_key_block0"].startswith("76b8e0ada0f13d90405d6ae55386bd28")
+
+
+def test_test_rng_stream(lib):
+    g = golden("rng.json")
+    rng = M.generate_rand()
+    assert [hex(rng.next_u64()) for _ in range(70)] == g["test_rng_u64"]
+    rng = M.generate_rand()
+    R = M.R_MODULUS
+    rinv = pow(1 << 256, -1, R)
+    for exp in g["test_rng_fr"]:
+        limbs = rng.rand_fr_mont()
+        mont = sum(int(limbs[k]) << (64 * k) for k in range(4))
+        assert hex(mont * rinv % R) == exp
+
+
+def _pub(case):
+    return [h2i(x) for x in case["public_input"]]
+
+
+@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32"])
+def test_verifier_accepts_golden_proofs(name):
+    case = golden("marlin.json")[name]
+    vk = S.deserialize_verifying_key(bytes.fromhex(case["vk"]))
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]  # codec round trip, byte for byte
+    proof = S.deserialize_proof(bytes.fromhex(case["proof"]))
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert len(proof.data) == 951
+    assert M.verify_proof(vk, _pub(case), proof, M.generate_rand()) is True
+    # wrong public input
+    bad = list(_pub(case))
+    bad[0] = (bad[0] + 1) % M.R_MODULUS
+    assert M.verify_proof(vk, bad, proof, M.generate_rand()) is False
+
+
+def test_verifier_rejects_tampered_proofs():
+    case = golden("marlin.json")["synthetic_8"]
+    vk = S.deserialize_verifying_key(bytes.fromhex(case["vk"]))
+    raw = bytearray(bytes.fromhex(case["proof"]))
+    # flip one bit in the first evaluation (offset: commitments block is 569 bytes, then the u64 length)
+    t = bytearray(raw)
+    t[569 + 8] ^= 1
+    assert M.verify_proof(vk, _pub(case), M.MarlinProof(bytes(t)), M.generate_rand()) is False
+    # swap two commitments of round 1 (w <-> z_a)
+    t = bytearray(raw)
+    a, b = 16, 16 + 49
+    t[a:a + 49], t[b:b + 49] = raw[b:b + 49], raw[a:a + 49]
+    assert M.verify_proof(vk, _pub(case), M.MarlinProof(bytes(t)), M.generate_rand()) is False
+    # truncated / trailing garbage must fail to deserialize, not crash
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proof(bytes(raw[:-1]))
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proof(bytes(raw) + b"\x00")
+    with pytest.raises(M.MarlinError):
+        S.deserialize_verifying_key(bytes.fromhex(case["vk"])[:-3])
+
+
+def test_python_reference_agrees_with_fixture():
+    """The pure-Python prover regenerates the committed proof bytes (guards the fixture against drift)."""
+    from pyref import marlin as P
+    case = golden("marlin.json")["synthetic_8"]
+    rng = P.generate_rand()
+    cs = P.synthetic_circuit(8, h2i(case["a"]), h2i(case["b"]))
+    srs = P.generate_universal_srs(8, 8, 8, rng)
+    pk, vk = P.generate_proving_and_verifying_keys(srs, cs)
+    proof = P.generate_proof(cs, pk, rng)
+    assert P.serialize_proof(proof).hex() == case["proof"]
+    assert P.serialize_verifying_key(vk).hex() == case["vk"]
