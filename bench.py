@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — headline measurement of the hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""bench.py — headline measurement of the hot path on MI355X (contract: task statement; notes in DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm|prove] [--log-n L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload prove|msm] [--log-n L]
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.
-  workload msm   : one G1 MSM over 2^L SRS-shaped bases [tau^i]G with uniform Fr scalars (Montgomery form in HBM,
-                   i.e. polynomial coefficients as the prover hands them to KZG commit).  value = points/s.
-With N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank owns a 2^L-point shard of a
-N*2^L-point MSM; the per-rank Jacobian partials (144 B) are all-gathered and folded on every rank ("weak" scaling).
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM.
+  workload prove (default) : one Marlin prove() of the 2^L-constraint synthetic R1CS (BASELINE.json configs[2]; L = 20):
+                             universal SRS and proving key are built once, untimed, and stay device resident; the
+                             timed region is generate_proof (witness upload included).  value = constraints/s.
+  workload msm             : one G1 MSM over 2^L SRS-shaped bases [tau^i]G with uniform Montgomery scalars in HBM.
+                             value = points/s.
+With N > 1 (torch.distributed.run, one rank per GPU, RCCL): `prove` runs one independent proof per rank (replicas,
+weak scaling, no data-path collective); `msm` gives each rank a 2^L-point shard of an N*2^L-point MSM and folds the
+144-byte Jacobian partials after an all-gather.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -25,41 +28,79 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = "Marlin prove() constraints/sec at 2^20 R1CS; G1 MSM points/sec"
+FR_R = int("12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001", 16)
 
 
-def cpu_baseline_msm(orc, log_n_sample, tau, G):
-    """arkworks-algorithm CPU restatement (oracle/oracle.c: VariableBaseMSM, one task per window) on a bounded
-    sample of the same workload, timed on this host."""
+def _oracle_inputs():
+    from oracle_lib import Oracle, golden, h2i
+    orc = Oracle()
+    tau = h2i(golden("msm.json")["tau"])
+    G = orc.points_to_mont([tuple(h2i(v) for v in golden("g1.json")["generator"])])
+    return orc, tau, G
+
+
+def cpu_baseline_msm(log_n_sample):
+    """arkworks-algorithm CPU restatement (oracle/oracle.c: VariableBaseMSM, one thread per window) on a bounded
+    sample of the MSM workload, timed on this host."""
     from pyref.prng import fr_array
+    orc, tau, G = _oracle_inputs()
     n = 1 << log_n_sample
     bases = orc.srs_bases(n, tau, G)
     sc = fr_array(n, 7)
-    nwin = (253 + orc.lib.oracle_msm_window(n) - 1) // orc.lib.oracle_msm_window(n)
+    c = orc.lib.oracle_msm_window(n)
+    nwin = (253 + c - 1) // c
     threads = max(1, min(nwin, orc.lib.oracle_max_threads(), os.cpu_count() or 1))
     t0 = time.perf_counter()
     orc.msm(bases, sc, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
             "sample": "one 2^%d-point G1 MSM, arkworks Pippenger (c=%d, %d windows, one thread per window), %.2f s"
-                      % (log_n_sample, orc.lib.oracle_msm_window(n), nwin, dt)}
+                      % (log_n_sample, c, nwin, dt)}
+
+
+def cpu_baseline_prove(log_n_sample):
+    """CPU port of one prove() at a bounded size: the oracle's arkworks-algorithm kernels (Pippenger MSM with arkworks'
+    window rule, radix-2 FFT, both with OpenMP where arkworks' `parallel` feature uses rayon) run over the SAME call
+    list one GPU prove() issues at N = 2^log_n_sample (17 MSMs, 19 NTTs; sizes below), with random
+    coefficients.  Reported as constraints/s = N / total time."""
+    from pyref.prng import fr_array
+    orc, tau, G = _oracle_inputs()
+    N = 1 << log_n_sample
+    threads = max(1, min(orc.lib.oracle_max_threads(), os.cpu_count() or 1, 32))
+    bases = orc.srs_bases(3 * N, tau, G)
+    msm_sizes = [N, N + 1, N + 1, 3 * N, N, N - 1, N - 1, 2 * N + 1, N - 1, N - 1, 3 * N - 3, 3 * N - 1, N - 2, 3 * N - 4, N - 2]
+    ntt_logs = [log_n_sample] * 9 + [log_n_sample + 2] * 10
+    sc = fr_array(3 * N, 8)
+    x = orc.fr_to_mont(fr_array(4 * N, 9))
+    t0 = time.perf_counter()
+    for m in msm_sizes:
+        orc.msm(np.ascontiguousarray(bases[:m]), np.ascontiguousarray(sc[:m]), threads=threads)
+    t_msm = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for lg in ntt_logs:
+        orc.ntt(np.ascontiguousarray(x[: 1 << lg]), lg, 0, 0, threads)
+    t_ntt = time.perf_counter() - t1
+    dt = t_msm + t_ntt
+    return {"value": N / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "kernel calls of one prove() at N=2^%d replayed on the CPU oracle: %d MSMs (%.1f N points, %.2f s) + %d "
+                      "NTTs (%.2f s); mat-vec and pointwise work omitted (< 5 %%)"
+                      % (log_n_sample, len(msm_sizes), sum(msm_sizes) / N, t_msm, len(ntt_logs), t_ntt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="msm", choices=["msm"])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="prove", choices=["prove", "msm"])
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-log-n", type=int, default=18)
+    ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import simpleworks_amd as swm
-    from oracle_lib import Oracle, golden, h2i  # oracle: input generation + cpu_baseline leg only
-    from pyref.prng import fr_array
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,30 +111,50 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     ctx = swm.Context(local_rank)
-    orc = Oracle()
     n = 1 << args.log_n
-    tau = h2i(golden("msm.json")["tau"])
-    G = orc.points_to_mont([tuple(h2i(v) for v in golden("g1.json")["generator"])])
-    # rank r owns bases [tau^(r n) .. tau^((r+1) n)) of the global SRS: shift the generator by tau^(r n)
-    shift = pow(tau, rank * n, int("12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001", 16))
-    from oracle_lib import ints_to_limbs
-    G_r = orc.fixed_base_mul(G, ints_to_limbs([shift], 4), threads=1) if rank else G
-    bases = orc.srs_bases(n, tau, np.ascontiguousarray(G_r.reshape(1, 12)))
-    bh = ctx.srs_upload(bases)
-    d_sc = ctx.to_device(fr_array(n, 1000 + rank))  # any reduced limbs are valid Montgomery residues
-    del bases
 
-    def step():
-        part = ctx.msm_g1_dev(bh, d_sc, n, True)
-        if world > 1:
-            t = torch.from_numpy(part.view(np.int64)).cuda()
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
-            acc = out[0].cpu().numpy().view(np.uint64)
-            for o in out[1:]:
-                acc = ctx.g1_add_jac(acc, o.cpu().numpy().view(np.uint64))
-            return acc
-        return part
+    if args.workload == "msm":
+        from oracle_lib import ints_to_limbs
+        from pyref.prng import fr_array
+        orc, tau, G = _oracle_inputs()  # oracle used for INPUT generation only ([tau^i]G bases)
+        shift = pow(tau, rank * n, FR_R)
+        G_r = orc.fixed_base_mul(G, ints_to_limbs([shift], 4), threads=1) if rank else G
+        bases = orc.srs_bases(n, tau, np.ascontiguousarray(G_r.reshape(1, 12)))
+        bh = ctx.srs_upload(bases)
+        d_sc = ctx.to_device(fr_array(n, 1000 + rank))  # any reduced limbs are valid Montgomery residues
+        del bases
+
+        def step():
+            part = ctx.msm_g1_dev(bh, d_sc, n, True)
+            if world > 1:
+                t = torch.from_numpy(part.view(np.int64)).cuda()
+                out = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(out, t)
+                acc = out[0].cpu().numpy().view(np.uint64)
+                for o in out[1:]:
+                    acc = ctx.g1_add_jac(acc, o.cpu().numpy().view(np.uint64))
+                return acc
+            return part
+        dominant, units, unit = "msm_accumulate", n, "points/s"
+        alg_bytes = 128.0 * n  # 96 B affine base + 32 B scalar per point (SURVEY §8d), n points per launch
+        workload = "g1_msm: 2^%d SRS-shaped bases [tau^i]G per GPU, uniform Fr scalars resident in HBM" % args.log_n
+    else:
+        from simpleworks_amd import marlin as M
+        from simpleworks_amd import workloads as W
+        M.set_default_context(ctx)
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(n, n, n, rng)
+        cs, public = W.synthetic_r1cs(n, 0x1234567 + rank, 0x7654321)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        last = {}
+
+        def step():
+            last["proof"] = M.generate_proof(cs, pk, rng)
+        dominant, units, unit = "msm_accumulate", n, "constraints/s"
+        alg_bytes = None
+        workload = ("marlin_prove: synthetic R1CS, 2^%d constraints = variables = non-zeros per matrix (|H| = |K| = 2^%d), "
+                    "SRS + proving key device resident" % (args.log_n, args.log_n))
 
     def sync():
         ctx.synchronize()
@@ -114,29 +175,41 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile()
+    if args.workload == "prove":
+        assert M.verify_proof(vk, public, last["proof"], M.generate_rand()), "bench: proof does not verify"
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
-        total_points = n * world * args.steps
-        dom = prof["msm_accumulate"]
-        alg_bytes = 128.0 * n  # SURVEY §8d: 96 B affine base + 32 B scalar per point, n points per launch
+        dom = prof[dominant]
+        launches_per_step = dom["calls"] / args.steps
+        work = dict(ctx.last_work)
+        if alg_bytes is None:
+            # dominant kernel of prove(): the bucket accumulation behind the KZG commitments, one launch per MSM.
+            # Algorithmic bytes per launch = 128 B x (points the library logged) / (MSM launches)  (SURVEY §8d).
+            alg_bytes = 128.0 * work["msm_points"] / work["msm_calls"]
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
         out = {
-            "metric": METRIC, "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": units * world * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x12 (384-bit Montgomery Fq) / u32x8 (Fr)", "data": "synthetic",
-            "config": {"workload": "g1_msm: 2^%d SRS-shaped bases [tau^i]G per GPU, uniform Fr scalars resident in HBM"
-                                   % args.log_n, "points_per_gpu": n, "sharding": "point-range, all-gather of 144-B partials"},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "vs_baseline": None, "dtype": "u32 limbs (384-bit Montgomery Fq for G1, 256-bit Fr)", "data": "synthetic",
+            "config": {"workload": workload, "per_gpu_units": n,
+                       "multi_gpu": "replicas (one proof per rank)" if args.workload == "prove" else
+                       "point-range shards, all-gather of 144-B partials"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": alg_bytes},
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof.items())},
+                         "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "work_per_step": {k: v / args.steps for k, v in work.items()},
+            "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_msm(orc, args.cpu_log_n, tau, G)
+            if args.workload == "msm":
+                out["cpu_baseline"] = cpu_baseline_msm(args.cpu_log_n or 18)
+            else:
+                out["cpu_baseline"] = cpu_baseline_prove(args.cpu_log_n or 14)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

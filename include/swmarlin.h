@@ -178,7 +178,8 @@ int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
  * kernel launch is bracketed by hipEventRecord on the stream it is launched on.  swm_profile_json writes
- * {"kernels":[{"name":..,"calls":..,"total_ms":..,"avg_ms":..}, ...]} into buf (NUL-terminated). */
+ * {"kernels":[{"name":..,"calls":..,"total_ms":..,"avg_ms":..}, ...],
+ *  "work":{"msm_calls":..,"msm_points":..,"ntt_calls":..,"ntt_elements":..,"spmv_calls":..,"spmv_rows":..}} into buf. */
 int swm_profile_enable(swm_ctx *ctx, int on);
 int swm_profile_reset(swm_ctx *ctx);
 int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);

@@ -274,7 +274,9 @@ class Context:
     def profile(self):
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.lib.swm_profile_json(self.h, buf, len(buf)), "swm_profile_json")
-        return {k["name"]: k for k in json.loads(buf.value.decode())["kernels"]}
+        doc = json.loads(buf.value.decode())
+        self.last_work = doc.get("work", {})
+        return {k["name"]: k for k in doc["kernels"]}
 
     # ---- self tests
     def selftest_mul(self, which, a, b):

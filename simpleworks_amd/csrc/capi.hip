@@ -375,6 +375,8 @@ int swm_profile_reset(swm_ctx* ctx) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
     prof_flush(ctx);
     ctx->prof.clear();
+    ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
+    ctx->stat_spmv_calls = ctx->stat_spmv_rows = 0;
     return SWM_OK;
 }
 int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
@@ -390,7 +392,14 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
         s += line;
         first = false;
     }
-    s += "]}";
+    char tail[320];
+    snprintf(tail, sizeof(tail),
+             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"ntt_calls\":%llu,\"ntt_elements\":%llu,"
+             "\"spmv_calls\":%llu,\"spmv_rows\":%llu}}",
+             (unsigned long long)ctx->stat_msm_calls, (unsigned long long)ctx->stat_msm_points,
+             (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
+             (unsigned long long)ctx->stat_spmv_calls, (unsigned long long)ctx->stat_spmv_rows);
+    s += tail;
     if (s.size() + 1 > buflen) return set_err(ctx, SWM_ERR_INVALID_ARG, "profile_json: buffer too small");
     memcpy(buf, s.c_str(), s.size() + 1);
     return SWM_OK;

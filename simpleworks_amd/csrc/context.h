@@ -45,6 +45,9 @@ struct swm_ctx {
     std::map<uint64_t, swm::NttTables> ntt_tables;
     std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
+    // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
+    uint64_t stat_msm_calls = 0, stat_msm_points = 0, stat_ntt_calls = 0, stat_ntt_elems = 0, stat_spmv_calls = 0,
+             stat_spmv_rows = 0;
     bool profiling = false;
     std::map<std::string, swm::ProfAgg> prof;
     std::vector<swm::ProfPending> pending;

@@ -87,7 +87,7 @@ inline DVec dv_copy_padded(swm_ctx* ctx, const Fr* src, size_t len, size_t n) {
 
 // ------------------------------------------------------------------------------------------------ pointwise launcher
 template <class F>
-__global__ void __launch_bounds__(256) ew_kernel(size_t n, F f) {
+static __global__ void __launch_bounds__(256) ew_kernel(size_t n, F f) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) f(i);
 }
 template <class F>
@@ -128,7 +128,7 @@ inline void dv_ntt(swm_ctx* ctx, DVec& v, unsigned log_n, bool inverse, bool cos
 // z = 1, stride m:  quotient of p / (X^m - 1) = a[m..]  (DensePolynomial::divide_by_vanishing_poly).
 static constexpr int REC_T = 64;  // rows per lane
 
-__global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z, Fr* head, size_t nblk) {
+static __global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z, Fr* head, size_t nblk) {
     // lane = (block of REC_T rows, column); rows = ceil(n / m)
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nblk * m) return;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z
     }
     head[blk * m + col] = acc;
 }
-__global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m, Fr z, const Fr* head, size_t nblk) {
+static __global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m, Fr z, const Fr* head, size_t nblk) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nblk * m) return;
     size_t blk = t / m, col = t % m;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m, Fr z, 
         pw = fp_mul(pw, z);
     }
 }
-__global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
+static __global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
     size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (col >= m) return;
     size_t rows = (n + m - 1) / m;
@@ -213,7 +213,7 @@ inline DivResult div_linear(swm_ctx* ctx, const Fr* p, size_t n, const Fr& x) {
 
 // ------------------------------------------------------------------------------------------------ Horner evaluation
 static constexpr int EVAL_CHUNK = 64;
-__global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x, Fr* __restrict__ out,
+static __global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x, Fr* __restrict__ out,
                                                    size_t nchunks) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
@@ -262,7 +262,7 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* sm) {
     }
     return sm[tid];
 }
-__global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* in, size_t n, uint32_t* tot) {
+static __global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* in, size_t n, uint32_t* tot) {
     __shared__ uint32_t sm[SC_BLOCK];
     size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t a = 0;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* in, size
     uint32_t inc = block_scan_incl(a, sm);
     if (threadIdx.x == SC_BLOCK - 1) tot[blockIdx.x] = inc;
 }
-__global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint32_t ntiles) {
+static __global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint32_t ntiles) {
     __shared__ uint32_t sm[SC_BLOCK];
     uint32_t per = (ntiles + SC_BLOCK - 1) / SC_BLOCK;
     uint32_t lo = threadIdx.x * per, hi = min(lo + per, ntiles);
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint32_t nti
     }
     if (threadIdx.x == SC_BLOCK - 1) tot[ntiles] = inc;
 }
-__global__ void __launch_bounds__(SC_BLOCK) scan_final(const uint32_t* in, size_t n, const uint32_t* tot, uint32_t* out) {
+static __global__ void __launch_bounds__(SC_BLOCK) scan_final(const uint32_t* in, size_t n, const uint32_t* tot, uint32_t* out) {
     __shared__ uint32_t sm[SC_BLOCK];
     size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t a = 0;
@@ -315,7 +315,7 @@ inline uint32_t scan_exclusive_u32(swm_ctx* ctx, const uint32_t* in, uint32_t* o
 struct ChaChaKey {
     uint32_t k[8];
 };
-__global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, int rounds, uint64_t pos, size_t m,
+static __global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, int rounds, uint64_t pos, size_t m,
                                                          Fr* __restrict__ cand, uint32_t* __restrict__ flag) {
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, int roun
     cand[j] = r;
     flag[j] = lt ? 1u : 0u;
 }
-__global__ void __launch_bounds__(256) sample_compact(const Fr* __restrict__ cand, const uint32_t* __restrict__ flag,
+static __global__ void __launch_bounds__(256) sample_compact(const Fr* __restrict__ cand, const uint32_t* __restrict__ flag,
                                                       const uint32_t* __restrict__ rank, size_t m, size_t need,
                                                       Fr* __restrict__ out, uint32_t* __restrict__ last_idx) {
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

@@ -205,8 +205,10 @@ HostCsr import_csr(const uint32_t* rowptr, const uint32_t* col, const uint64_t* 
     return m;
 }
 
-// ark-marlin constraint_systems.rs: pad_input_for_indexer_and_prover + make_matrices_square
-PaddedR1cs pad_and_square(const swm_r1cs* cs) {
+// ark-marlin constraint_systems.rs: pad_input_for_indexer_and_prover + make_matrices_square.
+// with_matrices = false (prover): only the assignment and the padded shape are needed — z_A, z_B come from the
+// index's matrices, as in ark-marlin's prover_init.
+PaddedR1cs pad_and_square(const swm_r1cs* cs, bool with_matrices = true) {
     if (!cs || cs->num_instance == 0 || !cs->instance) throw MarlinError(SWM_ERR_INVALID_ARG, "r1cs: bad arguments");
     PaddedR1cs p;
     for (size_t i = 0; i < cs->num_instance; i++) p.inst.push_back(fp_from_limbs<Fr>((const uint32_t*)(cs->instance + 4 * i)));
@@ -218,11 +220,14 @@ PaddedR1cs pad_and_square(const swm_r1cs* cs) {
     size_t nvars = p.inst.size() + p.wit.size();
     size_t ncons = cs->num_constraints;
     size_t total_cols = nvars;
-    p.a = import_csr(cs->a_rowptr, cs->a_col, cs->a_val, ncons, cs->num_instance, shift, total_cols);
-    p.b = import_csr(cs->b_rowptr, cs->b_col, cs->b_val, ncons, cs->num_instance, shift, total_cols);
-    p.c = import_csr(cs->c_rowptr, cs->c_col, cs->c_val, ncons, cs->num_instance, shift, total_cols);
+    if (with_matrices) {
+        p.a = import_csr(cs->a_rowptr, cs->a_col, cs->a_val, ncons, cs->num_instance, shift, total_cols);
+        p.b = import_csr(cs->b_rowptr, cs->b_col, cs->b_val, ncons, cs->num_instance, shift, total_cols);
+        p.c = import_csr(cs->c_rowptr, cs->c_col, cs->c_val, ncons, cs->num_instance, shift, total_cols);
+    }
     if (nvars > ncons) {
-        for (HostCsr* m : {&p.a, &p.b, &p.c}) m->rowptr.resize(nvars + 1, m->rowptr.back());
+        if (with_matrices)
+            for (HostCsr* m : {&p.a, &p.b, &p.c}) m->rowptr.resize(nvars + 1, m->rowptr.back());
         ncons = nvars;
     } else {
         p.wit.resize(p.wit.size() + (ncons - nvars), fp_one<Fr>());  // dummy unconstrained variables (value one)
@@ -647,7 +652,7 @@ struct LPoly {
 };
 
 std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk) {
-    PaddedR1cs pr = pad_and_square(cs);
+    PaddedR1cs pr = pad_and_square(cs, false);
     if (pr.ncons != pk.info.num_constraints || pr.inst.size() + pr.wit.size() != pk.info.num_variables ||
         pr.inst.size() != pk.info.num_instance_variables)
         throw MarlinError(SWM_ERR_MISMATCH, "InstanceDoesNotMatchIndex");

@@ -426,6 +426,8 @@ int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t
     *result = g1_xyzz_identity();
     if (n == 0) return SWM_OK;
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
+    ctx->stat_msm_calls++;
+    ctx->stat_msm_points += n;
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");

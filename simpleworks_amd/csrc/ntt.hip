@@ -188,6 +188,8 @@ static int get_small_table(swm_ctx* ctx, unsigned log_r, int inverse, const Fr**
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
     if (log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: log_n > 30 unsupported");
     const uint64_t n = 1ull << log_n;
+    ctx->stat_ntt_calls++;
+    ctx->stat_ntt_elems += n;
     Fr* data = reinterpret_cast<Fr*>(d_data);
     NttTables *rt = nullptr, *ct = nullptr;
     SWM_TRY(get_root_tables(ctx, log_n, inverse, &rt));

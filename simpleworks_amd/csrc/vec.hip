@@ -1,32 +1,13 @@
-// vec.hip — K3 (R1CS sparse mat-vec) and K4 (batch inversion, pointwise products) over BLS12-377 Fr, plus the
-// device self-tests of the field / curve primitives.
+// vec.hip — K4 (batch inversion, pointwise products) over BLS12-377 Fr, plus the device self-tests of the
+// field / curve primitives.
 //
-// K3 replaces the row-wise inner products of ark-marlin's AHPForR1CS::prover_init (z_A = A z, z_B = B z; SURVEY.md
-// A.4) and ConstraintSystem::is_satisfied (/root/reference/src/merkle_tree/simple_merkle_tree.rs:197-199).
-// K4 replaces ark_ff::batch_inversion and the cfg_iter pointwise loops of ark-marlin's prover rounds.
+// (K3, the R1CS mat-vec, lives in spmv.hip.)  K4 replaces ark_ff::batch_inversion and the cfg_iter pointwise loops of ark-marlin's prover rounds.
 // All of it is HBM-bound integer work: one lane per row / element, 16-B vector loads, no LDS, no MFMA.
-// Algorithmic bytes: SpMV 68 B per non-zero + 36 B per row; vec_mul 96 B per element.
+// Algorithmic bytes: vec_mul 96 B per element; batch inverse 64 B per element.
 #include "context.h"
 #include "g1.cuh"
 
 namespace swm {
-
-// CSR row-per-lane.  R1CS rows hold 0-3 non-zeros (gadget rows of shape 0*0 = a-b, booleanity rows, ...), so a
-// row-per-wave scheme would idle 60 lanes; lanes of a wave read consecutive rowptr/col/val ranges instead.
-__global__ void __launch_bounds__(256) spmv_rows(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
-                                                 const Fr* __restrict__ val, const Fr* __restrict__ z,
-                                                 Fr* __restrict__ out, size_t rows) {
-    size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    uint32_t k = rowptr[r], e = rowptr[r + 1];
-    Fr acc = fp_zero<Fr>();
-    for (; k < e; k++) {
-        Fr c = val[k];
-        Fr zv = z[col[k]];
-        acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));  // coeff.is_one() shortcut as in prover_init
-    }
-    out[r] = acc;
-}
 
 __global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b,
                                                       Fr* __restrict__ out, size_t n) {
@@ -64,13 +45,6 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(Fr* __restrict__ v, 
     }
 }
 
-int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
-             size_t rows) {
-    if (rows == 0) return SWM_OK;
-    SWM_LAUNCH(ctx, "spmv_rows", spmv_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-               (const uint32_t*)d_rowptr, (const uint32_t*)d_col, (const Fr*)d_val, (const Fr*)d_z, (Fr*)d_out, rows);
-    return SWM_OK;
-}
 int vec_mul_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
     if (n == 0) return SWM_OK;
     unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
