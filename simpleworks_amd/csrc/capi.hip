@@ -167,6 +167,15 @@ void swm_destroy(swm_ctx* ctx) {
     for (auto& kv : ctx->ntt_small) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++)
+        if (ctx->aux_stream[i]) {
+            (void)hipStreamSynchronize(ctx->aux_stream[i]);
+            (void)hipStreamDestroy(ctx->aux_stream[i]);
+        }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    for (auto e : ctx->slot_event)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -44,6 +44,13 @@ struct swm_ctx {
     // NTT root tables keyed by (log_n << 1 | inverse); coset tables keyed by inverse flag
     std::map<uint64_t, swm::NttTables> ntt_tables;
     std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
+    // asynchronous MSM lanes: two auxiliary streams, a fork event, pinned result slots with their completion events
+    static constexpr int MSM_SLOTS = 8;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    void* pinned = nullptr;
+    hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
+    int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
     uint64_t stat_msm_calls = 0, stat_msm_points = 0, stat_ntt_calls = 0, stat_ntt_elems = 0, stat_spmv_calls = 0,

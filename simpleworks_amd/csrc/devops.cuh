@@ -222,30 +222,41 @@ static __global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__
     for (size_t k = hi; k-- > lo;) acc = fp_add(fp_mul(acc, x), c[k]);
     out[t] = acc;
 }
-// returns p(x) on the host (synchronises)
-inline Fr poly_eval(swm_ctx* ctx, const Fr* p, size_t n, Fr x) {
-    if (n == 0) return fp_zero<Fr>();
+// p(x) for a device polynomial, written to the device word *d_result (no host synchronisation)
+inline void poly_eval_async(swm_ctx* ctx, const Fr* p, size_t n, Fr x, Fr* d_result) {
+    if (n == 0) {
+        hip_check(ctx, hipMemsetAsync(d_result, 0, sizeof(Fr), ctx->stream), "memset");
+        return;
+    }
     DVec cur;
     const Fr* src = p;
     size_t len = n;
-    while (len > 1) {
+    for (;;) {
         size_t nchunks = (len + EVAL_CHUNK - 1) / EVAL_CHUNK;
-        DVec next(ctx, nchunks);
+        DVec next;
+        Fr* dst = d_result;
+        if (nchunks > 1) {
+            next = DVec(ctx, nchunks);
+            dst = next.p;
+        }
         prof_begin(ctx, "poly_eval");
-        hipLaunchKernelGGL(eval_chunks, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream, src, len, x,
-                           next.p, nchunks);
+        hipLaunchKernelGGL(eval_chunks, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream, src, len, x, dst,
+                           nchunks);
         prof_end(ctx);
         hip_check(ctx, hipGetLastError(), "poly_eval");
+        if (nchunks == 1) break;
         for (int i = 0; i < 6; i++) x = fp_sqr(x);  // x^64
         static_assert(EVAL_CHUNK == 64, "x exponent");
         cur = std::move(next);
         src = cur.p;
         len = nchunks;
     }
-    Fr out;
-    hip_check(ctx, hipMemcpyAsync(&out, src, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream), "d2h");
-    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
-    return out;
+}
+// returns p(x) on the host (synchronises)
+inline Fr poly_eval(swm_ctx* ctx, const Fr* p, size_t n, Fr x) {
+    DVec r(ctx, 1);
+    poly_eval_async(ctx, p, n, x, r.p);
+    return r.download(0, 1)[0];
 }
 
 // ------------------------------------------------------------------------------------------------ u32 exclusive scan

@@ -10,14 +10,13 @@
 //   * only the three gamma-powers KZG hiding needs are generated at setup (arkworks generates max_degree + 2).
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include "devops.cuh"
 #include "g1.cuh"
 #include "host/ahp.h"
 
-namespace swm {
-int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result);
-}
+#include "msm.h"
 using namespace swm;
 
 // launch + profile bracket, throwing MarlinError instead of returning a status
@@ -315,12 +314,26 @@ uint64_t ahp_max_degree(uint64_t num_constraints, uint64_t num_variables, uint64
 }
 
 // ================================================================================================ commitments
-// MSM of a device coefficient vector against SRS powers starting at `offset` -> host XYZZ
+// MSM of a device coefficient vector against SRS powers starting at `offset` -> host XYZZ (synchronous form)
 G1XYZZ commit_dev(swm_ctx* ctx, const G1Affine* d_powers, size_t n_powers, size_t offset, const Fr* coeffs, size_t n) {
     if (n == 0) return g1_xyzz_identity();
     if (offset + n > n_powers) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
     G1XYZZ r;
     rc_check(ctx, msm_run(ctx, d_powers + offset, coeffs, n, 1, &r));
+    return r;
+}
+// asynchronous form: alternates between the two MSM lanes of the context
+struct AsyncMsm {
+    MsmJob job;
+};
+void commit_enqueue(swm_ctx* ctx, int* lane, const G1Affine* d_powers, size_t n_powers, size_t offset, const Fr* coeffs,
+                    size_t n, AsyncMsm* out) {
+    if (n && offset + n > n_powers) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ & 1, d_powers + offset, coeffs, n, 1, &out->job));
+}
+G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
+    G1XYZZ r;
+    rc_check(ctx, msm_finish(ctx, &a->job, &r));
     return r;
 }
 
@@ -329,22 +342,36 @@ struct PolyRand {
     bool has_shifted = false;
 };
 
-// MarlinKZG10::commit for one labelled polynomial resident in HBM.  Draw order: plain blinding, then shifted blinding.
-Commitment pc_commit(swm_ctx* ctx, const swm_pk& pk, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
-                     bool hiding, ChaChaRng* rng, PolyRand* pr) {
+// MarlinKZG10::commit for one labelled polynomial resident in HBM, split in two halves so that the MSMs of a round
+// run back to back on the GPU while the host is still enqueueing:
+//   pc_commit_begin  enqueues the plain (and, with a degree bound, the shifted) MSM;
+//   pc_commit_end    waits, draws the blinding polynomials (plain first, then shifted — the arkworks draw order, so
+//                    pc_commit_end must be called in label order) and adds the hiding terms.
+struct CommitJob {
+    AsyncMsm plain, shifted;
+    bool has_bound = false, hiding = false;
+};
+void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
+                     bool hiding, CommitJob* job) {
+    job->has_bound = has_bound;
+    job->hiding = hiding;
+    commit_enqueue(ctx, lane, pk.d_powers, pk.srs_max_degree + 1, 0, coeffs, n, &job->plain);
+    if (has_bound) commit_enqueue(ctx, lane, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
+}
+Commitment pc_commit_end(swm_ctx* ctx, const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
     Commitment c;
-    G1XYZZ plain = commit_dev(ctx, pk.d_powers, pk.srs_max_degree + 1, 0, coeffs, n);
+    G1XYZZ plain = commit_wait(ctx, &job->plain);
     pr->rand.clear();
     pr->shifted_rand.clear();
-    pr->has_shifted = has_bound;
-    if (hiding) {
+    pr->has_shifted = job->has_bound;
+    if (job->hiding) {
         for (int i = 0; i < 3; i++) pr->rand.push_back(rng->rand_fr());  // DensePolynomial::rand(hiding_bound + 1)
         g1_add(plain, gamma_msm(pk, pr->rand));
     }
     c.comm = g1_to_affine(plain);
-    if (has_bound) {
-        G1XYZZ sh = commit_dev(ctx, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - bound, coeffs, n);
-        if (hiding) {
+    if (job->has_bound) {
+        G1XYZZ sh = commit_wait(ctx, &job->shifted);
+        if (job->hiding) {
             for (int i = 0; i < 3; i++) pr->shifted_rand.push_back(rng->rand_fr());
             g1_add(sh, gamma_msm(pk, pr->shifted_rand));
         }
@@ -626,11 +653,14 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     vk.vk.max_degree = srs->max_degree;
     vk.vk.supported_degree = max_deg;
     // commit the 12 index polynomials (no hiding, no degree bounds)
+    int lane = 0;
     for (int i = 0; i < 3; i++) {
         const DVec* polys[4] = {&pk->ar[i].row, &pk->ar[i].col, &pk->ar[i].val, &pk->ar[i].row_col};
-        for (auto pl : polys) {
+        AsyncMsm jobs[4];
+        for (int j = 0; j < 4; j++) commit_enqueue(ctx, &lane, pk->d_powers, pk->srs_max_degree + 1, 0, polys[j]->p, pk->K, &jobs[j]);
+        for (int j = 0; j < 4; j++) {
             Commitment c;
-            c.comm = g1_to_affine(commit_dev(ctx, pk->d_powers, pk->srs_max_degree + 1, 0, pl->p, pk->K));
+            c.comm = g1_to_affine(commit_wait(ctx, &jobs[j]));
             vk.index_comms.push_back(c);
         }
     }
@@ -651,9 +681,42 @@ struct LPoly {
     PolyRand rand;
 };
 
+// SWM_TRACE=1: wall-clock per prover phase on stderr (synchronises at phase ends; diagnostic only)
+struct PhaseTrace {
+    swm_ctx* ctx;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTrace(swm_ctx* c) : ctx(c), on(getenv("SWM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[swm trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk) {
-    PaddedR1cs pr = pad_and_square(cs, false);
-    if (pr.ncons != pk.info.num_constraints || pr.inst.size() + pr.wit.size() != pk.info.num_variables ||
+    PhaseTrace tr(ctx);
+    // padded shape (pad_input_for_indexer_and_prover + make_matrices_square); the witness itself is uploaded straight
+    // from the caller's buffer, padding is filled on the device
+    if (!cs || cs->num_instance == 0 || !cs->instance || (cs->num_witness && !cs->witness))
+        throw MarlinError(SWM_ERR_INVALID_ARG, "r1cs: bad arguments");
+    struct {
+        std::vector<Fr> inst;
+        size_t nwit_orig, nwit, ncons;
+    } pr;
+    for (size_t i = 0; i < cs->num_instance; i++) pr.inst.push_back(fp_from_limbs<Fr>((const uint32_t*)(cs->instance + 4 * i)));
+    if (!fp_is_one(pr.inst[0])) throw MarlinError(SWM_ERR_INVALID_ARG, "r1cs: instance[0] must be one");
+    pr.inst.resize(HDomain(pr.inst.size()).size, fp_zero<Fr>());
+    pr.nwit_orig = cs->num_witness;
+    {
+        size_t nv = pr.inst.size() + cs->num_witness, nc = cs->num_constraints;
+        pr.nwit = nv > nc ? cs->num_witness : cs->num_witness + (nc - nv);
+        pr.ncons = nv > nc ? nv : nc;
+    }
+    tr.mark("pad_and_square");
+    if (pr.ncons != pk.info.num_constraints || pr.inst.size() + pr.nwit != pk.info.num_variables ||
         pr.inst.size() != pk.info.num_instance_variables)
         throw MarlinError(SWM_ERR_MISMATCH, "InstanceDoesNotMatchIndex");
     const uint64_t H = pk.H, K = pk.K, X = pk.X, Bsz = pk.B;
@@ -666,14 +729,19 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     fs_init(fs, pk.vk, public_input);
 
     // ---- z on the device, z_A = A z, z_B = B z  (K3)
-    std::vector<Fr> zh(pr.inst);
-    zh.insert(zh.end(), pr.wit.begin(), pr.wit.end());
     DVec z(ctx, nvars);
-    z.upload(zh.data(), nvars);
+    hip_check(ctx, hipMemcpyAsync(z.p, pr.inst.data(), ninst * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
+    if (pr.nwit_orig)
+        hip_check(ctx, hipMemcpyAsync(z.p + ninst, cs->witness, pr.nwit_orig * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
+    if (pr.nwit > pr.nwit_orig) {  // dummy unconstrained variables have the value one
+        Fr* zp = z.p + ninst + pr.nwit_orig;
+        ew(ctx, "z_pad", pr.nwit - pr.nwit_orig, [=] __device__(size_t i) { zp[i] = fp_one<Fr>(); });
+    }
     DVec za_evals = dv_zeros(ctx, H), zb_evals = dv_zeros(ctx, H);
     rc_check(ctx, spmv_run(ctx, pk.a.rowptr.p, pk.a.col.p, pk.a.val.p, z.p, za_evals.p, pk.a.rows));
     rc_check(ctx, spmv_run(ctx, pk.b.rowptr.p, pk.b.col.p, pk.b.val.p, z.p, zb_evals.p, pk.b.rows));
 
+    tr.mark("upload z, z_A, z_B");
     // ================= round 1
     // x_poly = interpolate(formatted input over X); x_evals = FFT_H(x_poly)
     DVec x_poly(ctx, X);
@@ -683,7 +751,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     dv_ntt(ctx, x_evals, pk.logH, false);
     // w evaluations on H: 0 on the X-subgroup positions, w_extended[k - k/ratio - 1] - x_evals[k] elsewhere
     const uint64_t ratio = H / X;
-    const size_t nwit = pr.wit.size();
+    const size_t nwit = pr.nwit;
     DVec w_poly = dv_zeros(ctx, H + 1);
     {
         Fr* out = w_poly.p;
@@ -741,16 +809,26 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
         });
     }
+    tr.mark("round 1 polynomials");
     LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
+    int lane = 0;
     std::vector<Commitment> comms1(4);
-    P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
-    comms1[0] = pc_commit(ctx, pk, P_w.p, P_w.n, false, 0, true, &zk, &P_w.rand);
-    P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
-    comms1[1] = pc_commit(ctx, pk, P_za.p, P_za.n, false, 0, true, &zk, &P_za.rand);
-    P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
-    comms1[2] = pc_commit(ctx, pk, P_zb.p, P_zb.n, false, 0, true, &zk, &P_zb.rand);
-    P_mask.p = mask.p; P_mask.n = mask_len;
-    comms1[3] = pc_commit(ctx, pk, P_mask.p, P_mask.n, false, 0, false, nullptr, &P_mask.rand);
+    {
+        CommitJob j[4];
+        P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
+        pc_commit_begin(ctx, pk, &lane, P_w.p, P_w.n, false, 0, true, &j[0]);
+        P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
+        pc_commit_begin(ctx, pk, &lane, P_za.p, P_za.n, false, 0, true, &j[1]);
+        P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
+        pc_commit_begin(ctx, pk, &lane, P_zb.p, P_zb.n, false, 0, true, &j[2]);
+        P_mask.p = mask.p; P_mask.n = mask_len;
+        pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j[3]);
+        comms1[0] = pc_commit_end(ctx, pk, &j[0], &zk, &P_w.rand);
+        comms1[1] = pc_commit_end(ctx, pk, &j[1], &zk, &P_za.rand);
+        comms1[2] = pc_commit_end(ctx, pk, &j[2], &zk, &P_zb.rand);
+        comms1[3] = pc_commit_end(ctx, pk, &j[3], nullptr, &P_mask.rand);
+    }
+    tr.mark("round 1 commitments");
     fs_absorb_commitments(fs, comms1);
     VerifierState st;
     st.alpha = fs.sample_outside(dh);
@@ -839,17 +917,25 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             if (j < H) pg[j] = fp_add(q[j], acc);
         });
     }
-    {
-        Fr rem0 = g1x.download(0, 1)[0];
-        if (!fp_is_zero(rem0)) throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
-    }
+    tr.mark("round 2 polynomials");
     std::vector<Commitment> comms2(3);
-    P_t.p = t_poly.p; P_t.n = H;
-    comms2[0] = pc_commit(ctx, pk, P_t.p, P_t.n, false, 0, false, nullptr, &P_t.rand);
-    P_g1.p = g1x.p + 1; P_g1.n = H - 1; P_g1.has_bound = true; P_g1.bound = H - 2; P_g1.hiding = true;
-    comms2[1] = pc_commit(ctx, pk, P_g1.p, P_g1.n, true, H - 2, true, &zk, &P_g1.rand);
-    P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
-    comms2[2] = pc_commit(ctx, pk, P_h1.p, P_h1.n, false, 0, false, nullptr, &P_h1.rand);
+    {
+        CommitJob j[3];
+        P_t.p = t_poly.p; P_t.n = H;
+        pc_commit_begin(ctx, pk, &lane, P_t.p, P_t.n, false, 0, false, &j[0]);
+        P_g1.p = g1x.p + 1; P_g1.n = H - 1; P_g1.has_bound = true; P_g1.bound = H - 2; P_g1.hiding = true;
+        pc_commit_begin(ctx, pk, &lane, P_g1.p, P_g1.n, true, H - 2, true, &j[1]);
+        P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
+        pc_commit_begin(ctx, pk, &lane, P_h1.p, P_h1.n, false, 0, false, &j[2]);
+        // the sumcheck remainder check needs a download; do it while the MSMs run
+        Fr rem0 = g1x.download(0, 1)[0];
+        bool unsat = !fp_is_zero(rem0);
+        comms2[0] = pc_commit_end(ctx, pk, &j[0], nullptr, &P_t.rand);
+        comms2[1] = pc_commit_end(ctx, pk, &j[1], &zk, &P_g1.rand);
+        comms2[2] = pc_commit_end(ctx, pk, &j[2], nullptr, &P_h1.rand);
+        if (unsat) throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
+    }
+    tr.mark("round 2 commitments");
     fs_absorb_commitments(fs, comms2);
     st.beta = fs.sample_outside(dh);
     const Fr beta = st.beta;
@@ -909,11 +995,18 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             ph[j] = acc;
         });
     }
+    tr.mark("round 3 polynomials");
     std::vector<Commitment> comms3(2);
-    P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
-    comms3[0] = pc_commit(ctx, pk, P_g2.p, P_g2.n, true, K - 2, false, nullptr, &P_g2.rand);
-    P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
-    comms3[1] = pc_commit(ctx, pk, P_h2.p, P_h2.n, false, 0, false, nullptr, &P_h2.rand);
+    {
+        CommitJob j[2];
+        P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
+        pc_commit_begin(ctx, pk, &lane, P_g2.p, P_g2.n, true, K - 2, false, &j[0]);
+        P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
+        pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j[1]);
+        comms3[0] = pc_commit_end(ctx, pk, &j[0], nullptr, &P_g2.rand);
+        comms3[1] = pc_commit_end(ctx, pk, &j[1], nullptr, &P_h2.rand);
+    }
+    tr.mark("round 3 commitments");
     fs_absorb_commitments(fs, comms3);
     st.gamma = fs.rand_fr();
     const Fr gamma = st.gamma;
@@ -931,7 +1024,22 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     polys["w"] = &P_w; polys["z_a"] = &P_za; polys["z_b"] = &P_zb; polys["mask_poly"] = &P_mask;
     polys["t"] = &P_t; polys["g_1"] = &P_g1; polys["h_1"] = &P_h1; polys["g_2"] = &P_g2; polys["h_2"] = &P_h2;
+    // every evaluation the linear combinations can ask for, enqueued back to back and downloaded once
     std::map<std::pair<std::string, bool>, Fr> eval_cache;  // (label, at_gamma)
+    {
+        std::vector<std::pair<std::string, bool>> want;
+        for (const char* l : {"z_b", "t", "g_1", "mask_poly", "z_a", "w", "h_1"}) want.push_back({l, false});
+        for (int i = 0; i < 12; i++) want.push_back({kIndexerPolys[i], true});
+        want.push_back({"g_2", true});
+        want.push_back({"h_2", true});
+        DVec slots(ctx, want.size());
+        for (size_t i = 0; i < want.size(); i++) {
+            LPoly* lp = polys.at(want[i].first);
+            poly_eval_async(ctx, lp->p, lp->n, want[i].second ? gamma : beta, slots.p + i);
+        }
+        std::vector<Fr> vals = slots.download(0, want.size());
+        for (size_t i = 0; i < want.size(); i++) eval_cache[want[i]] = vals[i];
+    }
     auto poly_at = [&](const std::string& label, const Fr& point) {
         bool at_gamma = fp_eq(point, gamma);
         auto key = std::make_pair(label, at_gamma);
@@ -959,32 +1067,46 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         evals.push_back({q.label, v});
     }
     std::sort(evals.begin(), evals.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    tr.mark("evaluations");
     Proof proof;
     for (auto& e : evals) proof.evaluations.push_back(e.second);
     fs_absorb_evals(fs, proof.evaluations);
     Fr xi = fs.challenge_u128();
 
     // ================= MarlinKZG10::open_combinations: per query point, labels in sorted order, challenges xi^0, xi^1, ...
+    // Phase 1 builds the combined polynomial, its witness and the shifted witnesses for BOTH points and enqueues all
+    // their MSMs; phase 2 waits and adds the host-side hiding terms.  Nothing is awaited before everything is enqueued.
+    struct ShiftedTerm {
+        LPoly* lp;
+        Fr ch;
+    };
+    struct PointOpen {
+        Fr point;
+        DVec comb;
+        DivResult wq;
+        std::vector<DivResult> sq;
+        AsyncMsm wjob;
+        std::vector<AsyncMsm> sjobs;
+        HPoly r_comb, shifted_r, shifted_r_witness;
+        std::vector<ShiftedTerm> shifted_terms;
+    };
     const char* points[2] = {"beta", "gamma"};
-    for (auto pl : points) {
-        const Fr& point = std::string(pl) == "beta" ? beta : gamma;
+    PointOpen po[2];
+    for (int pi = 0; pi < 2; pi++) {
+        const char* pl = points[pi];
+        PointOpen& o = po[pi];
+        o.point = pi == 0 ? beta : gamma;
+        const Fr point = o.point;
         std::vector<std::string> labels;
         for (auto& q : kQuerySet)
             if (std::string(q.point) == pl) labels.push_back(q.label);
         std::sort(labels.begin(), labels.end());
-        // combined polynomial p = sum_j xi^ctr * LC_j (device), combined blinding r (host)
         size_t plen = 0;
         for (auto& l : labels)
             for (auto& t : lcs.at(l))
                 if (!t.second.empty()) plen = std::max(plen, polys.at(t.second)->n);
-        DVec comb = dv_zeros(ctx, plen);
-        HPoly r_comb, shifted_r, shifted_r_witness;
+        o.comb = dv_zeros(ctx, plen);
         Fr ch = fr_one();
-        struct ShiftedTerm {
-            LPoly* lp;
-            Fr ch;
-        };
-        std::vector<ShiftedTerm> shifted_terms;
         for (auto& l : labels) {
             const LcTerms& terms = lcs.at(l);
             bool single_bounded = false;
@@ -994,47 +1116,53 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
                 if (terms.size() == 1 && lp->has_bound) single_bounded = true;
                 else if (lp->has_bound) throw MarlinError(SWM_ERR_INTERNAL, "EquationHasDegreeBounds");
                 Fr k = fp_mul(ch, t.first);
-                Fr* out = comb.p;
+                Fr* out = o.comb.p;
                 const Fr* src = lp->p;
                 ew(ctx, "open_combine", lp->n, [=] __device__(size_t i) { out[i] = fp_add(out[i], fp_mul(k, src[i])); });
-                hp_add_scaled(r_comb, lp->rand.rand, k);
+                hp_add_scaled(o.r_comb, lp->rand.rand, k);
             }
             ch = fp_mul(ch, xi);
             if (single_bounded) {
                 LPoly* lp = polys.at(terms[0].second);
-                shifted_terms.push_back({lp, ch});
-                hp_add_scaled(shifted_r, lp->rand.shifted_rand, ch);
-                if (!hp_is_zero(lp->rand.shifted_rand)) hp_add_scaled(shifted_r_witness, hp_div_linear(lp->rand.shifted_rand, point), ch);
+                o.shifted_terms.push_back({lp, ch});
+                hp_add_scaled(o.shifted_r, lp->rand.shifted_rand, ch);
+                if (!hp_is_zero(lp->rand.shifted_rand)) hp_add_scaled(o.shifted_r_witness, hp_div_linear(lp->rand.shifted_rand, point), ch);
                 ch = fp_mul(ch, xi);
             }
         }
-        // witness = p / (X - point) -> commitment against the powers
-        DivResult wq = div_linear(ctx, comb.p, plen, point);
-        G1XYZZ w = commit_dev(ctx, pk.d_powers, pk.srs_max_degree + 1, 0, wq.work.p + 1, plen ? plen - 1 : 0);
-        PcProof pp;
-        if (!hp_is_zero(r_comb)) {
-            g1_add(w, gamma_msm(pk, hp_div_linear(r_comb, point)));
-            pp.has_random_v = true;
-            pp.random_v = host_poly_eval(r_comb, point);
-        }
-        // degree-bounded members: shifted witnesses, committed against the shifted powers
-        for (auto& stt : shifted_terms) {
-            DivResult sq = div_linear(ctx, stt.lp->p, stt.lp->n, point);
-            // scale by the challenge on the device, then MSM at offset max_degree - bound
+        // witness = p / (X - point) against the powers; degree-bounded members: shifted witnesses against the shifted powers
+        o.wq = div_linear(ctx, o.comb.p, plen, point);
+        commit_enqueue(ctx, &lane, pk.d_powers, pk.srs_max_degree + 1, 0, o.wq.work.p + 1, plen ? plen - 1 : 0, &o.wjob);
+        o.sq.resize(o.shifted_terms.size());
+        o.sjobs.resize(o.shifted_terms.size());
+        for (size_t i = 0; i < o.shifted_terms.size(); i++) {
+            auto& stt = o.shifted_terms[i];
+            o.sq[i] = div_linear(ctx, stt.lp->p, stt.lp->n, point);
             Fr k = stt.ch;
-            Fr* q = sq.work.p;
+            Fr* q = o.sq[i].work.p;
             size_t qn = stt.lp->n ? stt.lp->n - 1 : 0;
-            ew(ctx, "open_scale", qn, [=] __device__(size_t i) { q[i + 1] = fp_mul(q[i + 1], k); });
-            G1XYZZ sw = commit_dev(ctx, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - stt.lp->bound, q + 1, qn);
-            g1_add(w, sw);
+            ew(ctx, "open_scale", qn, [=] __device__(size_t t) { q[t + 1] = fp_mul(q[t + 1], k); });
+            commit_enqueue(ctx, &lane, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - stt.lp->bound, q + 1, qn, &o.sjobs[i]);
         }
-        if (!shifted_terms.empty()) {
-            if (!hp_is_zero(shifted_r_witness)) g1_add(w, gamma_msm(pk, shifted_r_witness));
-            if (!hp_is_zero(shifted_r) && pp.has_random_v) pp.random_v = fp_add(pp.random_v, host_poly_eval(shifted_r, point));
+    }
+    for (int pi = 0; pi < 2; pi++) {
+        PointOpen& o = po[pi];
+        G1XYZZ w = commit_wait(ctx, &o.wjob);
+        PcProof pp;
+        if (!hp_is_zero(o.r_comb)) {
+            g1_add(w, gamma_msm(pk, hp_div_linear(o.r_comb, o.point)));
+            pp.has_random_v = true;
+            pp.random_v = host_poly_eval(o.r_comb, o.point);
+        }
+        for (size_t i = 0; i < o.shifted_terms.size(); i++) g1_add(w, commit_wait(ctx, &o.sjobs[i]));
+        if (!o.shifted_terms.empty()) {
+            if (!hp_is_zero(o.shifted_r_witness)) g1_add(w, gamma_msm(pk, o.shifted_r_witness));
+            if (!hp_is_zero(o.shifted_r) && pp.has_random_v) pp.random_v = fp_add(pp.random_v, host_poly_eval(o.shifted_r, o.point));
         }
         pp.w = g1_to_affine(w);
         proof.pc_proof.push_back(pp);
     }
+    tr.mark("openings");
     proof.commitments = {comms1, comms2, comms3};
     return serialize_proof(proof);
 }

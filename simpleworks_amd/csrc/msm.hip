@@ -28,6 +28,7 @@
 #include <algorithm>
 #include "context.h"
 #include "g1.cuh"
+#include "msm.h"
 
 namespace swm {
 
@@ -38,19 +39,6 @@ static constexpr int RED_CHUNK = 8;     // buckets per lane in the window reduct
 static constexpr int RED_BLOCK = 256;
 static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
 static constexpr int SORT_THREADS = 1024;
-
-static constexpr int MAX_WIN = 64;
-// Window layout: the 254 recoding bits (253 scalar bits + 1 for the carry) are spread over nwin windows whose
-// widths differ by at most one, so that no window is degenerate (a short top window would put n/2 points in two
-// buckets).  boff[w] = first bucket of window w in the flat bucket array; window w has 2^(c[w]-1) buckets.
-struct WinLayout {
-    uint32_t nwin;
-    uint32_t NB;
-    uint32_t maxB;
-    uint8_t c[MAX_WIN];
-    uint16_t bit[MAX_WIN];
-    uint32_t boff[MAX_WIN + 1];
-};
 
 WinLayout msm_plan(size_t n) {
     // Target window size for the GPU schedule (NOT arkworks' ln-based rule): large enough that the n*W accumulate
@@ -288,19 +276,77 @@ __device__ __forceinline__ uint32_t bucket_of_segment(const uint32_t* __restrict
     return lo;
 }
 
+// Segment descriptors + ordering by length.  Lanes of a wave run in lock step, so a wave costs as much as its
+// longest segment; bucket sizes are Poisson-spread (a wave of 64 unsorted segments idles ~25 % of its lane-cycles).
+// Segments are therefore counting-sorted by length (longest first) and handed to lanes in that order.
+static constexpr int ORD_THREADS = 256;
+__global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __restrict__ bucket_off,
+                                                            const uint32_t* __restrict__ seg_off, uint32_t NB,
+                                                            uint32_t* __restrict__ seg_start,
+                                                            uint32_t* __restrict__ seg_len,
+                                                            uint32_t* __restrict__ len_hist) {
+    __shared__ uint32_t lh[SEG + 1];
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
+    __syncthreads();
+    uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
+    if (seg < seg_off[NB]) {
+        uint32_t b = bucket_of_segment(seg_off, NB, seg);
+        uint32_t s = seg - seg_off[b], ns = seg_off[b + 1] - seg_off[b];
+        uint32_t o = bucket_off[b], cnt = bucket_off[b + 1] - o;
+        uint32_t k = o + (uint32_t)(((uint64_t)cnt * s) / ns), e = o + (uint32_t)(((uint64_t)cnt * (s + 1)) / ns);
+        seg_start[seg] = k;
+        seg_len[seg] = e - k;
+        atomicAdd(&lh[SEG - (e - k)], 1u);  // bin 0 = longest
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS)
+        if (lh[i]) atomicAdd(&len_hist[i], lh[i]);
+}
+__global__ void msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i <= SEG; i++) {
+            uint32_t c = len_hist[i];
+            len_hist[i] = run;
+            run += c;
+        }
+    }
+}
+__global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
+                                                             const uint32_t* __restrict__ nseg_ptr,
+                                                             uint32_t* __restrict__ len_cursor /* offsets, advanced */,
+                                                             uint32_t* __restrict__ order) {
+    __shared__ uint32_t lh[SEG + 1];
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
+    __syncthreads();
+    uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
+    bool live = seg < *nseg_ptr;
+    uint32_t bin = 0;
+    if (live) {
+        bin = SEG - seg_len[seg];
+        atomicAdd(&lh[bin], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) {
+        uint32_t v = lh[i];
+        if (v) lh[i] = atomicAdd(&len_cursor[i], v);  // reserve a run; lh[i] = its start
+    }
+    __syncthreads();
+    if (live) order[atomicAdd(&lh[bin], 1u)] = seg;
+}
+
 // Dominant kernel: one lane per segment, XYZZ accumulator in registers, affine bases gathered from HBM/L2.
 __global__ void __launch_bounds__(256) msm_accumulate(const G1Affine* __restrict__ bases,
                                                       const uint32_t* __restrict__ sorted,
-                                                      const uint32_t* __restrict__ bucket_off,
-                                                      const uint32_t* __restrict__ seg_off, uint32_t NB,
+                                                      const uint32_t* __restrict__ seg_start,
+                                                      const uint32_t* __restrict__ seg_len,
+                                                      const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ nseg_ptr,
                                                       G1XYZZ* __restrict__ partial) {
-    uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= seg_off[NB]) return;
-    // balanced split of the owning bucket into its segments
-    uint32_t b = bucket_of_segment(seg_off, NB, seg);
-    uint32_t s = seg - seg_off[b], ns = seg_off[b + 1] - seg_off[b];
-    uint32_t o = bucket_off[b], cnt = bucket_off[b + 1] - o;
-    uint32_t k = o + (uint32_t)(((uint64_t)cnt * s) / ns), e = o + (uint32_t)(((uint64_t)cnt * (s + 1)) / ns);
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *nseg_ptr) return;
+    uint32_t seg = order[t];
+    uint32_t k = seg_start[seg], e = k + seg_len[seg];
     G1XYZZ acc = g1_xyzz_identity();
     if (k < e) {
         uint32_t ent = sorted[k];
@@ -420,10 +466,17 @@ static int allow_big_lds(swm_ctx* ctx, const void* fn, size_t bytes) {
     return SWM_OK;
 }
 
-// d_scalars: n Fr in HBM.  Result: XYZZ on the host.  Everything up to the final 17-point download is enqueued
-// without host synchronisation (segment counts are bounded, not read back).
-int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result) {
-    *result = g1_xyzz_identity();
+// ---- asynchronous form -------------------------------------------------------------------------------------
+// msm_enqueue launches every kernel of one MSM plus the download of its window sums WITHOUT host synchronisation;
+// msm_finish waits for that download and does the host Horner fold.  `lane` selects the stream + device scratch set:
+//   lane < 0 : the context's own stream (what the K1 ABI entry points use);
+//   lane 0/1 : two auxiliary streams that first wait for everything enqueued on the context's stream so far.
+// The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
+// and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
+// results land in per-job pinned host slots.
+int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, MsmJob* job) {
+    job->active = false;
+    job->n = n;
     if (n == 0) return SWM_OK;
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
     ctx->stat_msm_calls++;
@@ -431,25 +484,65 @@ int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
+    unsigned red_blocks = (pl.maxB + RED_CHUNK * RED_BLOCK - 1) / (RED_CHUNK * RED_BLOCK);
+    // ---- lane set-up: stream, pinned result slot, event
+    hipStream_t main_stream = ctx->stream;
+    hipStream_t st = main_stream;
+    if (lane >= 0) {
+        lane &= 1;
+        if (!ctx->aux_stream[lane]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[lane], hipStreamNonBlocking));
+        st = ctx->aux_stream[lane];
+        if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+        SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
+        SWM_HIP(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
+    }
+    const size_t slot_bytes = (size_t)MAX_WIN * 16 * sizeof(G1XYZZ);
+    if ((size_t)pl.nwin * red_blocks * sizeof(G1XYZZ) > slot_bytes) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
+    if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
+    int slot = ctx->next_slot;
+    ctx->next_slot = (ctx->next_slot + 1) % swm_ctx::MSM_SLOTS;
+    if (!ctx->slot_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->slot_event[slot], hipEventDisableTiming));
+    job->host = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned + slot_bytes * slot);
+    job->done = ctx->slot_event[slot];
+    job->pl = pl;
+    job->red_blocks = red_blocks;
+
+    // everything below is enqueued on `st`: temporarily make it the context's stream so that launches, memsets,
+    // scratch growth and the profiling events all refer to it
+    struct StreamSwap {
+        swm_ctx* c;
+        hipStream_t old;
+        ~StreamSwap() { c->stream = old; }
+    } swap{ctx, main_stream};
+    ctx->stream = st;
+    char nm[9][32];
+    const char* base[9] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points"};
+    for (int i = 0; i < 9; i++) snprintf(nm[i], sizeof(nm[i]), "msm%d.%s", lane < 0 ? 9 : lane, base[i]);
+
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
-    uint32_t *hist, *cursor, *big_count, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4;
-    SWM_TRY(scratch(ctx, "msm.hist", zero_words * 4, (void**)&hist));
+    uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
+    uint32_t *seg_start, *seg_len, *order;
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG + 1);
+    SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
-    SWM_TRY(scratch(ctx, "msm.bucket_off", (pl.NB + 1) * 4ull, (void**)&bucket_off));
-    SWM_TRY(scratch(ctx, "msm.seg_off", (pl.NB + 1) * 4ull, (void**)&seg_off));
-    SWM_TRY(scratch(ctx, "msm.digits", total * 4, (void**)&digits));
-    SWM_TRY(scratch(ctx, "msm.sorted", total * 4, (void**)&sorted));
+    len_hist = big_count + 4;
+    SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
+    seg_len = seg_start + nseg_max;
+    order = seg_len + nseg_max;
+    SWM_TRY(scratch(ctx, nm[2], (pl.NB + 1) * 4ull, (void**)&bucket_off));
+    SWM_TRY(scratch(ctx, nm[3], (pl.NB + 1) * 4ull, (void**)&seg_off));
+    SWM_TRY(scratch(ctx, nm[4], total * 4, (void**)&digits));
+    SWM_TRY(scratch(ctx, nm[5], total * 4, (void**)&sorted));
     const unsigned scan_tiles = (pl.NB + SCAN_TILE - 1) / SCAN_TILE;
-    SWM_TRY(scratch(ctx, "msm.scan_tot", (size_t)(scan_tiles + 1) * 8, (void**)&tot_cnt));
+    SWM_TRY(scratch(ctx, nm[6], (size_t)(scan_tiles + 1) * 8, (void**)&tot_cnt));
     tot_seg = tot_cnt + scan_tiles + 1;
-    SWM_TRY(scratch(ctx, "msm.big_list", (size_t)pl.NB * 4, (void**)&big_list));
+    SWM_TRY(scratch(ctx, nm[7], (size_t)pl.NB * 4, (void**)&big_list));
+    // XYZZ scratch: partial[nseg_max] | buckets[NB] | wpart[nwin * red_blocks]
     G1XYZZ *partial, *buckets, *wpart;
-    SWM_TRY(scratch(ctx, "msm.partial", nseg_max * sizeof(G1XYZZ), (void**)&partial));
-    SWM_TRY(scratch(ctx, "msm.buckets", (size_t)pl.NB * sizeof(G1XYZZ), (void**)&buckets));
-    unsigned red_blocks = (pl.maxB + RED_CHUNK * RED_BLOCK - 1) / (RED_CHUNK * RED_BLOCK);
-    SWM_TRY(scratch(ctx, "msm.wpart", (size_t)pl.nwin * red_blocks * sizeof(G1XYZZ), (void**)&wpart));
+    SWM_TRY(scratch(ctx, nm[8], (nseg_max + pl.NB + (size_t)pl.nwin * red_blocks) * sizeof(G1XYZZ), (void**)&partial));
+    buckets = partial + nseg_max;
+    wpart = buckets + pl.NB;
 
     SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
@@ -467,26 +560,49 @@ int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t
     SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
                bucket_off, cursor, sorted);
     unsigned grid_b = (pl.NB + 255) / 256;
+    unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
+               seg_start, seg_len, len_hist);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, len_hist,
+               order);
     SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
-               sorted, bucket_off, seg_off, pl.NB, partial);
+               sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_bucket_sum", msm_bucket_sum, dim3(grid_b), dim3(256), 0, partial, seg_off, pl.NB, buckets);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, buckets);
     SWM_LAUNCH(ctx, "msm_window_reduce", msm_window_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), buckets, pl, wpart);
-    std::vector<G1XYZZ> h((size_t)pl.nwin * red_blocks);
-    SWM_HIP(ctx, hipMemcpyAsync(h.data(), wpart, h.size() * sizeof(G1XYZZ), hipMemcpyDeviceToHost, ctx->stream));
-    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
+    job->active = true;
+    return SWM_OK;
+}
+
+int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
+    *result = g1_xyzz_identity();
+    if (!job->active) return SWM_OK;
+    SWM_HIP(ctx, hipEventSynchronize(job->done));
+    job->active = false;
     // host: fold workgroup partials, then Horner over windows (high -> low, c doublings each)
+    const WinLayout& pl = job->pl;
     G1XYZZ total_pt = g1_xyzz_identity();
     for (unsigned w = pl.nwin; w-- > 0;) {
         for (unsigned k = 0; k < pl.c[w]; k++) total_pt = g1_dbl(total_pt);
         G1XYZZ ws = g1_xyzz_identity();
-        for (unsigned j = 0; j < red_blocks; j++) g1_add(ws, h[(size_t)w * red_blocks + j]);
+        for (unsigned j = 0; j < job->red_blocks; j++) g1_add(ws, job->host[(size_t)w * job->red_blocks + j]);
         g1_add(total_pt, ws);
     }
     *result = total_pt;
     return SWM_OK;
+}
+
+// Synchronous form on the context's stream (K1 ABI).
+int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result) {
+    MsmJob job;
+    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_scalars, n, mont, &job));
+    return msm_finish(ctx, &job, result);
 }
 
 }  // namespace swm
