@@ -7,9 +7,10 @@
 #include <algorithm>
 #include "context.h"
 #include "g1.cuh"
+#include "msm.h"
 
 namespace swm {
-int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result);
+
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
 int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
              size_t rows);
@@ -230,10 +231,19 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
     }
     e = hipMemcpyAsync(b->d_points, xy, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&b->d_points28, n * sizeof(G1Affine));
     if (e != hipSuccess) {
         (void)hipFree(b->d_points);
         delete b;
         return set_err(ctx, SWM_ERR_HIP, "srs_upload: %s", hipGetErrorString(e));
+    }
+    int rc = msm_scale_bases_run(ctx, (const G1Affine*)b->d_points, n, (G1Affine*)b->d_points28);
+    if (rc == SWM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SWM_ERR_HIP;
+    if (rc != SWM_OK) {
+        (void)hipFree(b->d_points);
+        (void)hipFree(b->d_points28);
+        delete b;
+        return rc;
     }
     *out = b;
     return SWM_OK;
@@ -242,6 +252,7 @@ int swm_srs_free(swm_ctx* ctx, swm_bases* bases) {
     if (!ctx || !bases) return SWM_ERR_INVALID_ARG;
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SWM_HIP(ctx, hipFree(bases->d_points));
+    SWM_HIP(ctx, hipFree(bases->d_points28));
     delete bases;
     return SWM_OK;
 }
@@ -258,8 +269,8 @@ int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const vo
     if (offset > bases->n || n > bases->n - offset)
         return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: %zu scalars at offset %zu exceed %zu bases", n, offset, bases->n);
     G1XYZZ r;
-    SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset, d_scalars, n,
-                    scalars_montgomery, &r));
+    SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset,
+                    reinterpret_cast<const G1Affine*>(bases->d_points28) + offset, d_scalars, n, scalars_montgomery, &r));
     write_jac(r, out_jac);
     return SWM_OK;
 }
@@ -417,7 +428,7 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
 // ------------------------------------------------------------------------------------------------ self-tests
 int swm_selftest_mul(swm_ctx* ctx, int which, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!ctx || !a || !b || !out) return SWM_ERR_INVALID_ARG;
-    size_t es = which == 0 ? 48 : 32;
+    size_t es = which == 1 ? 32 : 48;
     char *da = nullptr, *db = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", n * es + 64, (void**)&da));
     SWM_TRY(scratch(ctx, "stage.b", n * es + 64, (void**)&db));

@@ -62,7 +62,8 @@ struct swm_ctx {
 };
 
 struct swm_bases {
-    void* d_points = nullptr;  // n x G1Affine (96 B, Montgomery)
+    void* d_points = nullptr;    // n x G1Affine (96 B, Montgomery radix 2^384)
+    void* d_points28 = nullptr;  // same points, coordinates x 2^8 (radix 2^392) for the MSM inner loop
     size_t n = 0;
 };
 

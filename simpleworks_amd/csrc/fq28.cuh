@@ -1,0 +1,162 @@
+// fq28.cuh — BLS12-377 Fq in 14 x 28-bit limbs with LAZY carries, used inside the MSM bucket accumulation.
+//
+// Why: on gfx950 every carry-propagating integer op (v_addc_co_u32, v_lshl_add_u64) issues at the same half rate as
+// v_mad_u64_u32 (measured 4.2 cycles per wave64 per SIMD, tools/ubench/valu_rates.hip), so the 32-bit-limb Comba
+// multiply in ff.cuh pays one carry fold per partial product: 276 x (mad + addc) ~ 2640 cycles per wave.
+// With 28-bit limbs a column of up to 28 partial products fits a 64-bit accumulator without any carry handling:
+// 378 v_mad_u64_u32 + 27 column shifts ~ 1.9k cycles, and additions / subtractions become 14 full-rate 32-bit adds
+// with no comparison against the modulus.
+//
+// Representation.  value = sum l[i] 2^(28 i); Montgomery radix R' = 2^392 (NOT the 2^384 of the memory format: inputs
+// are pre-scaled by 2^8 once, outputs are scaled back with one multiplication per coordinate).
+// Bounds (checked case by case at the call sites, see g1_28 in msm.hip):
+//   N  "normalised": limbs < 2^28 (top limb < 2^15), value < 2p         — what mul28 returns
+//   D  "lazy":       limbs < 2^30,                    value < 128 p      — what mul28 accepts for BOTH operands:
+//        column sum <= 14 * 2^60 + 14 * 2^56 + 2^37 < 2^64;  a b / 2^392 < 2^14 p^2 / 2^392 < p / 2  =>  result < 1.5 p
+// Subtraction a - b is a + SPREADk - b, where SPREADk are limbs of k*p with 2^28 borrowed into every limb so that no
+// limb goes negative; the value grows by k*p, which the next multiplication absorbs.
+#pragma once
+#include "ff.cuh"
+
+namespace swm {
+
+struct Fq28 {
+    uint32_t l[14];
+};
+static constexpr uint32_t M28 = (1u << 28) - 1;
+
+struct Fq28Consts {
+    static constexpr uint32_t P[14] = SWM_FQ28_P;
+    static constexpr uint32_t ONE[14] = SWM_FQ28_ONE;
+    static constexpr uint32_t TO384[14] = SWM_FQ28_TO384;
+    static constexpr uint32_t SPREAD4[14] = SWM_FQ28_SPREAD4_1;
+    static constexpr uint32_t SPREAD8[14] = SWM_FQ28_SPREAD8_1;
+    static constexpr uint32_t SPREAD16_3[14] = SWM_FQ28_SPREAD16_3;
+    static constexpr uint32_t SPREAD32[14] = SWM_FQ28_SPREAD32_1;
+    static constexpr uint32_t SPREAD64[14] = SWM_FQ28_SPREAD64_1;
+};
+
+// 12 x 32-bit words (value < 2^384) -> 14 x 28-bit limbs (top limb holds bits 364..383)
+__device__ __forceinline__ Fq28 fq28_unpack(const Fq& a) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int bit = 28 * i, w = bit >> 5, off = bit & 31;
+        uint32_t v = a.v[w] >> off;
+        if (off > 4 && w + 1 < 12) v |= a.v[w + 1] << (32 - off);
+        r.l[i] = i < 13 ? (v & M28) : v;
+    }
+    return r;
+}
+// normalised limbs (< 2^28, value < 2^384) -> 12 words
+__device__ __forceinline__ Fq fq28_pack(const Fq28& a) {
+    Fq r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 32 * w, i = bit / 28, off = bit - 28 * i;
+        uint32_t v = a.l[i] >> off;
+        if (i + 1 < 14) v |= a.l[i + 1] << (28 - off);
+        if (28 - off + 28 < 32 && i + 2 < 14) v |= a.l[i + 2] << (56 - off);
+        r.v[w] = v;
+    }
+    return r;
+}
+
+// carry propagation: limbs < 2^32 in, limbs < 2^28 out (top limb takes what is left)
+__device__ __forceinline__ Fq28 fq28_normalize(const Fq28& a) {
+    Fq28 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        uint32_t t = a.l[i] + c;
+        r.l[i] = t & M28;
+        c = t >> 28;
+    }
+    r.l[13] = a.l[13] + c;
+    return r;
+}
+__device__ __forceinline__ Fq28 fq28_add(const Fq28& a, const Fq28& b) {  // lazy: limbs add, no carry
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a - b + k p  (b limbs must not exceed the spread's borrow: < 2^28 for the _1 spreads, < 3 * 2^28 for SPREAD16_3)
+template <const uint32_t* SP>
+__device__ __forceinline__ Fq28 fq28_sub(const Fq28& a, const Fq28& b, const uint32_t (&sp)[14]) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + sp[i] - b.l[i];
+    return r;
+}
+#define FQ28_SUB(a, b, SPREAD) fq28_sub_impl((a), (b), Fq28Consts::SPREAD)
+__device__ __forceinline__ Fq28 fq28_sub_impl(const Fq28& a, const Fq28& b, const uint32_t (&sp)[14]) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + sp[i] - b.l[i];
+    return r;
+}
+
+// Montgomery product a b 2^-392 mod p (result N).  Operands may be lazy (D).
+__device__ __forceinline__ Fq28 fq28_mul(const Fq28& a, const Fq28& b) {
+    Fq28 r;
+    uint32_t m[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        // p = 1 mod 2^28: m_k = -acc mod 2^28 and acc + m_k * p_0 clears the low limb
+        m[k] = (0u - (uint32_t)acc) & M28;
+        acc = (acc + m[k]) >> 28;
+    }
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        r.l[k - 14] = (uint32_t)acc & M28;
+        acc >>= 28;
+    }
+    r.l[13] = (uint32_t)acc;
+    return r;
+}
+__device__ __forceinline__ Fq28 fq28_sqr(const Fq28& a) { return fq28_mul(a, a); }
+
+// value == 0 mod p for an N value (normalised limbs, value < 2p): all limbs zero, or equal to p
+__device__ __forceinline__ bool fq28_is_zero_mod_p(const Fq28& a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        z |= a.l[i];
+        e |= a.l[i] ^ Fq28Consts::P[i];
+    }
+    return z == 0 || e == 0;
+}
+// N value (< 2p) -> canonical (< p), normalised limbs
+__device__ __forceinline__ Fq28 fq28_canonical(const Fq28& a) {
+    // t = a - p with borrow chain
+    Fq28 t;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint32_t d = a.l[i] - Fq28Consts::P[i] - borrow;
+        borrow = (d >> 31) & 1;  // limbs < 2^28 (top < 2^15): a negative difference sets bit 31
+        t.l[i] = i < 13 ? (d & M28) : d;
+    }
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = borrow ? a.l[i] : t.l[i];
+    return r;
+}
+__device__ __forceinline__ Fq28 fq28_const(const uint32_t (&c)[14]) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = c[i];
+    return r;
+}
+
+}  // namespace swm

@@ -75,7 +75,8 @@ struct swm_pk {
     HostCsr ha, hb, hc;  // padded, balanced matrices (kept for key serialisation)
     DevCsr a, b, c, at, bt, ct;
     MatrixArith ar[3];
-    G1Affine* d_powers = nullptr;  // full SRS powers [0, srs_max_degree]
+    G1Affine* d_powers = nullptr;    // full SRS powers [0, srs_max_degree]
+    G1Affine* d_powers28 = nullptr;  // the same powers scaled for the MSM inner loop (msm_scale_bases_run)
     size_t srs_max_degree = 0;
     std::vector<G1Affine> gamma_powers;
     GammaTable gtab;
@@ -315,21 +316,20 @@ uint64_t ahp_max_degree(uint64_t num_constraints, uint64_t num_variables, uint64
 
 // ================================================================================================ commitments
 // MSM of a device coefficient vector against SRS powers starting at `offset` -> host XYZZ (synchronous form)
-G1XYZZ commit_dev(swm_ctx* ctx, const G1Affine* d_powers, size_t n_powers, size_t offset, const Fr* coeffs, size_t n) {
+G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n) {
     if (n == 0) return g1_xyzz_identity();
-    if (offset + n > n_powers) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+    if (offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
     G1XYZZ r;
-    rc_check(ctx, msm_run(ctx, d_powers + offset, coeffs, n, 1, &r));
+    rc_check(ctx, msm_run(ctx, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &r));
     return r;
 }
 // asynchronous form: alternates between the two MSM lanes of the context
 struct AsyncMsm {
     MsmJob job;
 };
-void commit_enqueue(swm_ctx* ctx, int* lane, const G1Affine* d_powers, size_t n_powers, size_t offset, const Fr* coeffs,
-                    size_t n, AsyncMsm* out) {
-    if (n && offset + n > n_powers) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ & 1, d_powers + offset, coeffs, n, 1, &out->job));
+void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
+    if (n && offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ & 1, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &out->job));
 }
 G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
     G1XYZZ r;
@@ -355,8 +355,8 @@ void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs
                      bool hiding, CommitJob* job) {
     job->has_bound = has_bound;
     job->hiding = hiding;
-    commit_enqueue(ctx, lane, pk.d_powers, pk.srs_max_degree + 1, 0, coeffs, n, &job->plain);
-    if (has_bound) commit_enqueue(ctx, lane, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
+    commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
+    if (has_bound) commit_enqueue(ctx, lane, pk, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
 }
 Commitment pc_commit_end(swm_ctx* ctx, const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
     Commitment c;
@@ -627,6 +627,8 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     hip_check(ctx, hipMalloc((void**)&pk->d_powers, (srs->max_degree + 1) * sizeof(G1Affine)), "hipMalloc(pk powers)");
     hip_check(ctx, hipMemcpyAsync(pk->d_powers, srs->d_powers, (srs->max_degree + 1) * sizeof(G1Affine),
                                   hipMemcpyDeviceToDevice, ctx->stream), "d2d");
+    hip_check(ctx, hipMalloc((void**)&pk->d_powers28, (srs->max_degree + 1) * sizeof(G1Affine)), "hipMalloc(pk powers28)");
+    rc_check(ctx, msm_scale_bases_run(ctx, pk->d_powers, srs->max_degree + 1, pk->d_powers28));
     pk->gamma_powers = srs->gamma_powers;
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->ha = p.a; pk->hb = p.b; pk->hc = p.c;
@@ -657,7 +659,7 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     for (int i = 0; i < 3; i++) {
         const DVec* polys[4] = {&pk->ar[i].row, &pk->ar[i].col, &pk->ar[i].val, &pk->ar[i].row_col};
         AsyncMsm jobs[4];
-        for (int j = 0; j < 4; j++) commit_enqueue(ctx, &lane, pk->d_powers, pk->srs_max_degree + 1, 0, polys[j]->p, pk->K, &jobs[j]);
+        for (int j = 0; j < 4; j++) commit_enqueue(ctx, &lane, *pk, 0, polys[j]->p, pk->K, &jobs[j]);
         for (int j = 0; j < 4; j++) {
             Commitment c;
             c.comm = g1_to_affine(commit_wait(ctx, &jobs[j]));
@@ -1132,7 +1134,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         }
         // witness = p / (X - point) against the powers; degree-bounded members: shifted witnesses against the shifted powers
         o.wq = div_linear(ctx, o.comb.p, plen, point);
-        commit_enqueue(ctx, &lane, pk.d_powers, pk.srs_max_degree + 1, 0, o.wq.work.p + 1, plen ? plen - 1 : 0, &o.wjob);
+        commit_enqueue(ctx, &lane, pk, 0, o.wq.work.p + 1, plen ? plen - 1 : 0, &o.wjob);
         o.sq.resize(o.shifted_terms.size());
         o.sjobs.resize(o.shifted_terms.size());
         for (size_t i = 0; i < o.shifted_terms.size(); i++) {
@@ -1142,7 +1144,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             Fr* q = o.sq[i].work.p;
             size_t qn = stt.lp->n ? stt.lp->n - 1 : 0;
             ew(ctx, "open_scale", qn, [=] __device__(size_t t) { q[t + 1] = fp_mul(q[t + 1], k); });
-            commit_enqueue(ctx, &lane, pk.d_powers, pk.srs_max_degree + 1, pk.srs_max_degree - stt.lp->bound, q + 1, qn, &o.sjobs[i]);
+            commit_enqueue(ctx, &lane, pk, pk.srs_max_degree - stt.lp->bound, q + 1, qn, &o.sjobs[i]);
         }
     }
     for (int pi = 0; pi < 2; pi++) {
@@ -1251,6 +1253,8 @@ swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
     hip_check(ctx, hipMalloc((void**)&pk->d_powers, np * sizeof(G1Affine)), "hipMalloc(pk powers)");
     hip_check(ctx, hipMemcpyAsync(pk->d_powers, pw, np * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream), "h2d");
     hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    hip_check(ctx, hipMalloc((void**)&pk->d_powers28, np * sizeof(G1Affine)), "hipMalloc(pk powers28)");
+    rc_check(ctx, msm_scale_bases_run(ctx, pk->d_powers, np, pk->d_powers28));
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->a = upload_csr(ctx, pk->ha);
     pk->b = upload_csr(ctx, pk->hb);
@@ -1364,6 +1368,7 @@ void swm_pk_destroy(swm_ctx* ctx, swm_pk* pk) {
     if (!pk) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (pk->d_powers) (void)hipFree(pk->d_powers);
+    if (pk->d_powers28) (void)hipFree(pk->d_powers28);
     delete pk;
 }
 void swm_vk_destroy(swm_vk* vk) { delete vk; }

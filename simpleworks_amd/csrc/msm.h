@@ -27,8 +27,13 @@ struct MsmJob {
     hipEvent_t done = nullptr;
 };
 
-int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, MsmJob* job);
+// d_bases28: the bases with both coordinates pre-multiplied by 2^8 (msm_scale_bases_run), consumed by the 28-bit-limb
+// inner loop of msm_accumulate; d_bases: the plain Montgomery (radix 2^384) points, used by the cold path.
+int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out);
+int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
+                int mont, MsmJob* job);
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
-int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result);
+int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
+            G1XYZZ* result);
 
 }  // namespace swm

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "context.h"
+#include "fq28.cuh"
 #include "g1.cuh"
 #include "msm.h"
 
@@ -336,7 +337,48 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __r
 }
 
 // Dominant kernel: one lane per segment, XYZZ accumulator in registers, affine bases gathered from HBM/L2.
-__global__ void __launch_bounds__(256) msm_accumulate(const G1Affine* __restrict__ bases,
+//
+// The inner loop runs in the 28-bit lazy-carry representation of fq28.cuh (bases28 = the same points with both
+// coordinates pre-multiplied by 2^8, i.e. in Montgomery radix 2^392).  Bounds, per EFD madd-2008-s step
+// (N: normalised limbs, value < 2p;  X1: normalised, < 18p;  Y1: normalised, < 6p;  ZZ1, ZZZ1: N):
+//   U2 = x2 ZZ1, S2 = y2 ZZZ1                              N          (y2 may be 4p - y2: limbs < 2^30, value < 4p)
+//   P  = U2 + 32p - X1                                     limbs < 2^30, value in (14p, 34p)
+//   R  = S2 +  8p - Y1                                     limbs < 2^30, value in ( 2p, 10p)
+//   PP = P^2, PPP = P PP, Q = X1 PP, RR = R^2              N          (products of two lazy values: 14 * 2^60 < 2^64)
+//   X3 = normalise(RR + 16p - PPP - 2Q)                    normalised, value in (10p, 18p)
+//   V  = Q + 32p - X3                                      limbs < 2^30, value in (14p, 24p)
+//   Y3 = normalise(R V + 4p - Y1 PPP)                      normalised, value in ( 2p,  6p)
+//   ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP                          N
+// P = 0 mod p (doubling or cancellation: the point equals +-accumulator) is detected on PP, which is an N value; the
+// segment is then recomputed with the fully reducing 32-bit-limb adder (cold path).
+struct Acc28 {
+    Fq28 x, y, zz, zzz;
+};
+__device__ __forceinline__ bool madd28(Acc28& a, const Fq28& x2, const Fq28& y2) {
+    Fq28 u2 = fq28_mul(x2, a.zz);
+    Fq28 s2 = fq28_mul(y2, a.zzz);
+    Fq28 p = FQ28_SUB(u2, a.x, SPREAD32);
+    Fq28 r = FQ28_SUB(s2, a.y, SPREAD8);
+    Fq28 pp = fq28_sqr(p);
+    if (fq28_is_zero_mod_p(pp)) return false;
+    Fq28 ppp = fq28_mul(p, pp);
+    Fq28 q = fq28_mul(a.x, pp);
+    Fq28 rr = fq28_sqr(r);
+    Fq28 x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - q.l[i] - q.l[i];
+    x3 = fq28_normalize(x3);
+    Fq28 v = FQ28_SUB(q, x3, SPREAD32);
+    Fq28 t1 = fq28_mul(r, v);
+    Fq28 t2 = fq28_mul(a.y, ppp);
+    a.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));
+    a.x = x3;
+    a.zz = fq28_mul(a.zz, pp);
+    a.zzz = fq28_mul(a.zzz, ppp);
+    return true;
+}
+__global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restrict__ bases,
+                                                      const G1Affine* __restrict__ bases28,
                                                       const uint32_t* __restrict__ sorted,
                                                       const uint32_t* __restrict__ seg_start,
                                                       const uint32_t* __restrict__ seg_len,
@@ -346,22 +388,58 @@ __global__ void __launch_bounds__(256) msm_accumulate(const G1Affine* __restrict
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *nseg_ptr) return;
     uint32_t seg = order[t];
-    uint32_t k = seg_start[seg], e = k + seg_len[seg];
-    G1XYZZ acc = g1_xyzz_identity();
-    if (k < e) {
+    const uint32_t k0 = seg_start[seg], e = k0 + seg_len[seg];
+    if (k0 >= e) {
+        partial[seg] = g1_xyzz_identity();
+        return;
+    }
+    bool ok = true;
+    Acc28 acc;
+    {
+        uint32_t ent = sorted[k0];
+        G1Affine p = bases28[ent & 0x7fffffffu];
+        acc.x = fq28_unpack(p.x);
+        Fq28 y = fq28_unpack(p.y);
+        if (ent >> 31) {  // -y = 4p - y, brought back to normalised limbs (value < 4p < 6p)
+            Fq28 z;
+#pragma unroll
+            for (int i = 0; i < 14; i++) z.l[i] = Fq28Consts::SPREAD4[i] - y.l[i];
+            y = fq28_normalize(z);
+        }
+        acc.y = y;
+        acc.zz = fq28_const(Fq28Consts::ONE);
+        acc.zzz = acc.zz;
+    }
+    for (uint32_t k = k0 + 1; k < e && ok; k++) {
+        uint32_t ent = sorted[k];
+        G1Affine p = bases28[ent & 0x7fffffffu];
+        Fq28 x2 = fq28_unpack(p.x), y2 = fq28_unpack(p.y);
+        if (ent >> 31) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) y2.l[i] = Fq28Consts::SPREAD4[i] - y2.l[i];  // limbs < 2^29, value < 4p
+        }
+        ok = madd28(acc, x2, y2);
+    }
+    if (ok) {
+        // back to the memory format: Montgomery radix 2^384, canonical, 32-bit limbs
+        Fq28 to384 = fq28_const(Fq28Consts::TO384);
+        G1XYZZ out;
+        out.x = fq28_pack(fq28_canonical(fq28_mul(acc.x, to384)));
+        out.y = fq28_pack(fq28_canonical(fq28_mul(acc.y, to384)));
+        out.zz = fq28_pack(fq28_canonical(fq28_mul(acc.zz, to384)));
+        out.zzz = fq28_pack(fq28_canonical(fq28_mul(acc.zzz, to384)));
+        partial[seg] = out;
+        return;
+    }
+    // cold path: a point met +-(the running sum); redo this segment with the fully reducing adder
+    G1XYZZ acc32 = g1_xyzz_identity();
+    for (uint32_t k = k0; k < e; k++) {
         uint32_t ent = sorted[k];
         G1Affine p = bases[ent & 0x7fffffffu];
         if (ent >> 31) p.y = fp_neg(p.y);
-        acc = g1_from_affine(p);
-        k++;
+        g1_add_mixed(acc32, p);
     }
-    for (; k < e; k++) {
-        uint32_t ent = sorted[k];
-        G1Affine p = bases[ent & 0x7fffffffu];
-        if (ent >> 31) p.y = fp_neg(p.y);
-        g1_add_mixed(acc, p);
-    }
-    partial[seg] = acc;
+    partial[seg] = acc32;
 }
 
 // kept out of line: these kernels are latency-bound and otherwise inline ~10 copies of the 14-multiplication adder
@@ -466,6 +544,25 @@ static int allow_big_lds(swm_ctx* ctx, const void* fn, size_t bytes) {
     return SWM_OK;
 }
 
+// bases28[i] = (2^8 x, 2^8 y): the same points with coordinates in Montgomery radix 2^392 (infinity stays (0, 0))
+__global__ void __launch_bounds__(256) msm_scale_bases(const G1Affine* __restrict__ in, size_t n, G1Affine* __restrict__ out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k[12] = SWM_FQ_SCALE256_MONT;
+    Fq c;
+#pragma unroll
+    for (int j = 0; j < 12; j++) c.v[j] = k[j];
+    G1Affine p = in[i];
+    p.x = fp_mul(p.x, c);
+    p.y = fp_mul(p.y, c);
+    out[i] = p;
+}
+int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out) {
+    if (n == 0) return SWM_OK;
+    SWM_LAUNCH(ctx, "msm_scale_bases", msm_scale_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_in, n, d_out);
+    return SWM_OK;
+}
+
 // ---- asynchronous form -------------------------------------------------------------------------------------
 // msm_enqueue launches every kernel of one MSM plus the download of its window sums WITHOUT host synchronisation;
 // msm_finish waits for that download and does the host Horner fold.  `lane` selects the stream + device scratch set:
@@ -474,7 +571,8 @@ static int allow_big_lds(swm_ctx* ctx, const void* fn, size_t bytes) {
 // The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
-int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, MsmJob* job) {
+int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
+                int mont, MsmJob* job) {
     job->active = false;
     job->n = n;
     if (n == 0) return SWM_OK;
@@ -567,7 +665,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const void* d_s
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, len_hist,
                order);
     SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
-               sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
+               d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_bucket_sum", msm_bucket_sum, dim3(grid_b), dim3(256), 0, partial, seg_off, pl.NB, buckets);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, buckets);
@@ -599,9 +697,10 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 }
 
 // Synchronous form on the context's stream (K1 ABI).
-int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const void* d_scalars, size_t n, int mont, G1XYZZ* result) {
+int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
+            G1XYZZ* result) {
     MsmJob job;
-    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_scalars, n, mont, &job));
+    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job));
     return msm_finish(ctx, &job, result);
 }
 

@@ -5,6 +5,7 @@
 // All of it is HBM-bound integer work: one lane per row / element, 16-B vector loads, no LDS, no MFMA.
 // Algorithmic bytes: vec_mul 96 B per element; batch inverse 64 B per element.
 #include "context.h"
+#include "fq28.cuh"
 #include "g1.cuh"
 
 namespace swm {
@@ -77,6 +78,22 @@ __global__ void __launch_bounds__(256) selftest_mul_chain(F* out, int iters) {
     }
     out[i] = fp_add(a, b);
 }
+// 28-bit-limb multiplier: out = canonical(a * b * 2^-392 mod p), operands given as packed 384-bit integers
+__global__ void __launch_bounds__(256) selftest_mul28_kernel(const Fq* a, const Fq* b, Fq* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(a[i]), fq28_unpack(b[i]))));
+}
+__global__ void __launch_bounds__(256) selftest_mul28_chain(Fq* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    Fq28 a = fq28_const(Fq28Consts::ONE), b = fq28_const(Fq28Consts::TO384);
+    a.l[0] ^= (uint32_t)i & 0xffff;
+    b.l[1] ^= (uint32_t)(i * 2654435761u) & 0xffff;
+    for (int k = 0; k < iters; k++) {
+        a = fq28_mul(a, b);
+        b = fq28_mul(b, a);
+    }
+    out[i] = fq28_pack(fq28_canonical(fq28_mul(a, b)));
+}
 __global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a, const G1Affine* b, G1Jac* out,
                                                               size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -92,7 +109,10 @@ __global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a,
 
 int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n) {
     unsigned grid = (unsigned)((n + 255) / 256);
-    if (which == 0)
+    if (which == 2)
+        SWM_LAUNCH(ctx, "selftest_mul28", selftest_mul28_kernel, dim3(grid), dim3(256), 0, (const Fq*)a, (const Fq*)b,
+                   (Fq*)out, n);
+    else if (which == 0)
         SWM_LAUNCH(ctx, "selftest_mul_fq", selftest_mul_kernel<Fq>, dim3(grid), dim3(256), 0, (const Fq*)a,
                    (const Fq*)b, (Fq*)out, n);
     else
@@ -102,7 +122,9 @@ int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void
 }
 int selftest_chain_run(swm_ctx* ctx, int which, void* out, size_t threads, int iters) {
     unsigned grid = (unsigned)(threads / 256);
-    if (which == 0)
+    if (which == 2)
+        SWM_LAUNCH(ctx, "selftest_chain28", selftest_mul28_chain, dim3(grid), dim3(256), 0, (Fq*)out, iters);
+    else if (which == 0)
         SWM_LAUNCH(ctx, "selftest_chain_fq", selftest_mul_chain<Fq>, dim3(grid), dim3(256), 0, (Fq*)out, iters);
     else
         SWM_LAUNCH(ctx, "selftest_chain_fr", selftest_mul_chain<Fr>, dim3(grid), dim3(256), 0, (Fr*)out, iters);
