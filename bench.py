@@ -191,6 +191,16 @@ def main():
             # Algorithmic bytes per launch = 128 B x (points the library logged) / (MSM launches)  (SURVEY §8d).
             alg_bytes = 128.0 * work["msm_points"] / work["msm_calls"]
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected
+        # separately as MI355X_MICROARCH.md prescribes; summary committed under profiles/), scaled per point
+        traffic = None
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_msm_accumulate.json"))
+            if pmcs:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+                traffic = pmc["hbm_bytes_per_point"] * (alg_bytes / 128.0)
+        except Exception:
+            traffic = None
         out = {
             "metric": METRIC, "value": units * world * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -199,7 +209,7 @@ def main():
                        "multi_gpu": "replicas (one proof per rank)" if args.workload == "prove" else
                        "point-range shards, all-gather of 144-B partials"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "work_per_step": {k: v / args.steps for k, v in work.items()},
