@@ -125,6 +125,27 @@ __device__ __forceinline__ Fq28 fq28_mul(const Fq28& a, const Fq28& b) {
     return r;
 }
 __device__ __forceinline__ Fq28 fq28_sqr(const Fq28& a) { return fq28_mul(a, a); }
+// Out-of-line form: ~4 KB of code reached through s_swappc instead of ~4 KB inlined at every call site.  A group
+// operation is 9-14 multiplications, i.e. 40-60 KB of straight-line code when inlined: more than the 64 KB instruction
+// cache two CUs share, so kernels that execute each adder once per step (bucket stage) stream their code from L2 on
+// every operation (measured ~28 us per addition instead of ~12).  Operands travel in VGPRs (2 x 14 dwords).
+__device__ __noinline__ Fq28 fq28_mul_call(const Fq28 a, const Fq28 b) { return fq28_mul(a, b); }
+struct MulInline {
+    static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul(a, b); }
+};
+struct MulCall {
+    static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul_call(a, b); }
+};
+// Inline multiplier fenced by scheduling barriers: stops the compiler from interleaving independent multiplications
+// of a group operation (which buys no ILP on an in-order SIMD but doubles the live registers and forces spills).
+struct MulFenced {
+    static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) {
+        __builtin_amdgcn_sched_barrier(0);
+        Fq28 r = fq28_mul(a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        return r;
+    }
+};
 
 // value == 0 mod p for an N value (normalised limbs, value < 2p): all limbs zero, or equal to p
 __device__ __forceinline__ bool fq28_is_zero_mod_p(const Fq28& a) {
@@ -157,6 +178,132 @@ __device__ __forceinline__ Fq28 fq28_const(const uint32_t (&c)[14]) {
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = c[i];
     return r;
+}
+
+// ------------------------------------------------------------------------------------------------ XYZZ points in the 28-bit domain
+// Coordinates are field elements times 2^392.  Invariants between operations ("point form"):
+//   x: normalised limbs, value < 18p;  y: normalised limbs, value < 6p;  zz, zzz: N (value < 2p);  identity: zz == 0 exactly.
+// In memory a point is a G1XYZZ whose four 384-bit slots hold these (non-canonical, < 2^382) integers.
+struct P28 {
+    Fq28 x, y, zz, zzz;
+};
+__device__ __forceinline__ bool p28_is_identity(const P28& p) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) z |= p.zz.l[i];
+    return z == 0;
+}
+__device__ __forceinline__ P28 p28_identity() {
+    P28 r;
+    r.x = fq28_const(Fq28Consts::ONE);
+    r.y = r.x;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.zz.l[i] = r.zzz.l[i] = 0;
+    return r;
+}
+template <class XYZZ>
+__device__ __forceinline__ P28 p28_load(const XYZZ& m) {
+    P28 r;
+    r.x = fq28_unpack(m.x);
+    r.y = fq28_unpack(m.y);
+    r.zz = fq28_unpack(m.zz);
+    r.zzz = fq28_unpack(m.zzz);
+    return r;
+}
+template <class XYZZ>
+__device__ __forceinline__ void p28_store(XYZZ& m, const P28& p) {
+    m.x = fq28_pack(p.x);
+    m.y = fq28_pack(p.y);
+    m.zz = fq28_pack(p.zz);
+    m.zzz = fq28_pack(p.zzz);
+}
+
+// doubling (EFD dbl-2008-s-1, a = 0); identity stays identity (zz, zzz are multiplied)
+template <class M = MulInline>
+__device__ __forceinline__ P28 p28_dbl(const P28& p) {
+    P28 r;
+    Fq28 u = fq28_add(p.y, p.y);             // limbs < 2^29, value < 12p
+    Fq28 v = M::mul(u, u);                    // N
+    Fq28 w = M::mul(u, v);                 // N
+    Fq28 s = M::mul(p.x, v);               // N
+    Fq28 xx = M::mul(p.x, p.x);                 // N
+    Fq28 m = fq28_add(fq28_add(xx, xx), xx); // limbs < 3 * 2^28, value < 6p
+    Fq28 mm = M::mul(m, m);                   // N
+    Fq28 x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = mm.l[i] + Fq28Consts::SPREAD16_3[i] - s.l[i] - s.l[i];
+    r.x = fq28_normalize(x3);                                 // (12p, 18p)
+    Fq28 t1 = M::mul(m, FQ28_SUB(s, r.x, SPREAD32));        // lazy operands: 3 * 2^28 x 2^30 limbs
+    Fq28 t2 = M::mul(w, p.y);
+    r.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));          // (2p, 6p)
+    r.zz = M::mul(v, p.zz);
+    r.zzz = M::mul(w, p.zzz);
+    return r;
+}
+
+// acc += q (EFD add-2008-s).  Returns false when the generic formula does not apply (q = +-acc): the caller falls
+// back to p28_add_slow.  Identity operands are handled here.
+template <class M = MulInline>
+__device__ __forceinline__ bool p28_add_fast(P28& a, const P28& q) {
+    if (p28_is_identity(q)) return true;
+    if (p28_is_identity(a)) {
+        a = q;
+        return true;
+    }
+    Fq28 u1 = M::mul(a.x, q.zz), u2 = M::mul(q.x, a.zz);
+    Fq28 s1 = M::mul(a.y, q.zzz), s2 = M::mul(q.y, a.zzz);
+    Fq28 p = FQ28_SUB(u2, u1, SPREAD4);   // limbs < 2^30, value in (2p, 6p)
+    Fq28 r = FQ28_SUB(s2, s1, SPREAD4);
+    Fq28 pp = M::mul(p, p);
+    if (fq28_is_zero_mod_p(pp)) return false;
+    Fq28 ppp = M::mul(p, pp);
+    Fq28 qq = M::mul(u1, pp);
+    Fq28 rr = M::mul(r, r);
+    Fq28 x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - qq.l[i] - qq.l[i];
+    x3 = fq28_normalize(x3);              // (10p, 18p)
+    Fq28 t1 = M::mul(r, FQ28_SUB(qq, x3, SPREAD32));
+    Fq28 t2 = M::mul(s1, ppp);
+    a.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));
+    a.x = x3;
+    a.zz = M::mul(M::mul(a.zz, q.zz), pp);
+    a.zzz = M::mul(M::mul(a.zzz, q.zzz), ppp);
+    return true;
+}
+// q = +-acc: doubling or cancellation, decided on R^2.  Cold, out of line, operands BY VALUE: a by-reference
+// parameter would make the caller's accumulators address-taken and pin them in scratch memory for good.
+template <class M = MulInline>
+__device__ __noinline__ P28 p28_add_slow(const P28 a, const P28 q) {
+    Fq28 s1 = M::mul(a.y, q.zzz), s2 = M::mul(q.y, a.zzz);
+    Fq28 d = FQ28_SUB(s2, s1, SPREAD4);
+    Fq28 rr = M::mul(d, d);
+    if (fq28_is_zero_mod_p(rr)) return p28_dbl<M>(a);
+    return p28_identity();
+}
+template <class M = MulInline>
+__device__ __forceinline__ void p28_add(P28& a, const P28& q) {
+    if (!p28_add_fast<M>(a, q)) a = p28_add_slow<M>(a, q);
+}
+
+// 28-bit domain (x 2^392) -> memory format of the rest of the library: Montgomery radix 2^384, canonical
+template <class XYZZ>
+__device__ __forceinline__ void p28_store_384(XYZZ& m, const P28& p) {
+    if (p28_is_identity(p)) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            m.x.v[i] = FqParams::R1[i];
+            m.y.v[i] = FqParams::R1[i];
+            m.zz.v[i] = 0;
+            m.zzz.v[i] = 0;
+        }
+        return;
+    }
+    Fq28 k = fq28_const(Fq28Consts::TO384);
+    m.x = fq28_pack(fq28_canonical(fq28_mul(p.x, k)));
+    m.y = fq28_pack(fq28_canonical(fq28_mul(p.y, k)));
+    m.zz = fq28_pack(fq28_canonical(fq28_mul(p.zz, k)));
+    m.zzz = fq28_pack(fq28_canonical(fq28_mul(p.zzz, k)));
 }
 
 }  // namespace swm

@@ -786,6 +786,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     suffix_recurrence(ctx, w_poly.p, H + 1, X, fr_one());
     const Fr* w_coeffs = w_poly.p + X;  // quotient[j] = s[j + X]
     const size_t w_len = H + 1 - X;
+    LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
+    int lane = 0;
+    CommitJob j1[4];
+    P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
+    pc_commit_begin(ctx, pk, &lane, P_w.p, P_w.n, false, 0, true, &j1[0]);
     Fr rho_a = zk.rand_fr();
     DVec za_poly = dv_zeros(ctx, H + 1);
     {
@@ -793,6 +798,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         hip_check(ctx, hipMemcpyAsync(za_poly.p, za_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
         add_rho_vh(za_poly.p, rho_a);
     }
+    P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
+    pc_commit_begin(ctx, pk, &lane, P_za.p, P_za.n, false, 0, true, &j1[1]);
     Fr rho_b = zk.rand_fr();
     DVec zb_poly = dv_zeros(ctx, H + 1);
     {
@@ -800,6 +807,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         hip_check(ctx, hipMemcpyAsync(zb_poly.p, zb_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
         add_rho_vh(zb_poly.p, rho_b);
     }
+    P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
+    pc_commit_begin(ctx, pk, &lane, P_zb.p, P_zb.n, false, 0, true, &j1[2]);
     // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
     const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
     DVec mask(ctx, mask_len);
@@ -812,24 +821,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
     }
     tr.mark("round 1 polynomials");
-    LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
-    int lane = 0;
     std::vector<Commitment> comms1(4);
-    {
-        CommitJob j[4];
-        P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
-        pc_commit_begin(ctx, pk, &lane, P_w.p, P_w.n, false, 0, true, &j[0]);
-        P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
-        pc_commit_begin(ctx, pk, &lane, P_za.p, P_za.n, false, 0, true, &j[1]);
-        P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
-        pc_commit_begin(ctx, pk, &lane, P_zb.p, P_zb.n, false, 0, true, &j[2]);
-        P_mask.p = mask.p; P_mask.n = mask_len;
-        pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j[3]);
-        comms1[0] = pc_commit_end(ctx, pk, &j[0], &zk, &P_w.rand);
-        comms1[1] = pc_commit_end(ctx, pk, &j[1], &zk, &P_za.rand);
-        comms1[2] = pc_commit_end(ctx, pk, &j[2], &zk, &P_zb.rand);
-        comms1[3] = pc_commit_end(ctx, pk, &j[3], nullptr, &P_mask.rand);
-    }
+    P_mask.p = mask.p; P_mask.n = mask_len;
+    pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
+    comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
+    comms1[2] = pc_commit_end(ctx, pk, &j1[2], &zk, &P_zb.rand);
+    comms1[3] = pc_commit_end(ctx, pk, &j1[3], nullptr, &P_mask.rand);
     tr.mark("round 1 commitments");
     fs_absorb_commitments(fs, comms1);
     VerifierState st;
@@ -865,6 +863,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
         dv_ntt(ctx, t_poly, pk.logH, true);
     }
+    CommitJob j2[3];
+    P_t.p = t_poly.p; P_t.n = H;
+    pc_commit_begin(ctx, pk, &lane, P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
     // evaluation form on the 4|H| domain
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
         DVec e = dv_copy_padded(ctx, coeffs, n, M);
@@ -922,19 +923,16 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     tr.mark("round 2 polynomials");
     std::vector<Commitment> comms2(3);
     {
-        CommitJob j[3];
-        P_t.p = t_poly.p; P_t.n = H;
-        pc_commit_begin(ctx, pk, &lane, P_t.p, P_t.n, false, 0, false, &j[0]);
         P_g1.p = g1x.p + 1; P_g1.n = H - 1; P_g1.has_bound = true; P_g1.bound = H - 2; P_g1.hiding = true;
-        pc_commit_begin(ctx, pk, &lane, P_g1.p, P_g1.n, true, H - 2, true, &j[1]);
         P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
-        pc_commit_begin(ctx, pk, &lane, P_h1.p, P_h1.n, false, 0, false, &j[2]);
+        pc_commit_begin(ctx, pk, &lane, P_h1.p, P_h1.n, false, 0, false, &j2[2]);  // largest first
+        pc_commit_begin(ctx, pk, &lane, P_g1.p, P_g1.n, true, H - 2, true, &j2[1]);
         // the sumcheck remainder check needs a download; do it while the MSMs run
         Fr rem0 = g1x.download(0, 1)[0];
         bool unsat = !fp_is_zero(rem0);
-        comms2[0] = pc_commit_end(ctx, pk, &j[0], nullptr, &P_t.rand);
-        comms2[1] = pc_commit_end(ctx, pk, &j[1], &zk, &P_g1.rand);
-        comms2[2] = pc_commit_end(ctx, pk, &j[2], nullptr, &P_h1.rand);
+        comms2[0] = pc_commit_end(ctx, pk, &j2[0], nullptr, &P_t.rand);
+        comms2[1] = pc_commit_end(ctx, pk, &j2[1], &zk, &P_g1.rand);
+        comms2[2] = pc_commit_end(ctx, pk, &j2[2], nullptr, &P_h1.rand);
         if (unsat) throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
     }
     tr.mark("round 2 commitments");
@@ -965,6 +963,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
         dv_ntt(ctx, f, pk.logK, true);
     }
+    CommitJob j3[2];
+    P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
+    pc_commit_begin(ctx, pk, &lane, P_g2.p, P_g2.n, true, K - 2, false, &j3[0]);  // overlaps the 4|K|-domain work below
     // h_2 = (a - b f) / v_K via evaluations on the 4K domain
     DVec h2(ctx, 3 * K);
     {
@@ -999,15 +1000,10 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     tr.mark("round 3 polynomials");
     std::vector<Commitment> comms3(2);
-    {
-        CommitJob j[2];
-        P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
-        pc_commit_begin(ctx, pk, &lane, P_g2.p, P_g2.n, true, K - 2, false, &j[0]);
-        P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
-        pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j[1]);
-        comms3[0] = pc_commit_end(ctx, pk, &j[0], nullptr, &P_g2.rand);
-        comms3[1] = pc_commit_end(ctx, pk, &j[1], nullptr, &P_h2.rand);
-    }
+    P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
+    pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j3[1]);
+    comms3[0] = pc_commit_end(ctx, pk, &j3[0], nullptr, &P_g2.rand);
+    comms3[1] = pc_commit_end(ctx, pk, &j3[1], nullptr, &P_h2.rand);
     tr.mark("round 3 commitments");
     fs_absorb_commitments(fs, comms3);
     st.gamma = fs.rand_fr();

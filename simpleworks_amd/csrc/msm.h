@@ -22,8 +22,8 @@ struct MsmJob {
     bool active = false;
     size_t n = 0;
     WinLayout pl;
-    unsigned red_blocks = 0;
-    G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks window partials
+    unsigned red_blocks = 0, log_m = 0;
+    G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
     hipEvent_t done = nullptr;
 };
 

@@ -36,7 +36,6 @@ namespace swm {
 // ---------------------------------------------------------------------------------------------- parameters
 static constexpr int SEG = 32;          // points per accumulation segment (upper bound)
 static constexpr int BIG_NSEG = 16;     // buckets with more segments than this are folded by a whole workgroup
-static constexpr int RED_CHUNK = 8;     // buckets per lane in the window reduction
 static constexpr int RED_BLOCK = 256;
 static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
 static constexpr int SORT_THREADS = 1024;
@@ -390,7 +389,7 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
     uint32_t seg = order[t];
     const uint32_t k0 = seg_start[seg], e = k0 + seg_len[seg];
     if (k0 >= e) {
-        partial[seg] = g1_xyzz_identity();
+        p28_store(partial[seg], p28_identity());
         return;
     }
     bool ok = true;
@@ -421,17 +420,13 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
         ok = madd28(acc, x2, y2);
     }
     if (ok) {
-        // back to the memory format: Montgomery radix 2^384, canonical, 32-bit limbs
-        Fq28 to384 = fq28_const(Fq28Consts::TO384);
-        G1XYZZ out;
-        out.x = fq28_pack(fq28_canonical(fq28_mul(acc.x, to384)));
-        out.y = fq28_pack(fq28_canonical(fq28_mul(acc.y, to384)));
-        out.zz = fq28_pack(fq28_canonical(fq28_mul(acc.zz, to384)));
-        out.zzz = fq28_pack(fq28_canonical(fq28_mul(acc.zzz, to384)));
-        partial[seg] = out;
+        // partial sums stay in the 28-bit domain (radix 2^392, "point form" of fq28.cuh) for the bucket stage
+        P28 out{acc.x, acc.y, acc.zz, acc.zzz};
+        p28_store(partial[seg], out);
         return;
     }
-    // cold path: a point met +-(the running sum); redo this segment with the fully reducing adder
+    // cold path: a point met +-(the running sum); redo this segment with the fully reducing adder, then move the
+    // result into the 28-bit domain (coordinates x 2^8)
     G1XYZZ acc32 = g1_xyzz_identity();
     for (uint32_t k = k0; k < e; k++) {
         uint32_t ent = sorted[k];
@@ -439,103 +434,128 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
         if (ent >> 31) p.y = fp_neg(p.y);
         g1_add_mixed(acc32, p);
     }
+    const uint32_t k256[12] = SWM_FQ_SCALE256_MONT;
+    Fq c;
+#pragma unroll
+    for (int j = 0; j < 12; j++) c.v[j] = k256[j];
+    acc32.x = fp_mul(acc32.x, c);
+    acc32.y = fp_mul(acc32.y, c);
+    acc32.zz = fp_mul(acc32.zz, c);   // identity (zz = 0) stays exactly zero
+    acc32.zzz = fp_mul(acc32.zzz, c);
     partial[seg] = acc32;
 }
 
-// kept out of line: these kernels are latency-bound and otherwise inline ~10 copies of the 14-multiplication adder
-__device__ __noinline__ void g1_add_ool(G1XYZZ& acc, const G1XYZZ& q) { g1_add(acc, q); }
+// ---------------------------------------------------------------------------------------------- bucket stage (28-bit domain)
+// Register budget of the bucket stage: a general addition keeps two points (2 x 56 VGPRs) plus ~8 temporaries
+// (112 VGPRs) live; a third live point spills to scratch, i.e. to HBM-backed private memory with nothing to hide the
+// latency at one wave per SIMD (measured: 5x slower).  So each lane parks the point it is not currently adding in LDS
+// (packed 192-B slots) and at most two points are ever in registers.
+__device__ __forceinline__ void p28_add_ool(P28& a, const P28& q) { p28_add<MulFenced>(a, q); }
 
-__global__ void __launch_bounds__(256) msm_bucket_sum(const G1XYZZ* __restrict__ partial,
-                                                      const uint32_t* __restrict__ seg_off, uint32_t NB,
-                                                      G1XYZZ* __restrict__ buckets) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= NB) return;
-    uint32_t s = seg_off[b], e = seg_off[b + 1];
-    if (e - s > BIG_NSEG) return;  // folded by msm_big_bucket_sum
-    G1XYZZ acc = g1_xyzz_identity();
-    if (s < e) acc = partial[s++];
-    for (; s < e; s++) {
-        G1XYZZ q = partial[s];
-        g1_add_ool(acc, q);
-    }
-    buckets[b] = acc;
-}
-
-// One workgroup per big bucket (structured scalars, short top window): strided partial sums + LDS tree.
-__global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(const G1XYZZ* __restrict__ partial,
+// Oversized buckets (> BIG_NSEG segments: structured scalars) are folded first, one workgroup each: strided partial
+// sums + LDS tree; the result replaces the bucket's first partial.
+__global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restrict__ partial,
                                                                 const uint32_t* __restrict__ seg_off,
                                                                 const uint32_t* __restrict__ big_count,
-                                                                const uint32_t* __restrict__ big_list,
-                                                                G1XYZZ* __restrict__ buckets) {
+                                                                const uint32_t* __restrict__ big_list) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
     const uint32_t nbig = *big_count;
     for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
         uint32_t b = big_list[j];
         uint32_t s = seg_off[b], e = seg_off[b + 1];
-        G1XYZZ acc = g1_xyzz_identity();
+        P28 acc = p28_identity();
         for (uint32_t k = s + threadIdx.x; k < e; k += RED_BLOCK) {
-            G1XYZZ q = partial[k];
-            g1_add_ool(acc, q);
+            P28 q = p28_load(partial[k]);
+            p28_add_ool(acc, q);
         }
-        sm[threadIdx.x] = acc;
+        p28_store(sm[threadIdx.x], acc);
         __syncthreads();
         for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
             if (threadIdx.x < stride) {
-                G1XYZZ a = sm[threadIdx.x];
-                G1XYZZ q = sm[threadIdx.x + stride];
-                g1_add_ool(a, q);
-                sm[threadIdx.x] = a;
+                P28 a = p28_load(sm[threadIdx.x]);
+                P28 q = p28_load(sm[threadIdx.x + stride]);
+                p28_add_ool(a, q);
+                p28_store(sm[threadIdx.x], a);
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) buckets[b] = sm[0];
+        if (threadIdx.x == 0) partial[s] = sm[0];
         __syncthreads();
     }
 }
 
-// grid = (ceil(B / RED_CHUNK / RED_BLOCK), nwin).  out[w * gridDim.x + blockIdx.x] = partial of sum_b (b+1) S_b.
-__global__ void __launch_bounds__(RED_BLOCK) msm_window_reduce(const G1XYZZ* __restrict__ buckets, WinLayout L,
-                                                               G1XYZZ* __restrict__ out) {
+// Per window: sum_b (b+1) S_b with S_b = sum of the bucket's partials, fused in one kernel.
+// grid = (nblk, nwin), RED_BLOCK lanes, lane t owns the m = 2^log_m buckets [lo, lo+m), lo = (blk RED_BLOCK + t) m:
+//     acc_t = sum_j (j+1) S_{lo+j},  run_t = sum_j S_{lo+j}                 (running sums, 2m adds)
+//     sum over the workgroup of (lo - lo_blk) run_t = m sum_{t>=1} Suffix_t,  Suffix_t = sum_{u>=t} run_u   (LDS suffix scan)
+//     A_blk = sum_t acc_t + m sum_{t>=1} Suffix_t  (one LDS tree),  R_blk = Suffix_0
+// The host finishes with sum_blk [A_blk + blk (RED_BLOCK m) R_blk] — a handful of additions per window.
+// No scalar multiplication by the bucket offset is needed: the serial chain is ~3m + 20 group operations.
+// LDS: two packed slots per lane (running sum, weighted sum) = 96 KB per workgroup.
+__global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __restrict__ partial,
+                                                               const uint32_t* __restrict__ seg_off, WinLayout L,
+                                                               unsigned log_m, G1XYZZ* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
-    uint32_t w = blockIdx.y;
-    const uint32_t B = 1u << (L.c[w] - 1);
-    uint32_t chunk = blockIdx.x * RED_BLOCK + threadIdx.x;
-    uint32_t lo = chunk * RED_CHUNK;
-    G1XYZZ acc = g1_xyzz_identity();
+    G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
+    G1XYZZ* sm_acc = sm_run + RED_BLOCK;
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
+    const uint32_t lo = (blockIdx.x * RED_BLOCK + t) << log_m;
+    p28_store(sm_run[t], p28_identity());
+    p28_store(sm_acc[t], p28_identity());
     if (lo < B) {
-        const G1XYZZ* base = buckets + L.boff[w];
-        uint32_t hi = min(lo + RED_CHUNK, B);
-        G1XYZZ run = g1_xyzz_identity();
+        const uint32_t base = L.boff[w];
+        uint32_t hi = min(lo + m, B);
         for (uint32_t b = hi; b-- > lo;) {
-            G1XYZZ q = base[b];
-            g1_add_ool(run, q);
-            g1_add_ool(acc, run);
-        }
-        // acc = sum (b - lo + 1) S_b ; add lo * sum S_b  (double-and-add on the chunk offset)
-        if (lo && !g1_is_inf(run)) {
-            G1XYZZ t = g1_xyzz_identity();
-            int top = 31 - __clz(lo);
-            for (int i = top; i >= 0; i--) {
-                t = g1_dbl(t);
-                if ((lo >> i) & 1) g1_add_ool(t, run);
+            uint32_t s = seg_off[base + b], e = seg_off[base + b + 1];
+            if (e - s > BIG_NSEG) e = s + 1;  // already folded into the first partial
+            P28 run = p28_load(sm_run[t]);
+            for (; s < e; s++) {
+                P28 q = p28_load(partial[s]);
+                p28_add_ool(run, q);
             }
-            g1_add_ool(acc, t);
+            p28_store(sm_run[t], run);
+            P28 acc = p28_load(sm_acc[t]);
+            p28_add_ool(acc, run);
+            p28_store(sm_acc[t], acc);
         }
     }
-    sm[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
-        if (threadIdx.x < stride) {
-            G1XYZZ a = sm[threadIdx.x];
-            G1XYZZ q = sm[threadIdx.x + stride];
-            g1_add_ool(a, q);
-            sm[threadIdx.x] = a;
+    // inclusive suffix scan of run over the workgroup (Hillis-Steele)
+    for (uint32_t d = 1; d < RED_BLOCK; d <<= 1) {
+        bool has = t + d < RED_BLOCK;
+        P28 v = p28_load(sm_run[t]);
+        P28 o = has ? p28_load(sm_run[t + d]) : p28_identity();
+        __syncthreads();
+        if (has) {
+            p28_add_ool(v, o);
+            p28_store(sm_run[t], v);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)w * gridDim.x + blockIdx.x] = sm[0];
+    {
+        P28 next = t + 1 < RED_BLOCK ? p28_load(sm_run[t + 1]) : p28_identity();  // Suffix_{t+1}
+        for (unsigned i = 0; i < log_m; i++) next = p28_dbl<MulFenced>(next);
+        P28 acc = p28_load(sm_acc[t]);
+        p28_add_ool(acc, next);  // acc_t + m Suffix_{t+1}; summed over t this is A_blk
+        p28_store(sm_acc[t], acc);
+    }
+    __syncthreads();
+    for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
+        if (t < stride) {
+            P28 a = p28_load(sm_acc[t]);
+            P28 q = p28_load(sm_acc[t + stride]);
+            p28_add_ool(a, q);
+            p28_store(sm_acc[t], a);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        size_t o = ((size_t)w * gridDim.x + blockIdx.x) * 2;
+        p28_store_384(out[o], p28_load(sm_acc[0]));
+        p28_store_384(out[o + 1], p28_load(sm_run[0]));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host driver
@@ -582,7 +602,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
-    unsigned red_blocks = (pl.maxB + RED_CHUNK * RED_BLOCK - 1) / (RED_CHUNK * RED_BLOCK);
+    // buckets per lane in the reduction: at most 8 workgroups per window (the host folds one (A, R) pair per workgroup)
+    unsigned log_m = 2;
+    if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
+    while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > 16) log_m++;  // 16 (A, R) pairs per window fit a result slot
+    unsigned red_blocks = ((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK;
+    if (red_blocks == 0) red_blocks = 1;
     // ---- lane set-up: stream, pinned result slot, event
     hipStream_t main_stream = ctx->stream;
     hipStream_t st = main_stream;
@@ -595,7 +620,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_HIP(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
     }
     const size_t slot_bytes = (size_t)MAX_WIN * 16 * sizeof(G1XYZZ);
-    if ((size_t)pl.nwin * red_blocks * sizeof(G1XYZZ) > slot_bytes) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
+    if ((size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > slot_bytes) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
     if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
     int slot = ctx->next_slot;
     ctx->next_slot = (ctx->next_slot + 1) % swm_ctx::MSM_SLOTS;
@@ -604,6 +629,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->done = ctx->slot_event[slot];
     job->pl = pl;
     job->red_blocks = red_blocks;
+    job->log_m = log_m;
 
     // everything below is enqueued on `st`: temporarily make it the context's stream so that launches, memsets,
     // scratch growth and the profiling events all refer to it
@@ -636,11 +662,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_TRY(scratch(ctx, nm[6], (size_t)(scan_tiles + 1) * 8, (void**)&tot_cnt));
     tot_seg = tot_cnt + scan_tiles + 1;
     SWM_TRY(scratch(ctx, nm[7], (size_t)pl.NB * 4, (void**)&big_list));
-    // XYZZ scratch: partial[nseg_max] | buckets[NB] | wpart[nwin * red_blocks]
-    G1XYZZ *partial, *buckets, *wpart;
-    SWM_TRY(scratch(ctx, nm[8], (nseg_max + pl.NB + (size_t)pl.nwin * red_blocks) * sizeof(G1XYZZ), (void**)&partial));
-    buckets = partial + nseg_max;
-    wpart = buckets + pl.NB;
+    // XYZZ scratch: partial[nseg_max] | wpart[nwin * red_blocks * 2]
+    G1XYZZ *partial, *wpart;
+    SWM_TRY(scratch(ctx, nm[8], (nseg_max + (size_t)pl.nwin * red_blocks * 2) * sizeof(G1XYZZ), (void**)&partial));
+    wpart = partial + nseg_max;
 
     SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
@@ -666,12 +691,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                order);
     SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
                d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
-    SWM_LAUNCH(ctx, "msm_bucket_sum", msm_bucket_sum, dim3(grid_b), dim3(256), 0, partial, seg_off, pl.NB, buckets);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
-               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, buckets);
-    SWM_LAUNCH(ctx, "msm_window_reduce", msm_window_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
-               RED_BLOCK * sizeof(G1XYZZ), buckets, pl, wpart);
-    SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
+               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
+    SWM_TRY(allow_big_lds(ctx, (const void*)msm_bucket_reduce, 2 * RED_BLOCK * sizeof(G1XYZZ)));
+    SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
+               2 * RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
+    SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
                                 ctx->stream));
     SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
     job->active = true;
@@ -683,14 +708,27 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     if (!job->active) return SWM_OK;
     SWM_HIP(ctx, hipEventSynchronize(job->done));
     job->active = false;
-    // host: fold workgroup partials, then Horner over windows (high -> low, c doublings each)
+    // host: per window sum_blk [A_blk + blk * (RED_BLOCK * m) * R_blk] (suffix sums over the <= 8 workgroups), then Horner
+    // over windows (high -> low, c doublings each)
     const WinLayout& pl = job->pl;
+    const unsigned nb = job->red_blocks;
+    unsigned shift = job->log_m;
+    for (unsigned v = RED_BLOCK; v > 1; v >>= 1) shift++;
     G1XYZZ total_pt = g1_xyzz_identity();
     for (unsigned w = pl.nwin; w-- > 0;) {
         for (unsigned k = 0; k < pl.c[w]; k++) total_pt = g1_dbl(total_pt);
-        G1XYZZ ws = g1_xyzz_identity();
-        for (unsigned j = 0; j < job->red_blocks; j++) g1_add(ws, job->host[(size_t)w * job->red_blocks + j]);
-        g1_add(total_pt, ws);
+        const G1XYZZ* h = job->host + (size_t)w * nb * 2;
+        G1XYZZ sum_a = g1_xyzz_identity(), suffix = g1_xyzz_identity(), weighted = g1_xyzz_identity();
+        for (unsigned blk = nb; blk-- > 0;) {
+            g1_add(sum_a, h[2 * blk]);
+            if (blk >= 1) {
+                g1_add(suffix, h[2 * blk + 1]);  // Suffix_blk = sum_{u >= blk} R_u
+                g1_add(weighted, suffix);        // sum_{blk >= 1} Suffix_blk = sum_blk blk R_blk
+            }
+        }
+        for (unsigned k = 0; k < shift; k++) weighted = g1_dbl(weighted);
+        g1_add(sum_a, weighted);
+        g1_add(total_pt, sum_a);
     }
     *result = total_pt;
     return SWM_OK;
