@@ -43,13 +43,12 @@ static constexpr int SORT_THREADS = 1024;
 WinLayout msm_plan(size_t n) {
     // Target window size for the GPU schedule (NOT arkworks' ln-based rule): large enough that the n*W accumulate
     // adds dominate the fixed-latency bucket reduction, small enough that buckets stay populated.
+    // measured on MI355X (sweep over c = 8..16, r01): 2^10 -> 10, 2^12..2^16 -> 12, 2^18 -> 14, >= 2^19 -> 16.
+    // c is capped at 16 by the LDS histogram of the counting sort (2^(c-1) words).
     unsigned c;
-    if (n <= (1u << 8)) c = 6;
-    else if (n <= (1u << 11)) c = 8;
-    else if (n <= (1u << 14)) c = 10;
-    else if (n <= (1u << 16)) c = 12;
-    else if (n <= (1u << 18)) c = 13;
-    else if (n <= (1u << 20)) c = 15;
+    if (n <= (1u << 11)) c = 10;
+    else if (n <= 98304) c = 12;
+    else if (n <= 393216) c = 14;
     else c = 16;
     if (const char* e = getenv("SWM_MSM_C")) {
         int v = atoi(e);
