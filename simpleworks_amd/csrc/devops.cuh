@@ -212,18 +212,59 @@ inline DivResult div_linear(swm_ctx* ctx, const Fr* p, size_t n, const Fr& x) {
 }
 
 // ------------------------------------------------------------------------------------------------ Horner evaluation
-static constexpr int EVAL_CHUNK = 64;
-static __global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x, Fr* __restrict__ out,
-                                                   size_t nchunks) {
-    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    size_t lo = t * EVAL_CHUNK, hi = lo + EVAL_CHUNK < n ? lo + EVAL_CHUNK : n;
+// One workgroup evaluates a contiguous tile of EVAL_TILE = 256 * EVAL_PER coefficients: lane t runs Horner in
+// y = x^256 over the coefficients t, t + 256, t + 512, ... of the tile (adjacent lanes read adjacent 32-B elements:
+// coalesced), multiplies by x^t, and the workgroup sums its 256 values in LDS.  out[tile] = sum_i c[tile*T + i] x^i,
+// so the next level evaluates `out` at x^T.
+static constexpr int EVAL_PER = 16;
+static constexpr int EVAL_TILE = 256 * EVAL_PER;
+static __global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x256, const Fr* __restrict__ xpow,
+                                                          Fr* __restrict__ out) {
+    __shared__ Fr sm[256];
+    const size_t base = (size_t)blockIdx.x * EVAL_TILE;
+    const unsigned t = threadIdx.x;
     Fr acc = fp_zero<Fr>();
-    for (size_t k = hi; k-- > lo;) acc = fp_add(fp_mul(acc, x), c[k]);
-    out[t] = acc;
+#pragma unroll 1
+    for (int j = EVAL_PER - 1; j >= 0; j--) {
+        size_t k = base + (size_t)j * 256 + t;
+        acc = fp_mul(acc, x256);
+        if (k < n) acc = fp_add(acc, c[k]);
+    }
+    sm[t] = fp_mul(acc, xpow[t]);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fp_add(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) out[blockIdx.x] = sm[0];
+}
+// Evaluation point prepared once: per level l (tile T = 4096), the table y_l^0 .. y_l^255 and y_l^256, y_0 = x,
+// y_{l+1} = y_l^T.  Three levels cover 2^36 coefficients.
+struct EvalPoint {
+    DVec pw[3];
+    Fr y256[3];
+};
+inline EvalPoint eval_point(swm_ctx* ctx, Fr x) {
+    EvalPoint ep;
+    std::vector<Fr> host(3 * 256);
+    for (int l = 0; l < 3; l++) {
+        Fr* pw = host.data() + 256 * l;
+        pw[0] = fp_one<Fr>();
+        for (int i = 1; i < 256; i++) pw[i] = fp_mul(pw[i - 1], x);
+        ep.y256[l] = fp_mul(pw[255], x);
+        x = ep.y256[l];
+        for (int i = 0; i < 4; i++) x = fp_sqr(x);  // y^(256 * 16)
+        static_assert(EVAL_PER == 16, "x exponent");
+    }
+    for (int l = 0; l < 3; l++) {
+        ep.pw[l] = DVec(ctx, 256);
+        hip_check(ctx, hipMemcpyAsync(ep.pw[l].p, host.data() + 256 * l, 256 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
+    }
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");  // `host` goes out of scope
+    return ep;
 }
 // p(x) for a device polynomial, written to the device word *d_result (no host synchronisation)
-inline void poly_eval_async(swm_ctx* ctx, const Fr* p, size_t n, Fr x, Fr* d_result) {
+inline void poly_eval_async(swm_ctx* ctx, const Fr* p, size_t n, const EvalPoint& ep, Fr* d_result) {
     if (n == 0) {
         hip_check(ctx, hipMemsetAsync(d_result, 0, sizeof(Fr), ctx->stream), "memset");
         return;
@@ -231,31 +272,31 @@ inline void poly_eval_async(swm_ctx* ctx, const Fr* p, size_t n, Fr x, Fr* d_res
     DVec cur;
     const Fr* src = p;
     size_t len = n;
-    for (;;) {
-        size_t nchunks = (len + EVAL_CHUNK - 1) / EVAL_CHUNK;
+    for (int level = 0;; level++) {
+        if (level >= 3) throw MarlinError(SWM_ERR_INTERNAL, "poly_eval: polynomial too long");
+        size_t ntiles = (len + EVAL_TILE - 1) / EVAL_TILE;
         DVec next;
         Fr* dst = d_result;
-        if (nchunks > 1) {
-            next = DVec(ctx, nchunks);
+        if (ntiles > 1) {
+            next = DVec(ctx, ntiles);
             dst = next.p;
         }
         prof_begin(ctx, "poly_eval");
-        hipLaunchKernelGGL(eval_chunks, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream, src, len, x, dst,
-                           nchunks);
+        hipLaunchKernelGGL(eval_chunks, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, src, len, ep.y256[level],
+                           ep.pw[level].p, dst);
         prof_end(ctx);
         hip_check(ctx, hipGetLastError(), "poly_eval");
-        if (nchunks == 1) break;
-        for (int i = 0; i < 6; i++) x = fp_sqr(x);  // x^64
-        static_assert(EVAL_CHUNK == 64, "x exponent");
+        if (ntiles == 1) break;
         cur = std::move(next);
         src = cur.p;
-        len = nchunks;
+        len = ntiles;
     }
 }
 // returns p(x) on the host (synchronises)
 inline Fr poly_eval(swm_ctx* ctx, const Fr* p, size_t n, Fr x) {
+    EvalPoint ep = eval_point(ctx, x);
     DVec r(ctx, 1);
-    poly_eval_async(ctx, p, n, x, r.p);
+    poly_eval_async(ctx, p, n, ep, r.p);
     return r.download(0, 1)[0];
 }
 

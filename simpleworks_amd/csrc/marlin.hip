@@ -1031,9 +1031,10 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         want.push_back({"g_2", true});
         want.push_back({"h_2", true});
         DVec slots(ctx, want.size());
+        EvalPoint ep_beta = eval_point(ctx, beta), ep_gamma = eval_point(ctx, gamma);
         for (size_t i = 0; i < want.size(); i++) {
             LPoly* lp = polys.at(want[i].first);
-            poly_eval_async(ctx, lp->p, lp->n, want[i].second ? gamma : beta, slots.p + i);
+            poly_eval_async(ctx, lp->p, lp->n, want[i].second ? ep_gamma : ep_beta, slots.p + i);
         }
         std::vector<Fr> vals = slots.download(0, want.size());
         for (size_t i = 0; i < want.size(); i++) eval_cache[want[i]] = vals[i];
@@ -1078,6 +1079,12 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         LPoly* lp;
         Fr ch;
     };
+    static constexpr int MAX_COMBINE = 24;
+    struct CombineTerms {
+        const Fr* src[MAX_COMBINE];
+        size_t len[MAX_COMBINE];
+        Fr k[MAX_COMBINE];
+    };
     struct PointOpen {
         Fr point;
         DVec comb;
@@ -1103,7 +1110,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         for (auto& l : labels)
             for (auto& t : lcs.at(l))
                 if (!t.second.empty()) plen = std::max(plen, polys.at(t.second)->n);
-        o.comb = dv_zeros(ctx, plen);
+        o.comb = DVec(ctx, plen ? plen : 1);
+        CombineTerms cterms;
+        int nterms = 0;
         Fr ch = fr_one();
         for (auto& l : labels) {
             const LcTerms& terms = lcs.at(l);
@@ -1114,9 +1123,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
                 if (terms.size() == 1 && lp->has_bound) single_bounded = true;
                 else if (lp->has_bound) throw MarlinError(SWM_ERR_INTERNAL, "EquationHasDegreeBounds");
                 Fr k = fp_mul(ch, t.first);
-                Fr* out = o.comb.p;
-                const Fr* src = lp->p;
-                ew(ctx, "open_combine", lp->n, [=] __device__(size_t i) { out[i] = fp_add(out[i], fp_mul(k, src[i])); });
+                if (nterms >= MAX_COMBINE) throw MarlinError(SWM_ERR_INTERNAL, "too many terms in an opening");
+                cterms.src[nterms] = lp->p;
+                cterms.len[nterms] = lp->n;
+                cterms.k[nterms] = k;
+                nterms++;
                 hp_add_scaled(o.r_comb, lp->rand.rand, k);
             }
             ch = fp_mul(ch, xi);
@@ -1127,6 +1138,16 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
                 if (!hp_is_zero(lp->rand.shifted_rand)) hp_add_scaled(o.shifted_r_witness, hp_div_linear(lp->rand.shifted_rand, point), ch);
                 ch = fp_mul(ch, xi);
             }
+        }
+        {   // comb[i] = sum_j k_j * src_j[i]: every polynomial is read once, the combination written once
+            Fr* out = o.comb.p;
+            const int nt = nterms;
+            ew(ctx, "open_combine", plen, [=] __device__(size_t i) {
+                Fr acc = fp_zero<Fr>();
+                for (int j = 0; j < nt; j++)
+                    if (i < cterms.len[j]) acc = fp_add(acc, fp_mul(cterms.k[j], cterms.src[j][i]));
+                out[i] = acc;
+            });
         }
         // witness = p / (X - point) against the powers; degree-bounded members: shifted witnesses against the shifted powers
         o.wq = div_linear(ctx, o.comb.p, plen, point);

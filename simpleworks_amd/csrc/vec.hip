@@ -94,6 +94,32 @@ __global__ void __launch_bounds__(256) selftest_mul28_chain(Fq* out, int iters) 
     }
     out[i] = fq28_pack(fq28_canonical(fq28_mul(a, b)));
 }
+// throughput probe of the general 28-bit XYZZ addition: one call site in a loop (which = 3) or four unrolled call
+// sites (which = 4) — same arithmetic, different code footprint
+template <int SITES>
+__global__ void __launch_bounds__(256) selftest_p28_add_chain(Fq* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    P28 a, b;
+    a.x = fq28_const(Fq28Consts::ONE);
+    a.x.l[0] ^= (uint32_t)i & 0xffff;
+    a.y = fq28_const(Fq28Consts::TO384);
+    a.zz = fq28_const(Fq28Consts::ONE);
+    a.zzz = a.zz;
+    b = a;
+    b.x.l[1] ^= 0x1234;
+    b.y.l[2] ^= (uint32_t)(i * 2654435761u) & 0xfff;
+    for (int k = 0; k < iters; k++) {
+        if (SITES == 1) {
+            p28_add_fast<MulInline>(a, b);
+        } else {
+            p28_add_fast<MulInline>(a, b);
+            p28_add_fast<MulInline>(b, a);
+            p28_add_fast<MulInline>(a, b);
+            p28_add_fast<MulInline>(b, a);
+        }
+    }
+    out[i] = fq28_pack(fq28_canonical(fq28_mul(a.x, b.y)));
+}
 __global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a, const G1Affine* b, G1Jac* out,
                                                               size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -122,7 +148,11 @@ int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void
 }
 int selftest_chain_run(swm_ctx* ctx, int which, void* out, size_t threads, int iters) {
     unsigned grid = (unsigned)(threads / 256);
-    if (which == 2)
+    if (which == 3)
+        SWM_LAUNCH(ctx, "selftest_p28_1site", selftest_p28_add_chain<1>, dim3(grid), dim3(256), 0, (Fq*)out, iters);
+    else if (which == 4)
+        SWM_LAUNCH(ctx, "selftest_p28_4site", selftest_p28_add_chain<4>, dim3(grid), dim3(256), 0, (Fq*)out, iters / 4);
+    else if (which == 2)
         SWM_LAUNCH(ctx, "selftest_chain28", selftest_mul28_chain, dim3(grid), dim3(256), 0, (Fq*)out, iters);
     else if (which == 0)
         SWM_LAUNCH(ctx, "selftest_chain_fq", selftest_mul_chain<Fq>, dim3(grid), dim3(256), 0, (Fq*)out, iters);
