@@ -168,7 +168,7 @@ void swm_destroy(swm_ctx* ctx) {
     for (auto& kv : ctx->ntt_small) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < swm_ctx::MSM_LANES; i++)
         if (ctx->aux_stream[i]) {
             (void)hipStreamSynchronize(ctx->aux_stream[i]);
             (void)hipStreamDestroy(ctx->aux_stream[i]);

@@ -46,7 +46,8 @@ struct swm_ctx {
     std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
     // asynchronous MSM lanes: two auxiliary streams, a fork event, pinned result slots with their completion events
     static constexpr int MSM_SLOTS = 8;
-    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    static constexpr int MSM_LANES = 4;
+    hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};

@@ -126,7 +126,7 @@ inline void dv_ntt(swm_ctx* ctx, DVec& v, unsigned log_n, bool inverse, bool cos
 // In place: a[k] <- a[k] + z * a[k + m] (k descending), i.e. a[k] = sum_{i >= 0} z^i a_old[k + i m].
 // m = 1, z = point: synthetic division (quotient of p / (X - z) = a[1..], p(z) = a[0]).
 // z = 1, stride m:  quotient of p / (X^m - 1) = a[m..]  (DensePolynomial::divide_by_vanishing_poly).
-static constexpr int REC_T = 64;  // rows per lane
+static constexpr int REC_T = 16;  // rows per lane: short chains, many lanes (the kernels are latency-bound)
 
 static __global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z, Fr* head, size_t nblk) {
     // lane = (block of REC_T rows, column); rows = ceil(n / m)
@@ -190,8 +190,8 @@ inline void suffix_recurrence(swm_ctx* ctx, Fr* a, size_t n, size_t m, const Fr&
     hip_check(ctx, hipGetLastError(), "rec_local");
     // heads obey the same recurrence with multiplier z^REC_T
     Fr zt = z;
-    for (int i = 0; i < 6; i++) zt = fp_sqr(zt);  // REC_T = 64
-    static_assert(REC_T == 64, "zt exponent");
+    for (int i = 0; i < 4; i++) zt = fp_sqr(zt);  // z^REC_T
+    static_assert(REC_T == 16, "zt exponent");
     suffix_recurrence(ctx, head.p, nblk * m, m, zt);
     prof_begin(ctx, "rec_fix");
     hipLaunchKernelGGL(rec_fix, dim3(grid), dim3(256), 0, ctx->stream, a, n, m, z, head.p, nblk);

@@ -329,7 +329,8 @@ struct AsyncMsm {
 };
 void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
     if (n && offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ & 1, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &out->job));
+    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &out->job));
 }
 G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
     G1XYZZ r;

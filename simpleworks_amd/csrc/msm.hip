@@ -611,7 +611,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     hipStream_t main_stream = ctx->stream;
     hipStream_t st = main_stream;
     if (lane >= 0) {
-        lane &= 1;
+        lane %= swm_ctx::MSM_LANES;
         if (!ctx->aux_stream[lane]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[lane], hipStreamNonBlocking));
         st = ctx->aux_stream[lane];
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
