@@ -357,11 +357,11 @@ __device__ __forceinline__ bool madd28(Acc28& a, const Fq28& x2, const Fq28& y2)
     Fq28 s2 = fq28_mul(y2, a.zzz);
     Fq28 p = FQ28_SUB(u2, a.x, SPREAD32);
     Fq28 r = FQ28_SUB(s2, a.y, SPREAD8);
-    Fq28 pp = fq28_sqr(p);
+    Fq28 pp = fq28_mul(p, p);
     if (fq28_is_zero_mod_p(pp)) return false;
     Fq28 ppp = fq28_mul(p, pp);
     Fq28 q = fq28_mul(a.x, pp);
-    Fq28 rr = fq28_sqr(r);
+    Fq28 rr = fq28_mul(r, r);
     Fq28 x3;
 #pragma unroll
     for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - q.l[i] - q.l[i];

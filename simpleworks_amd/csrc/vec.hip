@@ -83,6 +83,11 @@ __global__ void __launch_bounds__(256) selftest_mul28_kernel(const Fq* a, const 
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(a[i]), fq28_unpack(b[i]))));
 }
+// dedicated squarer on a lazy operand: out = canonical((a + b)^2 * 2^-392) with a + b formed limb-wise (no carry)
+__global__ void __launch_bounds__(256) selftest_sqr28_kernel(const Fq* a, const Fq* b, Fq* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fq28_pack(fq28_canonical(fq28_sqr(fq28_add(fq28_unpack(a[i]), fq28_unpack(b[i])))));
+}
 __global__ void __launch_bounds__(256) selftest_mul28_chain(Fq* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     Fq28 a = fq28_const(Fq28Consts::ONE), b = fq28_const(Fq28Consts::TO384);
@@ -135,7 +140,10 @@ __global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a,
 
 int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n) {
     unsigned grid = (unsigned)((n + 255) / 256);
-    if (which == 2)
+    if (which == 5)
+        SWM_LAUNCH(ctx, "selftest_sqr28", selftest_sqr28_kernel, dim3(grid), dim3(256), 0, (const Fq*)a, (const Fq*)b,
+                   (Fq*)out, n);
+    else if (which == 2)
         SWM_LAUNCH(ctx, "selftest_mul28", selftest_mul28_kernel, dim3(grid), dim3(256), 0, (const Fq*)a, (const Fq*)b,
                    (Fq*)out, n);
     else if (which == 0)

@@ -24,3 +24,8 @@ for which, name in ((0, "Fq 32-bit Comba"), (2, "Fq 28-bit lazy")):
     for threads in (256*256*4, 256*256*16):
         ms = ctx.selftest_mul_throughput(which, threads, 2000)
         print(name, threads, round(ms,2), "ms", round(threads*2000*2/ms/1e6,1), "Gmul/s")
+# squarer on lazy operands (a + b limb-wise, each < 2^377 so limbs stay < 2^29)
+A2 = [random.randrange(1 << 377) for _ in range(5000)]; B2 = [random.randrange(1 << 377) for _ in range(5000)]
+out = ints(ctx.selftest_mul(5, limbs(A2), limbs(B2)))
+bad = sum(1 for a,b,o in zip(A2,B2,out) if o != (a+b)*(a+b)*inv % Q)
+print("sqr28 mismatches:", bad, "of", len(A2))
