@@ -148,6 +148,36 @@ def test_msm_linearity_2_20(ctx, orc):
     bh.free()
 
 
+def test_msm_empty_and_single(ctx, orc):
+    g = golden("msm.json")
+    srs = [_pt(p) for p in g["srs_bases"]][:8]
+    bh = ctx.srs_upload(orc.points_to_mont(srs))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, np.zeros((0, 4), dtype=np.uint64))) is None  # n = 0 -> identity
+    one = np.zeros((1, 4), dtype=np.uint64)
+    one[0, 0] = 1
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, one, offset=5)) == srs[5]
+    import simpleworks_amd as swm
+    with pytest.raises(swm.SwmError):  # more scalars than bases behind the offset
+        ctx.msm_g1(bh, np.zeros((4, 4), dtype=np.uint64), offset=6)
+    bh.free()
+
+
+def test_msm_pathological_buckets(ctx, orc):
+    """All scalars equal / all ones at 2^16: one bucket per window holds every point (oversized-bucket path)."""
+    from pyref.prng import fr_array
+    n = 1 << 16
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    for val in (1, 0x123456789ABCDEF0123456789ABCDEF):
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        sc[:, 0] = val & 0xFFFFFFFFFFFFFFFF
+        sc[:, 1] = val >> 64
+        ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref, hex(val)
+    bh.free()
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def test_ntt_golden(ctx, orc):
     g = golden("ntt.json")

@@ -77,7 +77,7 @@ def test_unsatisfied_witness_fails_at_prove_time(M, W):
     small.free()
 
 
-@pytest.mark.parametrize("log_n", [10, 14, 16])
+@pytest.mark.parametrize("log_n", [10, 14, 16, 20])
 def test_prove_verify_roundtrip(M, S, W, log_n):
     n = 1 << log_n
     rng = M.generate_rand()
