@@ -171,8 +171,129 @@ static __global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
         a[k] = acc;
     }
 }
+// ---- tiled form for the contiguous case (m = 1): three coalesced passes
+//   1. rec_tile_total   T_b = sum_i a[2048 b + i] z^i                      (read n)
+//   2. recursion        S_b = sum_{c >= b} T_c (z^2048)^(c - b) = true value at the first element of tile b
+//   3. rec_tile_scan    full in-tile scan with carry-in S_{b+1}            (read n, write n)
+// Lanes own 8 consecutive elements; tiles travel through a padded LDS image so that global traffic stays coalesced.
+static constexpr int RT_PER = 8;
+static constexpr int RT_TILE = 256 * RT_PER;
+struct RecConsts {
+    Fr zpow[RT_PER + 1];  // z^0 .. z^8
+    Fr zstep[9];          // (z^8)^(2^k), k = 0..8
+    Fr z256;              // z^256 (pass 1 Horner step)
+};
+static __global__ void __launch_bounds__(256) rec_tile_total(const Fr* __restrict__ a, size_t n, RecConsts rc,
+                                                             const Fr* __restrict__ zlow /* z^0..z^255 */,
+                                                             Fr* __restrict__ totals) {
+    __shared__ Fr sm[256];
+    const size_t base = (size_t)blockIdx.x * RT_TILE;
+    const unsigned t = threadIdx.x;
+    Fr acc = fp_zero<Fr>();
+#pragma unroll 1
+    for (int j = RT_PER - 1; j >= 0; j--) {
+        size_t k = base + (size_t)j * 256 + t;
+        acc = fp_mul(acc, rc.z256);
+        if (k < n) acc = fp_add(acc, a[k]);
+    }
+    sm[t] = fp_mul(acc, zlow[t]);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fp_add(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) totals[blockIdx.x] = sm[0];
+}
+__device__ __forceinline__ unsigned rt_pad(unsigned i) { return i + i / RT_PER; }  // one 32-B pad slot per lane chunk
+static __global__ void __launch_bounds__(256) rec_tile_scan(Fr* __restrict__ a, size_t n, RecConsts rc,
+                                                            const Fr* __restrict__ tile_true /* S_b */, size_t ntiles) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Fr* tile = reinterpret_cast<Fr*>(smem_raw);      // RT_TILE + 256 padded slots
+    Fr* hs = tile + RT_TILE + 256;                   // 257 heads
+    const size_t b = blockIdx.x, base = b * RT_TILE;
+    const unsigned t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < RT_PER; j++) {
+        unsigned e = j * 256 + t;
+        size_t k = base + e;
+        tile[rt_pad(e)] = k < n ? a[k] : fp_zero<Fr>();
+    }
+    __syncthreads();
+    // local scan of this lane's 8 consecutive elements (carry-in 0)
+    Fr loc[RT_PER];
+    Fr acc = fp_zero<Fr>();
+#pragma unroll
+    for (int i = RT_PER - 1; i >= 0; i--) {
+        acc = fp_add(tile[rt_pad(t * RT_PER + i)], fp_mul(acc, rc.zpow[1]));
+        loc[i] = acc;
+    }
+    hs[t] = acc;
+    if (t == 0) hs[256] = b + 1 < ntiles ? tile_true[b + 1] : fp_zero<Fr>();  // carry into the tile
+    __syncthreads();
+    // inclusive suffix scan of the heads with multiplier z^8 per lane step (Hillis-Steele, 257 entries)
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        unsigned d = 1u << k;
+        Fr v = hs[t];
+        bool has = t + d <= 256;
+        Fr o = has ? hs[t + d] : fp_zero<Fr>();
+        __syncthreads();
+        if (has) hs[t] = fp_add(v, fp_mul(rc.zstep[k], o));
+        __syncthreads();
+    }
+    Fr carry = hs[t + 1];  // true value at the first element of the next lane's chunk
+#pragma unroll
+    for (int i = 0; i < RT_PER; i++) tile[rt_pad(t * RT_PER + i)] = fp_add(loc[i], fp_mul(rc.zpow[RT_PER - i], carry));
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RT_PER; j++) {
+        unsigned e = j * 256 + t;
+        size_t k = base + e;
+        if (k < n) a[k] = tile[rt_pad(e)];
+    }
+}
+
+inline void suffix_recurrence(swm_ctx* ctx, Fr* a, size_t n, size_t m, const Fr& z);
+inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) {
+    size_t ntiles = (n + RT_TILE - 1) / RT_TILE;
+    RecConsts rc;
+    rc.zpow[0] = fp_one<Fr>();
+    for (int i = 1; i <= RT_PER; i++) rc.zpow[i] = fp_mul(rc.zpow[i - 1], z);
+    rc.zstep[0] = rc.zpow[RT_PER];
+    for (int k = 1; k < 9; k++) rc.zstep[k] = fp_sqr(rc.zstep[k - 1]);
+    std::vector<Fr> low(256);
+    low[0] = fp_one<Fr>();
+    for (int i = 1; i < 256; i++) low[i] = fp_mul(low[i - 1], z);
+    rc.z256 = fp_mul(low[255], z);
+    DVec zlow(ctx, 256), totals(ctx, ntiles);
+    zlow.upload(low.data(), 256);
+    prof_begin(ctx, "rec_tile_total");
+    hipLaunchKernelGGL(rec_tile_total, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc, (const Fr*)zlow.p,
+                       totals.p);
+    prof_end(ctx);
+    hip_check(ctx, hipGetLastError(), "rec_tile_total");
+    Fr ztile = rc.z256;
+    for (int i = 0; i < 3; i++) ztile = fp_sqr(ztile);  // z^2048
+    static_assert(RT_TILE == 2048, "tile exponent");
+    suffix_recurrence(ctx, totals.p, ntiles, 1, ztile);  // totals[b] <- true value at the first element of tile b
+    size_t lds = (size_t)(RT_TILE + 256 + 257) * sizeof(Fr);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
+        attr_set = true;
+    }
+    prof_begin(ctx, "rec_tile_scan");
+    hipLaunchKernelGGL(rec_tile_scan, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc, (const Fr*)totals.p, ntiles);
+    prof_end(ctx);
+    hip_check(ctx, hipGetLastError(), "rec_tile_scan");
+}
+
 inline void suffix_recurrence(swm_ctx* ctx, Fr* a, size_t n, size_t m, const Fr& z) {
     if (n == 0) return;
+    if (m == 1 && n >= 4 * (size_t)RT_TILE) {
+        suffix_recurrence_tiled(ctx, a, n, z);
+        return;
+    }
     size_t rows = (n + m - 1) / m;
     if (rows <= REC_T) {
         prof_begin(ctx, "rec_serial");
