@@ -34,7 +34,10 @@
 namespace swm {
 
 // ---------------------------------------------------------------------------------------------- parameters
-static constexpr int SEG = 32;          // points per accumulation segment (upper bound)
+#ifndef SWM_SEG
+#define SWM_SEG 128
+#endif
+static constexpr int SEG = SWM_SEG;     // points per accumulation segment (upper bound)
 static constexpr int BIG_NSEG = 16;     // buckets with more segments than this are folded by a whole workgroup
 static constexpr int RED_BLOCK = 256;
 static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
@@ -491,69 +494,109 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
 //     A_blk = sum_t acc_t + m sum_{t>=1} Suffix_t  (one LDS tree),  R_blk = Suffix_0
 // The host finishes with sum_blk [A_blk + blk (RED_BLOCK m) R_blk] — a handful of additions per window.
 // No scalar multiplication by the bucket offset is needed: the serial chain is ~3m + 20 group operations.
-// LDS: two packed slots per lane (running sum, weighted sum) = 96 KB per workgroup.
+//
+// Code layout matters as much as the arithmetic here.  A general addition is ~6 k instructions (48 KB); with one
+// inlined copy per use (running sums, scan, tree: five sites) the kernel was 480 KB of straight-line code executed
+// once per step at one wave per SIMD, i.e. every instruction came from L2 through a 64 KB instruction cache shared by
+// two CUs (measured ~32 us per addition).  So every step of every phase is expressed as the same micro-operation
+//     slot[dst] <- slot[dst] + *src          (dst: an LDS slot; src: an LDS slot or a partial sum in HBM)
+// issued from ONE loop around ONE copy of the adder; the phases only differ in how (dst, src, active) are chosen.
+// LDS: two packed slots per lane (running sum, weighted sum) + one for R = 96 KB per workgroup.
 __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __restrict__ partial,
                                                                const uint32_t* __restrict__ seg_off, WinLayout L,
                                                                unsigned log_m, G1XYZZ* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
     G1XYZZ* sm_acc = sm_run + RED_BLOCK;
+    G1XYZZ* sm_r = sm_acc + RED_BLOCK;  // one slot: R_blk, saved before the scan slots are reused
     const uint32_t w = blockIdx.y, t = threadIdx.x;
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RED_BLOCK + t) << log_m;
+    const uint32_t base = L.boff[w];
     p28_store(sm_run[t], p28_identity());
     p28_store(sm_acc[t], p28_identity());
-    if (lo < B) {
-        const uint32_t base = L.boff[w];
-        uint32_t hi = min(lo + m, B);
-        for (uint32_t b = hi; b-- > lo;) {
-            uint32_t s = seg_off[base + b], e = seg_off[base + b + 1];
-            if (e - s > BIG_NSEG) e = s + 1;  // already folded into the first partial
-            P28 run = p28_load(sm_run[t]);
-            for (; s < e; s++) {
-                P28 q = p28_load(partial[s]);
-                p28_add_ool(run, q);
+    // phase-1 sequencer of this lane: buckets b = hi-1 .. lo; per bucket "run += partial[s]" for its segments, then
+    // "acc += run"
+    uint32_t b = min(lo + m, B), s = 0, e = 0;
+    bool walking = lo < B;
+    if (walking) {
+        b--;
+        s = seg_off[base + b];
+        e = seg_off[base + b + 1];
+        if (e - s > BIG_NSEG) e = s + 1;  // already folded into the first partial
+    }
+    enum { WALK = 0, SCAN = 1, SHIFT = 2, FOLD = 3, TREE = 4 };
+    int phase = WALK;
+    uint32_t d = 1;  // scan distance / tree stride
+    __syncthreads();
+#pragma unroll 1
+    for (;;) {
+        G1XYZZ* dst = &sm_run[t];
+        const G1XYZZ* src = &sm_run[t];
+        bool act = false;
+        if (phase == WALK) {
+            if (!__syncthreads_or(walking)) {
+                phase = SCAN;
+                continue;
             }
-            p28_store(sm_run[t], run);
-            P28 acc = p28_load(sm_acc[t]);
-            p28_add_ool(acc, run);
-            p28_store(sm_acc[t], acc);
+            if (walking) {
+                act = true;
+                if (s < e) {
+                    src = &partial[s++];
+                } else {
+                    dst = &sm_acc[t];
+                    if (b == lo) {
+                        walking = false;
+                    } else {
+                        b--;
+                        s = seg_off[base + b];
+                        e = seg_off[base + b + 1];
+                        if (e - s > BIG_NSEG) e = s + 1;
+                    }
+                }
+            }
+        } else if (phase == SCAN) {  // inclusive suffix scan of run over the workgroup (Hillis-Steele)
+            if (d >= RED_BLOCK) {
+                phase = SHIFT;
+                continue;
+            }
+            act = t + d < RED_BLOCK;
+            if (act) src = &sm_run[t + d];
+            d <<= 1;
+        } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1}; R_blk = Suffix_0 is parked first
+            P28 next = t + 1 < RED_BLOCK ? p28_load(sm_run[t + 1]) : p28_identity();
+            if (t == 0) sm_r[0] = sm_run[0];
+            __syncthreads();
+#pragma unroll 1
+            for (unsigned i = 0; i < log_m; i++) next = p28_dbl<MulFenced>(next);
+            p28_store(sm_run[t], next);
+            phase = FOLD;
+            continue;
+        } else if (phase == FOLD) {  // acc_t += m Suffix_{t+1}; summed over t this is A_blk
+            dst = &sm_acc[t];
+            act = true;
+            phase = TREE;
+            d = RED_BLOCK / 2;
+        } else {
+            if (d == 0) break;
+            dst = &sm_acc[t];
+            act = t < d;
+            src = act ? &sm_acc[t + d] : &sm_acc[t];
+            d >>= 1;
         }
-    }
-    __syncthreads();
-    // inclusive suffix scan of run over the workgroup (Hillis-Steele)
-    for (uint32_t d = 1; d < RED_BLOCK; d <<= 1) {
-        bool has = t + d < RED_BLOCK;
-        P28 v = p28_load(sm_run[t]);
-        P28 o = has ? p28_load(sm_run[t + d]) : p28_identity();
-        __syncthreads();
-        if (has) {
-            p28_add_ool(v, o);
-            p28_store(sm_run[t], v);
-        }
-        __syncthreads();
-    }
-    {
-        P28 next = t + 1 < RED_BLOCK ? p28_load(sm_run[t + 1]) : p28_identity();  // Suffix_{t+1}
-        for (unsigned i = 0; i < log_m; i++) next = p28_dbl<MulFenced>(next);
-        P28 acc = p28_load(sm_acc[t]);
-        p28_add_ool(acc, next);  // acc_t + m Suffix_{t+1}; summed over t this is A_blk
-        p28_store(sm_acc[t], acc);
-    }
-    __syncthreads();
-    for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
-        if (t < stride) {
-            P28 a = p28_load(sm_acc[t]);
-            P28 q = p28_load(sm_acc[t + stride]);
+        P28 a = p28_load(*dst);
+        P28 q = p28_load(*src);
+        __syncthreads();  // scan steps read their neighbour's slot before it is rewritten
+        if (act) {
             p28_add_ool(a, q);
-            p28_store(sm_acc[t], a);
+            p28_store(*dst, a);
         }
         __syncthreads();
     }
     if (t == 0) {
         size_t o = ((size_t)w * gridDim.x + blockIdx.x) * 2;
         p28_store_384(out[o], p28_load(sm_acc[0]));
-        p28_store_384(out[o + 1], p28_load(sm_run[0]));
+        p28_store_384(out[o + 1], p28_load(sm_r[0]));
     }
 }
 
@@ -681,7 +724,6 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                scan_tiles, bucket_off, seg_off, big_count, big_list);
     SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
                bucket_off, cursor, sorted);
-    unsigned grid_b = (pl.NB + 255) / 256;
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                seg_start, seg_len, len_hist);
@@ -692,9 +734,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
-    SWM_TRY(allow_big_lds(ctx, (const void*)msm_bucket_reduce, 2 * RED_BLOCK * sizeof(G1XYZZ)));
+    SWM_TRY(allow_big_lds(ctx, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
     SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
-               2 * RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
+               (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
     SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
                                 ctx->stream));
     SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
