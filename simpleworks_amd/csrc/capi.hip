@@ -178,6 +178,7 @@ void swm_destroy(swm_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx->host_pool;
     delete ctx;
 }
 

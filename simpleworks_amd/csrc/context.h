@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "../../include/swmarlin.h"
+#include "host/pool.h"
 
 namespace swm {
 
@@ -60,6 +61,7 @@ struct swm_ctx {
     std::map<std::string, swm::ProfAgg> prof;
     std::vector<swm::ProfPending> pending;
     std::vector<hipEvent_t> event_pool;
+    swm::HostPool* host_pool = nullptr;  // created on first use (msm_finish), joined in swm_destroy
 };
 
 struct swm_bases {

@@ -749,27 +749,51 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     if (!job->active) return SWM_OK;
     SWM_HIP(ctx, hipEventSynchronize(job->done));
     job->active = false;
-    // host: per window sum_blk [A_blk + blk * (RED_BLOCK * m) * R_blk] (suffix sums over the <= 8 workgroups), then Horner
-    // over windows (high -> low, c doublings each)
+    // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per
+    // workgroup; W_w by suffix sums over the <= 16 workgroups).  The windows are independent: they are folded on the
+    // context's host workers.  Then Horner over the windows (high -> low, c_w doublings each), with the 2^shift of W_w
+    // riding on the window's own doublings:  T <- 2^shift (2^(c_w - shift) T + W_w) + sum_blk A_blk.
     const WinLayout& pl = job->pl;
     const unsigned nb = job->red_blocks;
     unsigned shift = job->log_m;
     for (unsigned v = RED_BLOCK; v > 1; v >>= 1) shift++;
-    G1XYZZ total_pt = g1_xyzz_identity();
-    for (unsigned w = pl.nwin; w-- > 0;) {
-        for (unsigned k = 0; k < pl.c[w]; k++) total_pt = g1_dbl(total_pt);
+    G1XYZZ sum_a[MAX_WIN], weighted[MAX_WIN];
+    auto fold_window = [&](int w) {
         const G1XYZZ* h = job->host + (size_t)w * nb * 2;
-        G1XYZZ sum_a = g1_xyzz_identity(), suffix = g1_xyzz_identity(), weighted = g1_xyzz_identity();
+        G1XYZZ sa = g1_xyzz_identity(), suffix = g1_xyzz_identity(), wt = g1_xyzz_identity();
         for (unsigned blk = nb; blk-- > 0;) {
-            g1_add(sum_a, h[2 * blk]);
+            g1_add(sa, h[2 * blk]);
             if (blk >= 1) {
                 g1_add(suffix, h[2 * blk + 1]);  // Suffix_blk = sum_{u >= blk} R_u
-                g1_add(weighted, suffix);        // sum_{blk >= 1} Suffix_blk = sum_blk blk R_blk
+                g1_add(wt, suffix);              // sum_{blk >= 1} Suffix_blk = sum_blk blk R_blk
             }
         }
-        for (unsigned k = 0; k < shift; k++) weighted = g1_dbl(weighted);
-        g1_add(sum_a, weighted);
-        g1_add(total_pt, sum_a);
+        sum_a[w] = sa;
+        weighted[w] = wt;
+    };
+    if (nb > 1 && pl.nwin > 1) {
+        if (!ctx->host_pool) {
+            unsigned hw = std::thread::hardware_concurrency();
+            ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
+        }
+        ctx->host_pool->parallel_for((int)pl.nwin, fold_window);
+    } else {
+        for (unsigned w = 0; w < pl.nwin; w++) fold_window((int)w);
+    }
+    G1XYZZ total_pt = g1_xyzz_identity();
+    for (unsigned w = pl.nwin; w-- > 0;) {
+        unsigned cw = pl.c[w];
+        if (!g1_is_inf(weighted[w])) {
+            if (cw >= shift) {
+                for (unsigned k = shift; k < cw; k++) total_pt = g1_dbl(total_pt);
+                g1_add(total_pt, weighted[w]);
+                cw = shift;
+            } else {  // a window narrower than one workgroup's span cannot have content beyond workgroup 0
+                return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
+            }
+        }
+        for (unsigned k = 0; k < cw; k++) total_pt = g1_dbl(total_pt);
+        g1_add(total_pt, sum_a[w]);
     }
     *result = total_pt;
     return SWM_OK;
