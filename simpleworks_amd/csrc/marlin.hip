@@ -825,6 +825,30 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     std::vector<Commitment> comms1(4);
     P_mask.p = mask.p; P_mask.n = mask_len;
     pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
+    // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
+    auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
+        DVec e = dv_copy_padded(ctx, coeffs, n, M);
+        dv_ntt(ctx, e, logM, false);
+        return e;
+    };
+    DVec e_za = on_mul_domain(za_poly.p, H + 1);
+    DVec e_zb = on_mul_domain(zb_poly.p, H + 1);
+    DVec e_z;
+    {
+        DVec z_poly = dv_zeros(ctx, H + 1);
+        Fr* out = z_poly.p;
+        const Fr* wc = w_coeffs;
+        const Fr* xp = x_poly.p;
+        ew(ctx, "z_poly", H + 1, [=] __device__(size_t i) {
+            Fr v = fp_zero<Fr>();
+            if (i >= X && i - X < w_len) v = wc[i - X];
+            if (i < w_len) v = fp_sub(v, wc[i]);
+            if (i < X) v = fp_add(v, xp[i]);
+            out[i] = v;
+        });
+        e_z = on_mul_domain(z_poly.p, H + 1);
+    }
     comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
     comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
     comms1[2] = pc_commit_end(ctx, pk, &j1[2], &zk, &P_zb.rand);
@@ -867,35 +891,12 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     CommitJob j2[3];
     P_t.p = t_poly.p; P_t.n = H;
     pc_commit_begin(ctx, pk, &lane, P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
-    // evaluation form on the 4|H| domain
-    auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
-        DVec e = dv_copy_padded(ctx, coeffs, n, M);
-        dv_ntt(ctx, e, logM, false);
-        return e;
-    };
     DVec q1(ctx, M);
     {
         DVec ra_poly = dv_copy_padded(ctx, r_alpha_evals.p, H, H);
         dv_ntt(ctx, ra_poly, pk.logH, true);
         DVec e_ra = on_mul_domain(ra_poly.p, H);
-        DVec e_za = on_mul_domain(za_poly.p, H + 1);
-        DVec e_zb = on_mul_domain(zb_poly.p, H + 1);
         DVec e_t = on_mul_domain(t_poly.p, H);
-        // z_poly = w_poly * v_X + x_poly
-        DVec z_poly = dv_zeros(ctx, H + 1);
-        {
-            Fr* out = z_poly.p;
-            const Fr* wc = w_coeffs;
-            const Fr* xp = x_poly.p;
-            ew(ctx, "z_poly", H + 1, [=] __device__(size_t i) {
-                Fr v = fp_zero<Fr>();
-                if (i >= X && i - X < w_len) v = wc[i - X];
-                if (i < w_len) v = fp_sub(v, wc[i]);
-                if (i < X) v = fp_add(v, xp[i]);
-                out[i] = v;
-            });
-        }
-        DVec e_z = on_mul_domain(z_poly.p, H + 1);
         Fr* out = q1.p;
         const Fr *pra = e_ra.p, *pza = e_za.p, *pzb = e_zb.p, *pt = e_t.p, *pz = e_z.p;
         ew(ctx, "round2_pointwise", M, [=] __device__(size_t i) {
@@ -903,6 +904,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             Fr summed = fp_add(fp_add(fp_mul(eta_c, fp_mul(a, b)), fp_mul(eta_a, a)), fp_mul(eta_b, b));
             out[i] = fp_sub(fp_mul(pra[i], summed), fp_mul(pz[i], pt[i]));
         });
+        e_za.release();
+        e_zb.release();
+        e_z.release();
         dv_ntt(ctx, q1, logM, true);
         const Fr* mp = mask.p;
         ew(ctx, "q1_add_mask", mask_len, [=] __device__(size_t i) { out[i] = fp_add(out[i], mp[i]); });
@@ -1003,14 +1007,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     std::vector<Commitment> comms3(2);
     P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
     pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j3[1]);
-    comms3[0] = pc_commit_end(ctx, pk, &j3[0], nullptr, &P_g2.rand);
-    comms3[1] = pc_commit_end(ctx, pk, &j3[1], nullptr, &P_h2.rand);
-    tr.mark("round 3 commitments");
-    fs_absorb_commitments(fs, comms3);
-    st.gamma = fs.rand_fr();
-    const Fr gamma = st.gamma;
-
-    // ================= evaluations
+    // ================= evaluations, part 1: everything asked at beta depends on rounds 1-2 only, so it is enqueued here
+    // and runs under the round-3 commitments
     std::map<std::string, LPoly*> polys;
     LPoly idx_polys[12];
     for (int m = 0; m < 3; m++) {
@@ -1032,14 +1030,28 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         want.push_back({"g_2", true});
         want.push_back({"h_2", true});
         DVec slots(ctx, want.size());
-        EvalPoint ep_beta = eval_point(ctx, beta), ep_gamma = eval_point(ctx, gamma);
+        EvalPoint ep_beta = eval_point(ctx, beta);
         for (size_t i = 0; i < want.size(); i++) {
+            if (want[i].second) continue;
             LPoly* lp = polys.at(want[i].first);
-            poly_eval_async(ctx, lp->p, lp->n, want[i].second ? ep_gamma : ep_beta, slots.p + i);
+            poly_eval_async(ctx, lp->p, lp->n, ep_beta, slots.p + i);
+        }
+        comms3[0] = pc_commit_end(ctx, pk, &j3[0], nullptr, &P_g2.rand);
+        comms3[1] = pc_commit_end(ctx, pk, &j3[1], nullptr, &P_h2.rand);
+        tr.mark("round 3 commitments");
+        fs_absorb_commitments(fs, comms3);
+        st.gamma = fs.rand_fr();
+        // part 2: the evaluations at gamma
+        EvalPoint ep_gamma = eval_point(ctx, st.gamma);
+        for (size_t i = 0; i < want.size(); i++) {
+            if (!want[i].second) continue;
+            LPoly* lp = polys.at(want[i].first);
+            poly_eval_async(ctx, lp->p, lp->n, ep_gamma, slots.p + i);
         }
         std::vector<Fr> vals = slots.download(0, want.size());
         for (size_t i = 0; i < want.size(); i++) eval_cache[want[i]] = vals[i];
     }
+    const Fr gamma = st.gamma;
     auto poly_at = [&](const std::string& label, const Fr& point) {
         bool at_gamma = fp_eq(point, gamma);
         auto key = std::make_pair(label, at_gamma);

@@ -34,10 +34,7 @@
 namespace swm {
 
 // ---------------------------------------------------------------------------------------------- parameters
-#ifndef SWM_SEG
-#define SWM_SEG 128
-#endif
-static constexpr int SEG = SWM_SEG;     // points per accumulation segment (upper bound)
+static constexpr int SEG_MAX = 128;     // points per accumulation segment: upper bound, chosen per MSM (msm_seg_bound)
 static constexpr int BIG_NSEG = 16;     // buckets with more segments than this are folded by a whole workgroup
 static constexpr int RED_BLOCK = 256;
 static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
@@ -165,7 +162,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __re
     }
 }
 
-__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt) { return (cnt + SEG - 1) / SEG; }
+__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
 
 // Exclusive scans of the bucket counts and of the per-bucket segment counts, in three launches:
 // per-workgroup totals, a single-workgroup scan of those totals, per-workgroup scan + offset.
@@ -190,7 +187,7 @@ __device__ __forceinline__ void block_inclusive_scan2(uint32_t& a, uint32_t& b, 
     b = sb[tid];
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_totals(const uint32_t* __restrict__ hist, uint32_t NB,
+__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_totals(const uint32_t* __restrict__ hist, uint32_t NB, uint32_t SEG,
                                                              uint32_t* __restrict__ tot_cnt,
                                                              uint32_t* __restrict__ tot_seg) {
     __shared__ uint32_t sa[SCAN_BLOCK], sb[SCAN_BLOCK];
@@ -198,7 +195,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_totals(const uint32_t* __
     uint32_t a = 0, b = 0;
     for (uint32_t i = lo; i < min(lo + SCAN_ITEMS, NB); i++) {
         a += hist[i];
-        b += nseg_of(hist[i]);
+        b += nseg_of(hist[i], SEG);
     }
     block_inclusive_scan2(a, b, sa, sb);
     if (threadIdx.x == SCAN_BLOCK - 1) {
@@ -235,7 +232,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_mid(uint32_t* __restrict_
 }
 
 // Also appends buckets with > BIG_NSEG segments to the big list.
-__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __restrict__ hist, uint32_t NB,
+__global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __restrict__ hist, uint32_t NB, uint32_t SEG,
                                                             const uint32_t* __restrict__ tot_cnt,
                                                             const uint32_t* __restrict__ tot_seg, uint32_t ntiles,
                                                             uint32_t* __restrict__ bucket_off,
@@ -248,13 +245,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __r
     uint32_t a = 0, b = 0;
     for (uint32_t i = lo; i < hi; i++) {
         a += hist[i];
-        b += nseg_of(hist[i]);
+        b += nseg_of(hist[i], SEG);
     }
     uint32_t la = a, lb = b;
     block_inclusive_scan2(a, b, sa, sb);
     uint32_t ra = tot_cnt[blockIdx.x] + a - la, rb = tot_seg[blockIdx.x] + b - lb;
     for (uint32_t i = lo; i < hi; i++) {
-        uint32_t h = hist[i], ns = nseg_of(h);
+        uint32_t h = hist[i], ns = nseg_of(h, SEG);
         bucket_off[i] = ra;
         seg_off[i] = rb;
         ra += h;
@@ -284,10 +281,10 @@ __device__ __forceinline__ uint32_t bucket_of_segment(const uint32_t* __restrict
 static constexpr int ORD_THREADS = 256;
 __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __restrict__ bucket_off,
                                                             const uint32_t* __restrict__ seg_off, uint32_t NB,
-                                                            uint32_t* __restrict__ seg_start,
+                                                            uint32_t SEG, uint32_t* __restrict__ seg_start,
                                                             uint32_t* __restrict__ seg_len,
                                                             uint32_t* __restrict__ len_hist) {
-    __shared__ uint32_t lh[SEG + 1];
+    __shared__ uint32_t lh[SEG_MAX + 1];
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
     __syncthreads();
     uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
@@ -304,10 +301,10 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __re
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS)
         if (lh[i]) atomicAdd(&len_hist[i], lh[i]);
 }
-__global__ void msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */) {
+__global__ void msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
-        for (int i = 0; i <= SEG; i++) {
+        for (uint32_t i = 0; i <= SEG; i++) {
             uint32_t c = len_hist[i];
             len_hist[i] = run;
             run += c;
@@ -315,10 +312,10 @@ __global__ void msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive
     }
 }
 __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
-                                                             const uint32_t* __restrict__ nseg_ptr,
+                                                             const uint32_t* __restrict__ nseg_ptr, uint32_t SEG,
                                                              uint32_t* __restrict__ len_cursor /* offsets, advanced */,
                                                              uint32_t* __restrict__ order) {
-    __shared__ uint32_t lh[SEG + 1];
+    __shared__ uint32_t lh[SEG_MAX + 1];
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
     __syncthreads();
     uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
@@ -685,10 +682,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const char* base[9] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points"};
     for (int i = 0; i < 9; i++) snprintf(nm[i], sizeof(nm[i]), "msm%d.%s", lane < 0 ? 9 : lane, base[i]);
 
+    // Segment bound.  Long segments mean one partial sum per bucket (the bucket stage walks fewer partials) but fewer,
+    // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
+    // 32 by 10 % at 2^20 and 2^22, loses at 2^16 where 45 k buckets cannot fill 196 k lane slots).
+    const uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG + 1);
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1);
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
@@ -718,18 +719,18 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_TRY(allow_big_lds(ctx, (const void*)msm_hist, lds_sort));
     SWM_TRY(allow_big_lds(ctx, (const void*)msm_scatter, lds_sort));
     SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, hist);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, tot_cnt, tot_seg);
+    SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, tot_cnt, tot_seg,
+    SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
                scan_tiles, bucket_off, seg_off, big_count, big_list);
     SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
                bucket_off, cursor, sorted);
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
-               seg_start, seg_len, len_hist);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, len_hist,
-               order);
+               SEG, seg_start, seg_len, len_hist);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, SEG,
+               len_hist, order);
     SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
                d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
