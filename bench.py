@@ -105,12 +105,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook for single-GPU boxes: SWM_BENCH_BACKEND=gloo SWM_BENCH_DEVICE=0 runs all ranks on one device (the
+    # collectives then carry host tensors).  The driver's multi-GPU runs use the default: RCCL, one rank per GPU.
+    backend = os.environ.get("SWM_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("SWM_BENCH_DEVICE", local_rank))
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    ctx = swm.Context(local_rank)
+    ctx = swm.Context(device_index)
     n = 1 << args.log_n
 
     if args.workload == "msm":
@@ -127,7 +135,7 @@ def main():
         def step():
             part = ctx.msm_g1_dev(bh, d_sc, n, True)
             if world > 1:
-                t = torch.from_numpy(part.view(np.int64)).cuda()
+                t = torch.from_numpy(part.view(np.int64)).to(coll_dev)
                 out = [torch.empty_like(t) for _ in range(world)]
                 dist.all_gather(out, t)
                 acc = out[0].cpu().numpy().view(np.uint64)
@@ -178,7 +186,7 @@ def main():
     if args.workload == "prove":
         assert M.verify_proof(vk, public, last["proof"], M.generate_rand()), "bench: proof does not verify"
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
