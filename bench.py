@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline measurement of the hot path on MI355X (contract: task statement; notes in DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload prove|msm] [--log-n L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload prove|msm|prove_sharded] [--log-n L]
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM.
   workload prove (default) : one Marlin prove() of the 2^L-constraint synthetic R1CS (BASELINE.json configs[2]; L = 20):
@@ -11,7 +11,9 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
                              value = points/s.
 With N > 1 (torch.distributed.run, one rank per GPU, RCCL): `prove` runs one independent proof per rank (replicas,
 weak scaling, no data-path collective); `msm` gives each rank a 2^L-point shard of an N*2^L-point MSM and folds the
-144-byte Jacobian partials after an all-gather.  Prints ONE JSON line on rank 0.
+144-byte Jacobian partials after an all-gather; `prove_sharded` (strong scaling, not the default) runs ONE proof over
+all ranks: every commitment MSM split by point range, partial sums all-gathered, everything else replicated
+(simpleworks_amd.dist.enable_sharded_prover).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -92,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prove", choices=["prove", "msm"])
+    ap.add_argument("--workload", default="prove", choices=["prove", "msm", "prove_sharded"])
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,9 +152,13 @@ def main():
         from simpleworks_amd import marlin as M
         from simpleworks_amd import workloads as W
         M.set_default_context(ctx)
+        sharded = args.workload == "prove_sharded"
+        if sharded and world > 1:
+            from simpleworks_amd.dist import enable_sharded_prover
+            enable_sharded_prover(ctx)
         rng = M.generate_rand()
         srs = M.generate_universal_srs(n, n, n, rng)
-        cs, public = W.synthetic_r1cs(n, 0x1234567 + rank, 0x7654321)
+        cs, public = W.synthetic_r1cs(n, 0x1234567 + (0 if sharded else rank), 0x7654321)
         pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
         srs.free()
         last = {}
@@ -183,7 +189,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile()
-    if args.workload == "prove":
+    if args.workload != "msm":
         assert M.verify_proof(vk, public, last["proof"], M.generate_rand()), "bench: proof does not verify"
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -210,12 +216,15 @@ def main():
         except Exception:
             traffic = None
         out = {
-            "metric": METRIC, "value": units * world * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC, "value": units * (1 if args.workload == "prove_sharded" else world) * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.workload == "prove_sharded" else "weak",
             "vs_baseline": None, "dtype": "u32 limbs (384-bit Montgomery Fq for G1, 256-bit Fr)", "data": "synthetic",
             "config": {"workload": workload, "per_gpu_units": n,
-                       "multi_gpu": "replicas (one proof per rank)" if args.workload == "prove" else
-                       "point-range shards, all-gather of 144-B partials"},
+                       "multi_gpu": {"prove": "replicas (one proof per rank)",
+                                     "prove_sharded": "one proof over all ranks: point-range sharded commitment MSMs, "
+                                                      "192-B partials all-gathered, transforms replicated",
+                                     "msm": "point-range shards, all-gather of 144-B partials"}[args.workload]},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,

@@ -175,6 +175,19 @@ int swm_r1cs_is_satisfied(swm_ctx *ctx, const swm_r1cs *cs, int *ok, size_t *fir
 int swm_blake2s(const uint8_t *data, size_t len, uint8_t out[32]);
 int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_t out[64]);
 
+/* ---------------------------------------------------------------------------------------------- one proof over several GPUs
+ * every commitment MSM of swm_generate_proof / swm_generate_proving_and_verifying_keys is split by
+ * point range — rank g of `world` takes coefficients and SRS powers [g n / world, (g+1) n / world) — and the
+ * per-rank partial sums (one 192-byte XYZZ point per MSM) are exchanged through `allgather`, which must behave like
+ * MPI_Allgather on `bytes` bytes per rank (recv holds world * bytes, rank order).  EC addition is not an RCCL
+ * reduction, so the exchange is an all-gather followed by the same rank-ordered sum on every rank; every rank then
+ * holds the same commitment and emits the same proof bytes as a single-GPU run.  Everything else of the prover
+ * (transforms, pointwise work, transcript) is replicated: it is cheaper to recompute a 2^20-point NTT (0.15 ms)
+ * than to move its 32 MB over xGMI.  world = 1 (the default) or allgather = NULL switches sharding off.
+ * The callback is invoked on the thread that called into the library, between kernels (the stream is idle). */
+typedef int (*swm_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+int swm_set_msm_sharding(swm_ctx *ctx, unsigned rank, unsigned world, swm_allgather_fn allgather, void *user);
+
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
  * kernel launch is bracketed by hipEventRecord on the stream it is launched on.  swm_profile_json writes

@@ -23,6 +23,7 @@ ABI = {
     "swm_destroy": (None, [_vp]),
     "swm_last_error": (ctypes.c_char_p, [_vp]),
     "swm_set_stream": (_int, [_vp, _vp]),
+    "swm_set_msm_sharding": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, _vp, _vp]),
     "swm_synchronize": (_int, [_vp]),
     "swm_malloc": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
     "swm_free": (_int, [_vp, _vp]),
@@ -185,6 +186,34 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.swm_synchronize(self.h), "swm_synchronize")
+
+    ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+    def set_msm_sharding(self, rank, world, allgather=None):
+        """swm_set_msm_sharding: split every commitment MSM of the prover / indexer by point range over `world`
+        contexts.  `allgather(send: bytes) -> bytes` must return the concatenation of every rank's `send` in rank
+        order (simpleworks_amd.dist.enable_sharded_prover supplies one over torch.distributed).  world <= 1 or
+        allgather None switches sharding off."""
+        if world <= 1 or allgather is None:
+            self._check(self.lib.swm_set_msm_sharding(self.h, 0, 1, None, None), "swm_set_msm_sharding")
+            self._shard_cb = None
+            return
+
+        def _cb(_user, send, nbytes, recv):
+            try:
+                out = allgather(ctypes.string_at(send, nbytes))
+                if len(out) != nbytes * world:
+                    return 1
+                ctypes.memmove(recv, out, len(out))
+                return 0
+            except Exception:  # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = Context.ALLGATHER_FN(_cb)
+        self._check(self.lib.swm_set_msm_sharding(self.h, rank, world, ctypes.cast(cb, ctypes.c_void_p), None),
+                    "swm_set_msm_sharding")
+        self._shard_cb = cb  # keep the trampoline alive as long as the library may call it
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

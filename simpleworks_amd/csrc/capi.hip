@@ -184,6 +184,23 @@ void swm_destroy(swm_ctx* ctx) {
 
 const char* swm_last_error(swm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+int swm_set_msm_sharding(swm_ctx* ctx, unsigned rank, unsigned world, swm_allgather_fn allgather, void* user) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    if (world <= 1 || !allgather) {
+        ctx->shard_rank = 0;
+        ctx->shard_world = 1;
+        ctx->shard_allgather = nullptr;
+        ctx->shard_user = nullptr;
+        return SWM_OK;
+    }
+    if (rank >= world || world > 1024) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm sharding: rank %u of %u", rank, world);
+    ctx->shard_rank = rank;
+    ctx->shard_world = world;
+    ctx->shard_allgather = allgather;
+    ctx->shard_user = user;
+    return SWM_OK;
+}
+
 int swm_set_stream(swm_ctx* ctx, void* hip_stream) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));

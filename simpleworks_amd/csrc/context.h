@@ -61,6 +61,10 @@ struct swm_ctx {
     std::map<std::string, swm::ProfAgg> prof;
     std::vector<swm::ProfPending> pending;
     std::vector<hipEvent_t> event_pool;
+    // point-range sharding of the prover's MSMs over several contexts/GPUs (swm_set_msm_sharding)
+    unsigned shard_rank = 0, shard_world = 1;
+    swm_allgather_fn shard_allgather = nullptr;
+    void* shard_user = nullptr;
     swm::HostPool* host_pool = nullptr;  // created on first use (msm_finish), joined in swm_destroy
 };
 

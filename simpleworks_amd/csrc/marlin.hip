@@ -324,17 +324,34 @@ G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeff
     return r;
 }
 // asynchronous form: alternates between the two MSM lanes of the context
+// With swm_set_msm_sharding active the context only takes its own point range of every MSM and the partial sums are
+// exchanged in commit_wait (all-gather of one point per rank + the same rank-ordered sum everywhere).
 struct AsyncMsm {
     MsmJob job;
+    bool sharded = false;
 };
 void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
     if (n && offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
     static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &out->job));
+    size_t lo = 0, hi = n;
+    out->sharded = ctx->shard_world > 1;
+    if (out->sharded) {
+        lo = (size_t)(((unsigned __int128)n * ctx->shard_rank) / ctx->shard_world);
+        hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
+    }
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, pk.d_powers + offset + lo, pk.d_powers28 + offset + lo, coeffs + lo,
+                              hi - lo, 1, &out->job));
 }
 G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
     G1XYZZ r;
     rc_check(ctx, msm_finish(ctx, &a->job, &r));
+    if (a->sharded) {
+        std::vector<G1XYZZ> all(ctx->shard_world);
+        int rc = ctx->shard_allgather(ctx->shard_user, &r, sizeof(G1XYZZ), all.data());
+        if (rc != 0) throw MarlinError(SWM_ERR_INTERNAL, "msm sharding: the all-gather callback failed");
+        r = all[0];
+        for (unsigned g = 1; g < ctx->shard_world; g++) g1_add(r, all[g]);
+    }
     return r;
 }
 

@@ -47,3 +47,29 @@ def sharded_msm(local_msm, add_fn, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return part
     return fold_partials(all_gather_partials(part, group), add_fn)
+
+
+def enable_sharded_prover(ctx, group=None):
+    """One proof over all ranks of `group` (include/swmarlin.h swm_set_msm_sharding): every rank calls
+    generate_proof with the SAME constraint system, key and rng state; each commitment MSM is computed by point range
+    and the 192-byte partial sums are all-gathered (RCCL over xGMI with the nccl backend, host tensors with gloo).
+    All ranks return the same proof bytes as a single-GPU run."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        ctx.set_msm_sharding(0, 1, None)
+        return
+    on_gpu = dist.get_backend(group) == "nccl"
+
+    def allgather(send):
+        t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+        if on_gpu:
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        return b"".join(o.cpu().numpy().tobytes() for o in out)
+
+    ctx.set_msm_sharding(rank, world, allgather)

@@ -126,3 +126,89 @@ def test_proving_key_roundtrip(M, S, W):
     pk.free()
     pk2.free()
     srs.free()
+
+
+# ------------------------------------------------------------------------------------------------ one proof over several contexts
+def _run_sharded(world, build):
+    """Runs build(ctx) on `world` contexts (threads of this process, all on GPU 0) whose commitment MSMs are split by
+    point range (swm_set_msm_sharding); the all-gather is a barrier over a shared list.  Returns the per-rank results."""
+    import threading
+    from simpleworks_amd._lib import Context
+    barrier = threading.Barrier(world)
+    slots, results, errors = [None] * world, [None] * world, []
+
+    def allgather_for(rank):
+        def allgather(send):
+            slots[rank] = send
+            barrier.wait(timeout=120)
+            out = b"".join(slots)
+            barrier.wait(timeout=120)
+            return out
+        return allgather
+
+    def worker(rank):
+        try:
+            ctx = Context(0)
+            ctx.set_msm_sharding(rank, world, allgather_for(rank))
+            results[rank] = build(ctx)
+            ctx.set_msm_sharding(0, 1, None)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prover_matches_golden_bytes(M, S, W, world):
+    """the result must be identical for every GPU count.  Ranges of a 8..32-point MSM over 2-3 ranks
+    include empty and single-point shards."""
+    for name in ("manual_constraints", "synthetic_32"):
+        case = golden("marlin.json")[name]
+
+        def build(ctx, case=case, name=name):
+            rng = M.generate_rand()
+            srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+            cs = W.manual_constraints_circuit(1, 1) if name == "manual_constraints" else W.synthetic_circuit(
+                case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
+            pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+            proof = M.generate_proof(cs, pk, rng)
+            out = (S.serialize_verifying_key(vk).hex(), S.serialize_proof(proof).hex())
+            pk.free()
+            srs.free()
+            return out
+
+        for vk_hex, proof_hex in _run_sharded(world, build):
+            assert vk_hex == case["vk"]
+            assert proof_hex == case["proof"]
+
+
+def test_sharded_prover_matches_single_context_at_2p14(M, S, W):
+    n = 1 << 14
+    cs, public = W.synthetic_r1cs(n, 0xabcdef, 0x123457)
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        proof = M.generate_proof(cs, pk, rng)
+        out = (S.serialize_verifying_key(vk), S.serialize_proof(proof))
+        pk.free()
+        srs.free()
+        return out
+
+    from simpleworks_amd._lib import Context
+    single_ctx = Context(0)
+    vk1, proof1 = build(single_ctx)
+    single_ctx.close()
+    for vk_b, proof_b in _run_sharded(4, build):
+        assert vk_b == vk1
+        assert proof_b == proof1
+    assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
