@@ -49,19 +49,13 @@ def sharded_msm(local_msm, add_fn, group=None):
     return fold_partials(all_gather_partials(part, group), add_fn)
 
 
-def enable_sharded_prover(ctx, group=None):
-    """One proof over all ranks of `group` (SURVEY.md §8e, include/swmarlin.h swm_set_msm_sharding): every rank calls
-    generate_proof with the SAME constraint system, key and rng state; each commitment MSM is computed by point range
-    and the 192-byte partial sums are all-gathered (RCCL over xGMI with the nccl backend, host tensors with gloo).
-    All ranks return the same proof bytes as a single-GPU run."""
+def make_byte_allgather(group=None):
+    """allgather(send: bytes) -> bytes of every rank in rank order, over torch.distributed (device tensors with the
+    nccl backend = RCCL over xGMI, host tensors with gloo).  This is the callback swm_set_msm_sharding asks for."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if world == 1:
-        ctx.set_msm_sharding(0, 1, None)
-        return
     on_gpu = dist.get_backend(group) == "nccl"
 
     def allgather(send):
@@ -72,4 +66,17 @@ def enable_sharded_prover(ctx, group=None):
         dist.all_gather(out, t, group=group)
         return b"".join(o.cpu().numpy().tobytes() for o in out)
 
-    ctx.set_msm_sharding(rank, world, allgather)
+    return allgather
+
+
+def enable_sharded_prover(ctx, group=None):
+    """One proof over all ranks of `group` (SURVEY.md §8e, include/swmarlin.h swm_set_msm_sharding): every rank calls
+    generate_proof with the SAME constraint system, key and rng state; each commitment MSM is computed by point range
+    and the 192-byte partial sums are all-gathered.  All ranks return the same proof bytes as a single-GPU run."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        ctx.set_msm_sharding(0, 1, None)
+        return
+    ctx.set_msm_sharding(dist.get_rank(group), world, make_byte_allgather(group))

@@ -67,3 +67,36 @@ def test_sharded_msm_world2_gloo(n):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _worker_bytes(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from simpleworks_amd.dist import make_byte_allgather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag = make_byte_allgather()
+    ok = True
+    for nbytes in (192, 1, 4096):  # 192 = one XYZZ partial, the size swm_set_msm_sharding exchanges
+        mine = bytes((rank * 31 + i) & 0xff for i in range(nbytes))
+        want = b"".join(bytes((r * 31 + i) & 0xff for i in range(nbytes)) for r in range(world))
+        ok = ok and ag(mine) == want
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_byte_allgather_world2_gloo():
+    """The exchange step of the sharded prover (include/swmarlin.h swm_allgather_fn) over torch.distributed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bytes, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]
