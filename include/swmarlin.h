@@ -198,7 +198,9 @@ int swm_profile_reset(swm_ctx *ctx);
 int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);
 
 /* Device self-test of the field / curve primitives the kernels are built from: computes a[i]*b[i] in Fq (which = 0),
- * or in Fr (which = 1), element-wise on the GPU.  Inputs/outputs are host buffers in Montgomery form. */
+ * or in Fr (which = 1), element-wise on the GPU.  Inputs/outputs are host buffers in Montgomery form.
+ * which = 2, 5, 6 exercise the MSM's 28-bit lazy-limb multipliers of csrc/fq28.cuh (plain, squarer, fused two-product)
+ * on packed 384-bit integers; results are canonical residues times 2^-392. */
 int swm_selftest_mul(swm_ctx *ctx, int which, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 /* out[i] = jacobian(a[i] (+) b[i]) with a, b affine (n x 12 limbs): exercises the mixed/XYZZ adders incl. doubling. */
 int swm_selftest_g1_add(swm_ctx *ctx, const uint64_t *a_xy, const uint64_t *b_xy, uint64_t *out_jac, size_t n);

@@ -124,6 +124,39 @@ __device__ __forceinline__ Fq28 fq28_mul(const Fq28& a, const Fq28& b) {
     r.l[13] = (uint32_t)acc;
     return r;
 }
+// (a b + c d) 2^-392 mod p with ONE Montgomery reduction: 2 x 196 + 182 multiply-adds instead of 2 x 378.  The
+// group formulas end in Y3 = R V - Y1 PPP; with c = k p - Y1 that is exactly this shape.
+// Bounds: limbs(a), limbs(b) < 1.5 * 2^29 (normalised + one "_1" spread), limbs(c) < 2^29, limbs(d) < 2^28:
+//   column sum <= 14 (2.25 * 2^58 + 2^57) + 14 * 2^56 + 2^37 < 2^63.5;  value < (a b + c d) / 2^392 + p < 2p  =>  N.
+__device__ __forceinline__ Fq28 fq28_mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+    Fq28 r;
+    uint32_t m[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        m[k] = (0u - (uint32_t)acc) & M28;
+        acc = (acc + m[k]) >> 28;
+    }
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        r.l[k - 14] = (uint32_t)acc & M28;
+        acc >>= 28;
+    }
+    r.l[13] = (uint32_t)acc;
+    return r;
+}
 // a^2 2^-392 mod p with the cross products computed once against the doubled operand: 105 instead of 196 partial
 // products for the a*a half.  Requires limbs < 0.75 * 2^30 (every caller: normalised + one spread subtraction, or
 // 3 * normalised): column sum <= 7 * (1.5 * 2^30)(0.75 * 2^30) + (0.75 * 2^30)^2 + 14 * 2^56 < 2^64.
@@ -166,10 +199,16 @@ struct MulInline {
     // the dedicated squarer (fq28_sqr, 105 instead of 196 a*a products) measured no faster inside the adders on
     // gfx950 (r01: 2.74 vs 2.63 ms per 2^20-point accumulation), so the policies square with the multiplier
     static __device__ __forceinline__ Fq28 sqr(const Fq28& a) { return fq28_mul(a, a); }
+    static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+        return fq28_mul2(a, b, c, d);
+    }
 };
 struct MulCall {
     static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul_call(a, b); }
     static __device__ __forceinline__ Fq28 sqr(const Fq28& a) { return fq28_mul_call(a, a); }
+    static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+        return fq28_mul2(a, b, c, d);
+    }
 };
 // Inline multiplier fenced by scheduling barriers: stops the compiler from interleaving independent multiplications
 // of a group operation (which buys no ILP on an in-order SIMD but doubles the live registers and forces spills).
@@ -183,6 +222,12 @@ struct MulFenced {
     static __device__ __forceinline__ Fq28 sqr(const Fq28& a) {
         __builtin_amdgcn_sched_barrier(0);
         Fq28 r = fq28_mul(a, a);
+        __builtin_amdgcn_sched_barrier(0);
+        return r;
+    }
+    static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+        __builtin_amdgcn_sched_barrier(0);
+        Fq28 r = fq28_mul2(a, b, c, d);
         __builtin_amdgcn_sched_barrier(0);
         return r;
     }
@@ -274,9 +319,10 @@ __device__ __forceinline__ P28 p28_dbl(const P28& p) {
 #pragma unroll
     for (int i = 0; i < 14; i++) x3.l[i] = mm.l[i] + Fq28Consts::SPREAD16_3[i] - s.l[i] - s.l[i];
     r.x = fq28_normalize(x3);                                 // (12p, 18p)
-    Fq28 t1 = M::mul(m, FQ28_SUB(s, r.x, SPREAD32));        // lazy operands: 3 * 2^28 x 2^30 limbs
-    Fq28 t2 = M::mul(w, p.y);
-    r.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));          // (2p, 6p)
+    Fq28 ny;                                                  // 8p - Y1 > 0 (Y1 < 6p), limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < 14; i++) ny.l[i] = Fq28Consts::SPREAD8[i] - p.y.l[i];
+    r.y = M::mul2(m, FQ28_SUB(s, r.x, SPREAD32), ny, w);      // M (S - X3) - W Y1, one reduction; N
     r.zz = M::mul(v, p.zz);
     r.zzz = M::mul(w, p.zzz);
     return r;
@@ -304,9 +350,10 @@ __device__ __forceinline__ bool p28_add_fast(P28& a, const P28& q) {
 #pragma unroll
     for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - qq.l[i] - qq.l[i];
     x3 = fq28_normalize(x3);              // (10p, 18p)
-    Fq28 t1 = M::mul(r, FQ28_SUB(qq, x3, SPREAD32));
-    Fq28 t2 = M::mul(s1, ppp);
-    a.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));
+    Fq28 ns1;                                                 // 4p - S1 > 0 (S1 < 2p), limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < 14; i++) ns1.l[i] = Fq28Consts::SPREAD4[i] - s1.l[i];
+    a.y = M::mul2(r, FQ28_SUB(qq, x3, SPREAD32), ns1, ppp);   // R (Q - X3) - S1 PPP, one reduction; N
     a.x = x3;
     a.zz = M::mul(M::mul(a.zz, q.zz), pp);
     a.zzz = M::mul(M::mul(a.zzz, q.zzz), ppp);

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __r
 //   PP = P^2, PPP = P PP, Q = X1 PP, RR = R^2              N          (products of two lazy values: 14 * 2^60 < 2^64)
 //   X3 = normalise(RR + 16p - PPP - 2Q)                    normalised, value in (10p, 18p)
 //   V  = Q + 32p - X3                                      limbs < 2^30, value in (14p, 24p)
-//   Y3 = normalise(R V + 4p - Y1 PPP)                      normalised, value in ( 2p,  6p)
+//   Y3 = (R V + (8p - Y1) PPP) 2^-392, ONE reduction        N          (fq28_mul2: limbs 1.5 2^29 x 1.5 2^29 + 2^29 x 2^28)
 //   ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP                          N
 // P = 0 mod p (doubling or cancellation: the point equals +-accumulator) is detected on PP, which is an N value; the
 // segment is then recomputed with the fully reducing 32-bit-limb adder (cold path).
@@ -367,9 +367,10 @@ __device__ __forceinline__ bool madd28(Acc28& a, const Fq28& x2, const Fq28& y2)
     for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - q.l[i] - q.l[i];
     x3 = fq28_normalize(x3);
     Fq28 v = FQ28_SUB(q, x3, SPREAD32);
-    Fq28 t1 = fq28_mul(r, v);
-    Fq28 t2 = fq28_mul(a.y, ppp);
-    a.y = fq28_normalize(FQ28_SUB(t1, t2, SPREAD4));
+    Fq28 ny;  // 8p - Y1 > 0, limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < 14; i++) ny.l[i] = Fq28Consts::SPREAD8[i] - a.y.l[i];
+    a.y = fq28_mul2(r, v, ny, ppp);  // R V - Y1 PPP with one reduction
     a.x = x3;
     a.zz = fq28_mul(a.zz, pp);
     a.zzz = fq28_mul(a.zzz, ppp);

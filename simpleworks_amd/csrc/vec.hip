@@ -88,6 +88,20 @@ __global__ void __launch_bounds__(256) selftest_sqr28_kernel(const Fq* a, const 
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = fq28_pack(fq28_canonical(fq28_sqr(fq28_add(fq28_unpack(a[i]), fq28_unpack(b[i])))));
 }
+// fused two-product multiplier at its operand bounds: out = canonical((x y + c d) 2^-392) with
+// x = a + 8p-spread, y = b + 32p-spread (limbs < 1.5 * 2^29), c = 8p-spread - a (limbs < 2^29), d = b
+__global__ void __launch_bounds__(256) selftest_mul2_28_kernel(const Fq* a, const Fq* b, Fq* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq28 ua = fq28_unpack(a[i]), ub = fq28_unpack(b[i]), x, y, c;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        x.l[k] = ua.l[k] + Fq28Consts::SPREAD8[k];
+        y.l[k] = ub.l[k] + Fq28Consts::SPREAD32[k];
+        c.l[k] = Fq28Consts::SPREAD8[k] - ua.l[k];
+    }
+    out[i] = fq28_pack(fq28_canonical(fq28_mul2(x, y, c, ub)));
+}
 __global__ void __launch_bounds__(256) selftest_mul28_chain(Fq* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     Fq28 a = fq28_const(Fq28Consts::ONE), b = fq28_const(Fq28Consts::TO384);
@@ -140,7 +154,10 @@ __global__ void __launch_bounds__(256) selftest_g1_add_kernel(const G1Affine* a,
 
 int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n) {
     unsigned grid = (unsigned)((n + 255) / 256);
-    if (which == 5)
+    if (which == 6)
+        SWM_LAUNCH(ctx, "selftest_mul2_28", selftest_mul2_28_kernel, dim3(grid), dim3(256), 0, (const Fq*)a, (const Fq*)b,
+                   (Fq*)out, n);
+    else if (which == 5)
         SWM_LAUNCH(ctx, "selftest_sqr28", selftest_sqr28_kernel, dim3(grid), dim3(256), 0, (const Fq*)a, (const Fq*)b,
                    (Fq*)out, n);
     else if (which == 2)

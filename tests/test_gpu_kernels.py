@@ -64,6 +64,23 @@ def test_device_field_mul_matches_golden_and_oracle(ctx, orc):
     assert np.array_equal(ctx.selftest_mul(0, xa, xb), ref)
 
 
+def test_device_lazy_limb_multipliers(ctx):
+    """fq28.cuh (the MSM's 14 x 28-bit lazy-carry domain, Montgomery radix 2^392) against Python integers: the plain
+    multiplier on operands up to 2^378, and the fused two-product form at its operand bounds (spread-subtracted limbs)."""
+    import random
+    Q = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+    rnd = random.Random(5)
+    edge = [0, 1, Q - 1, Q, Q + 1, 2 * Q - 1, (1 << 377) - 1, (1 << 378) - 1]
+    A = [rnd.randrange(2 * Q) for _ in range(4000)] + [x for x in edge for _ in edge]
+    B = [rnd.randrange(2 * Q) for _ in range(4000)] + [y for _ in edge for y in edge]
+    inv = pow(1 << 392, -1, Q)
+    out = limbs_to_ints(ctx.selftest_mul(2, ints_to_limbs(A, 6), ints_to_limbs(B, 6)))
+    assert out == [a * b * inv % Q for a, b in zip(A, B)]
+    # which = 6: ((a + 8p)(b + 32p) + (8p - a) b) / 2^392 with all four operands in lazy limb form
+    out = limbs_to_ints(ctx.selftest_mul(6, ints_to_limbs(A, 6), ints_to_limbs(B, 6)))
+    assert out == [((a + 8 * Q) * (b + 32 * Q) + (8 * Q - a) * b) * inv % Q for a, b in zip(A, B)]
+
+
 def test_device_group_law(ctx, orc):
     g = golden("g1.json")
     a_pts = [_pt(c["a"]) for c in g["adds"]] + [_pt(c["a"]) for c in g["adds"]]
