@@ -286,6 +286,9 @@ class Context:
         self._check(self.lib.swm_batch_inverse_fr(self.h, _p64(d), d.shape[0]), "swm_batch_inverse_fr")
         return d
 
+    def batch_inverse_fr_dev(self, dbuf, n):
+        self._check(self.lib.swm_batch_inverse_fr_dev(self.h, dbuf.ptr, n), "swm_batch_inverse_fr_dev")
+
     def vec_mul_fr(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)

@@ -259,10 +259,22 @@ template <class F> SWM_HD F fp_pow(const F& a, const uint32_t* e, int elimbs) {
 }
 // Fermat inverse; 0 -> 0 (matches the "zeros stay zero" convention of ark_ff::batch_inversion callers)
 template <class F> SWM_HD F fp_inv(const F& a) {
-    uint32_t e[F::N];
-#pragma unroll
-    for (int i = 0; i < F::N; i++) e[i] = F::Params::PM2[i];
-    return fp_pow(a, e, F::N);
+    // The exponent limbs are read straight from the constant table, one limb per outer iteration: a private copy
+    // indexed by a loop variable lives in scratch memory on the GPU, and its ~250 dependent loads made a single
+    // inversion (the serial tail of every batch inversion) twice as slow as its multiplications.
+    F acc = a;
+    bool started = false;
+    for (int limb = F::N - 1; limb >= 0; limb--) {
+        const uint32_t w = F::Params::PM2[limb];
+        for (int bit = 31; bit >= 0; bit--) {
+            if (started) acc = fp_sqr(acc);
+            if ((w >> bit) & 1) {
+                acc = started ? fp_mul(acc, a) : a;
+                started = true;
+            }
+        }
+    }
+    return started ? acc : fp_zero<F>();
 }
 
 // integer comparison of the standard-form values (ark-ff Ord): -1, 0, 1

@@ -967,16 +967,17 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     Fr vhab = fp_mul(vh_alpha, vh_beta);
     DVec f(ctx, K);
     {
-        DVec inv_a(ctx, K), inv_b(ctx, K), inv_c(ctx, K);
-        Fr* pi[3] = {inv_a.p, inv_b.p, inv_c.p};
+        // the three denominator vectors share one buffer and ONE batch inversion: its cost is the serial Fermat chain of
+        // a lane (~0.4 ms whatever the length), so three launches would pay it three times
+        DVec inv(ctx, 3 * K);
         for (int m = 0; m < 3; m++) {
-            Fr* out = pi[m];
+            Fr* out = inv.p + (size_t)m * K;
             const Fr *rk = pk.ar[m].row_K.p, *ck = pk.ar[m].col_K.p;
             ew(ctx, "round3_den_K", K, [=] __device__(size_t i) { out[i] = fp_mul(fp_sub(beta, rk[i]), fp_sub(alpha, ck[i])); });
-            rc_check(ctx, batch_inverse_run(ctx, out, K));
         }
+        rc_check(ctx, batch_inverse_run(ctx, inv.p, 3 * K));
         Fr* out = f.p;
-        const Fr *ia = inv_a.p, *ib = inv_b.p, *ic = inv_c.p;
+        const Fr *ia = inv.p, *ib = inv.p + K, *ic = inv.p + 2 * K;
         const Fr *va = pk.ar[0].val_K.p, *vb = pk.ar[1].val_K.p, *vc = pk.ar[2].val_K.p;
         ew(ctx, "round3_f_K", K, [=] __device__(size_t i) {
             Fr t = fp_add(fp_add(fp_mul(fp_mul(eta_a, va[i]), ia[i]), fp_mul(fp_mul(eta_b, vb[i]), ib[i])),
