@@ -17,7 +17,8 @@
 
 namespace swm {
 
-static constexpr int NTT_J = 8;         // contiguous columns per tile
+// contiguous columns per tile: chosen per pass so that a workgroup holds ~1024 elements (32 KB of LDS: four to five
+// workgroups per CU, every lane busy in every butterfly level) — 512 when the transform is too small to fill the chip
 static constexpr int NTT_THREADS = 256;
 static constexpr unsigned NTT_MAX_LOG_R = 8;
 
@@ -240,8 +241,19 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
             if (shmem < 64) shmem = 64;
             SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<1>, dim3((unsigned)cols), dim3(NTT_THREADS), shmem, a);
         } else {
-            size_t shmem = (sizeof(Fr) * NTT_J) << a.log_r;
-            SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<NTT_J>, dim3((unsigned)(cols / NTT_J)), dim3(NTT_THREADS), shmem, a);
+            unsigned J = (log_n >= 19 ? 1024u : 512u) >> a.log_r;
+            if (J < 1) J = 1;
+            if (J > 16) J = 16;
+            while (J > cols) J >>= 1;
+            size_t shmem = (sizeof(Fr) * J) << a.log_r;
+            dim3 grid((unsigned)(cols / J)), block(NTT_THREADS);
+            switch (J) {
+                case 1: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<1>, grid, block, shmem, a); break;
+                case 2: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<2>, grid, block, shmem, a); break;
+                case 4: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<4>, grid, block, shmem, a); break;
+                case 8: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<8>, grid, block, shmem, a); break;
+                default: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass<16>, grid, block, shmem, a); break;
+            }
         }
         log_ns += a.log_r;
         cur ^= 1;
