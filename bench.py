@@ -232,7 +232,7 @@ def main():
             "work_per_step": {k: v / args.steps for k, v in work.items()},
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             if args.workload == "msm":
                 out["cpu_baseline"] = cpu_baseline_msm(args.cpu_log_n or 18)
             else:
