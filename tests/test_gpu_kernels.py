@@ -195,6 +195,45 @@ def test_msm_pathological_buckets(ctx, orc):
     bh.free()
 
 
+def test_msm_edge_sizes_and_scalars(ctx, orc):
+    """SURVEY.md §8d edge cases: n = 1, 31, 32, 33 with scalars drawn from {0, 1, r - 1, one repeated value}."""
+    g = golden("msm.json")
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(64, h2i(g["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    for n in (1, 31, 32, 33):
+        for pattern in ([0], [1], [R - 1], [0, 1, R - 1], [0x1234567, 0x1234567]):
+            sc = ints_to_limbs([pattern[i % len(pattern)] for i in range(n)], 4)
+            ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[:n]), sc))
+            assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref, (n, pattern)
+    bh.free()
+
+
+def test_msm_structured_2_20(ctx, orc):
+    """Full-size schedule (c = 16, 128-point segments) on the inputs that stress it: every point in one bucket per
+    window (closed form: bases are [tau^i]G, so MSM(s, s, ..) = [s (tau^n - 1)/(tau - 1)]G) and the 25 % zeros /
+    25 % ones / 50 % uniform mix of SURVEY.md §8d against the CPU oracle."""
+    from pyref.prng import fr_array
+    n = 1 << 20
+    tau = h2i(golden("msm.json")["tau"])
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, tau, G)
+    bh = ctx.srs_upload(bases)
+    geo = (pow(tau, n, R) - 1) * pow(tau - 1, -1, R) % R
+    for s in (1, R - 1, 0xDEADBEEFCAFEBABE1234567):
+        sc = np.ascontiguousarray(np.tile(ints_to_limbs([s], 4), (n, 1)))
+        want = orc.fixed_base_mul(G, ints_to_limbs([s * geo % R], 4), threads=1)
+        want_aff = orc.points_from_mont(np.ascontiguousarray(want.reshape(1, 12)))[0]
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == want_aff, hex(s)
+    st = fr_array(n, 77)
+    st[0::4] = 0
+    st[1::4] = 0
+    st[1::4, 0] = 1
+    ref = orc.jac_to_affine_int(orc.msm(bases, st, threads=8))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, st)) == ref
+    bh.free()
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def test_ntt_golden(ctx, orc):
     g = golden("ntt.json")
@@ -225,6 +264,34 @@ def test_ntt_roundtrip_2_22(ctx, orc):
     ctx.ntt_fr_dev(d, log_n, True, True)
     assert np.array_equal(d.download(x.shape), x)
     d.free()
+
+
+def test_ntt_roundtrip_2_24_and_linearity(ctx, orc):
+    """BASELINE sizes beyond what the CPU oracle finishes quickly: inverse(forward(x)) == x at 2^24, and
+    NTT(x + y) == NTT(x) + NTT(y) at 2^22 (additions on the CPU oracle)."""
+    from pyref.prng import fr_array
+    from oracle_lib import p64
+    x = np.ascontiguousarray(np.tile(fr_array(1 << 20, 324), (16, 1)))
+    x[:, 0] ^= np.arange(x.shape[0], dtype=np.uint64)  # break the period of the tiling
+    x[:, 3] &= np.uint64((1 << 60) - 1)                 # keep every element < r
+    d = ctx.to_device(x)
+    ctx.ntt_fr_dev(d, 24, False, False)
+    ctx.ntt_fr_dev(d, 24, True, False)
+    assert np.array_equal(d.download(x.shape), x)
+    d.free()
+    n = 1 << 22
+    a, b = fr_array(n, 401), fr_array(n, 402)
+    c = np.empty_like(a)
+    orc.lib.oracle_fr_add(p64(a), p64(b), p64(c), n)
+    outs = []
+    for v in (a, b, c):
+        dv = ctx.to_device(v)
+        ctx.ntt_fr_dev(dv, 22, False, True)
+        outs.append(dv.download(v.shape))
+        dv.free()
+    s = np.empty_like(a)
+    orc.lib.oracle_fr_add(p64(outs[0]), p64(outs[1]), p64(s), n)
+    assert np.array_equal(s, outs[2])
 
 
 # ------------------------------------------------------------------------------------------------ K3 / K4

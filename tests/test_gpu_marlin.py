@@ -108,6 +108,21 @@ def test_prove_verify_roundtrip(M, S, W, log_n):
     srs.free()
 
 
+def test_prove_verify_2_22(M, S, W):
+    """BASELINE configs[3]: 2^22 constraints (|H| = |K| = 2^22, 12.6 M SRS powers, ~10 GB proving key)."""
+    n = 1 << 22
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 0xfeedface, 0x0badcafe)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
+    proof = M.generate_proof(cs, pk, rng)
+    assert len(proof.data) == 951
+    assert M.verify_proof(vk, public, proof, M.generate_rand())
+    assert not M.verify_proof(vk, [public[1], public[0]], proof, M.generate_rand())
+    pk.free()
+
+
 def test_proving_key_roundtrip(M, S, W):
     n = 1 << 10
     rng = M.generate_rand()
