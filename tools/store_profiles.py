@@ -19,7 +19,7 @@ for name, launches, log, cmd in (("prove", 75, "prof_prove", "--steps 5 --warmup
     r["bench_line_of_the_profiled_run"] = {"avg_launch_ms": b["roofline"]["avg_launch_ms"], "ms_per_step": b["ms_per_step"],
                                            "value": b["value"], "unit": b["unit"]}
     r["command"] = "rocprofv3 --kernel-trace --stats -- python3 bench.py %s --no-cpu-baseline" % cmd
-    r["note"] = ("HIP-event average inside bench.py and the rocprofv3 trace of the SAME run agree; kernels run ~5 % slower "
+    r["note"] = ("HIP-event average inside bench.py and the rocprofv3 trace of the SAME run agree; kernels run ~5 %% slower "
                  "with the profiler attached than in the unprofiled bench lines (%s_bench_*.json)" % pre)
     json.dump(r, open(os.path.join(p, "%s_%s_2p20_timed_region.json" % (pre, name)), "w"), indent=1)
     print(name, "rocprof", round(r["avg_ms_timed_region"], 4), "bench events", b["roofline"]["avg_launch_ms"])
