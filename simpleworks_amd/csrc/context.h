@@ -45,7 +45,7 @@ struct swm_ctx {
     // NTT root tables keyed by (log_n << 1 | inverse); coset tables keyed by inverse flag
     std::map<uint64_t, swm::NttTables> ntt_tables;
     std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
-    // asynchronous MSM lanes: two auxiliary streams, a fork event, pinned result slots with their completion events
+    // asynchronous MSM lanes: auxiliary streams (the prover alternates between two of them), a fork event, pinned result slots with their completion events
     static constexpr int MSM_SLOTS = 8;
     static constexpr int MSM_LANES = 4;
     hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};

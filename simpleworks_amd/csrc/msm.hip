@@ -627,7 +627,7 @@ int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* 
 // msm_enqueue launches every kernel of one MSM plus the download of its window sums WITHOUT host synchronisation;
 // msm_finish waits for that download and does the host Horner fold.  `lane` selects the stream + device scratch set:
 //   lane < 0 : the context's own stream (what the K1 ABI entry points use);
-//   lane 0/1 : two auxiliary streams that first wait for everything enqueued on the context's stream so far.
+//   lane >= 0: one of MSM_LANES auxiliary streams; it first waits for everything enqueued on the context's stream so far.
 // The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
@@ -642,7 +642,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
-    // buckets per lane in the reduction: at most 8 workgroups per window (the host folds one (A, R) pair per workgroup)
+    // buckets per lane in the reduction: at most 16 workgroups per window (the host folds one (A, R) pair per workgroup)
     unsigned log_m = 2;
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > 16) log_m++;  // 16 (A, R) pairs per window fit a result slot
