@@ -68,7 +68,7 @@ int swm_srs_upload(swm_ctx *ctx, const uint64_t *xy, size_t n, swm_bases **out);
 int swm_srs_free(swm_ctx *ctx, swm_bases *bases);
 size_t swm_srs_len(const swm_bases *bases);
 /* out_jac = sum_i scalars[i] * bases[offset + i].  scalars: n x 4 limbs, STANDARD form (what arkworks passes:
- * p.coeffs.map(|s| s.into_repr())), host memory. */
+ * p.coeffs.map(|s| s.into_repr())), host memory; every scalar must be a canonical field element (< r). */
 int swm_msm_g1(swm_ctx *ctx, const swm_bases *bases, size_t offset, const uint64_t *scalars, size_t n,
                uint64_t out_jac[18]);
 /* same with the scalars already in HBM; scalars_montgomery != 0 means they are Montgomery-form Fr (polynomial
