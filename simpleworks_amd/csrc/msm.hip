@@ -37,7 +37,7 @@ namespace swm {
 static constexpr int SEG_MAX = 128;     // points per accumulation segment: upper bound, chosen per MSM (msm_seg_bound)
 static constexpr int BIG_NSEG = 16;     // buckets with more segments than this are folded by a whole workgroup
 static constexpr int RED_BLOCK = 256;
-static constexpr uint32_t SORT_TILE = 65536;  // digits per workgroup in the LDS-privatised counting sort
+static constexpr uint32_t SORT_TILE_MIN = 65536;  // digits per workgroup in the LDS-privatised counting sort (at least)
 static constexpr int SORT_THREADS = 1024;
 
 WinLayout msm_plan(size_t n) {
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars
 
 // Counting sort, pass 1: per-(tile, window) histogram in LDS, one global atomic per non-empty LDS bin.
 __global__ void __launch_bounds__(SORT_THREADS) msm_hist(const uint32_t* __restrict__ digits, size_t n, WinLayout L,
-                                                         uint32_t* __restrict__ hist) {
+                                                         uint32_t SORT_TILE, uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t lh[];
     const uint32_t w = blockIdx.y;
     const uint32_t B = 1u << (L.c[w] - 1), boff = L.boff[w];
@@ -119,9 +119,14 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_hist(const uint32_t* __restr
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lh[b] = 0;
     __syncthreads();
     const uint32_t* d = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        uint32_t code = d[i];
-        if (code) atomicAdd(&lh[(code - 1) >> 1], 1u);
+    // four independent loads in flight per lane: the loop is bound by load latency, not by bandwidth
+    for (size_t i = lo + threadIdx.x; i < hi; i += 4 * SORT_THREADS) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? d[i + u * SORT_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u]) atomicAdd(&lh[(c[u] - 1) >> 1], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_hist(const uint32_t* __restr
 // Counting sort, pass 2: the tile reserves a contiguous run in every bucket it touches (one returning global
 // atomic per non-empty bin), then ranks its digits with LDS atomics and writes (point index | sign).
 __global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __restrict__ digits, size_t n, WinLayout L,
-                                                            const uint32_t* __restrict__ bucket_off,
+                                                            uint32_t SORT_TILE, const uint32_t* __restrict__ bucket_off,
                                                             uint32_t* __restrict__ cursor,
                                                             uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lh[];
@@ -143,22 +148,36 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __re
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lh[b] = 0;
     __syncthreads();
     const uint32_t* d = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        uint32_t code = d[i];
-        if (code) atomicAdd(&lh[(code - 1) >> 1], 1u);
+    for (size_t i = lo + threadIdx.x; i < hi; i += 4 * SORT_THREADS) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? d[i + u * SORT_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u]) atomicAdd(&lh[(c[u] - 1) >> 1], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) {
-        uint32_t v = lh[b];
-        if (v) lh[b] = bucket_off[boff + b] + atomicAdd(&cursor[boff + b], v);
+    for (uint32_t b = threadIdx.x; b < B; b += 4 * SORT_THREADS) {  // four returning global atomics in flight per lane
+        uint32_t v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = b + u * SORT_THREADS < B ? lh[b + u * SORT_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = v[u] ? atomicAdd(&cursor[boff + b + u * SORT_THREADS], v[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (v[u]) lh[b + u * SORT_THREADS] = bucket_off[boff + b + u * SORT_THREADS] + r[u];
     }
     __syncthreads();
-    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        uint32_t code = d[i];
-        if (code) {
-            uint32_t pos = atomicAdd(&lh[(code - 1) >> 1], 1u);
-            sorted[pos] = (uint32_t)i | (((code - 1) & 1u) << 31);
-        }
+    for (size_t i = lo + threadIdx.x; i < hi; i += 4 * SORT_THREADS) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? d[i + u * SORT_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u]) {
+                uint32_t pos = atomicAdd(&lh[(c[u] - 1) >> 1], 1u);
+                sorted[pos] = (uint32_t)(i + u * SORT_THREADS) | (((c[u] - 1) & 1u) << 31);
+            }
     }
 }
 
@@ -715,17 +734,20 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits);
+    // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
+    uint32_t SORT_TILE = SORT_TILE_MIN;
+    if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
     unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
     size_t lds_sort = (size_t)pl.maxB * 4;
     SWM_TRY(allow_big_lds(ctx, (const void*)msm_hist, lds_sort));
     SWM_TRY(allow_big_lds(ctx, (const void*)msm_scatter, lds_sort));
-    SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, hist);
+    SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, SORT_TILE, hist);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
                scan_tiles, bucket_off, seg_off, big_count, big_list);
     SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
-               bucket_off, cursor, sorted);
+               SORT_TILE, bucket_off, cursor, sorted);
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                SEG, seg_start, seg_len, len_hist);
