@@ -56,17 +56,29 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
     const uint64_t j0 = (uint64_t)blockIdx.x * J;
     const uint64_t ns_mask = (1ull << a.log_ns) - 1;
     const unsigned tw_shift = a.log_n - a.log_ns - a.log_r;  // w_{Ns R} = w_n^(2^tw_shift)
-    // ---- load (+ inter-pass twiddle, + coset scaling)
-    for (unsigned e = threadIdx.x; e < R * J; e += NTT_THREADS) {
-        unsigned jj = e % J, t = e / J;
-        uint64_t idx = j0 + jj + (uint64_t)t * stride;
-        Fr x = a.src[idx];
-        if (a.coset_in) x = fp_mul(x, two_level_pow(a.cs_lo, a.cs_hi, idx));
-        if (a.log_ns != 0 && t != 0) {
-            uint64_t k = (j0 + jj) & ns_mask;
-            if (k) x = fp_mul(x, two_level_pow(a.tw_lo, a.tw_hi, (k * t) << tw_shift));
+    // ---- load (+ inter-pass twiddle, + coset scaling).  A tile has at most 1024 elements (ntt_run): four per lane, all
+    // four global loads issued before the first twiddle multiplication so that their latencies overlap.
+    {
+        Fr xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned e = threadIdx.x + u * NTT_THREADS;
+            if (e < R * J) xs[u] = a.src[j0 + e % J + (uint64_t)(e / J) * stride];
         }
-        tile[t * J + jj] = x;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned e = threadIdx.x + u * NTT_THREADS;
+            if (e >= R * J) break;
+            unsigned jj = e % J, t = e / J;
+            uint64_t idx = j0 + jj + (uint64_t)t * stride;
+            Fr x = xs[u];
+            if (a.coset_in) x = fp_mul(x, two_level_pow(a.cs_lo, a.cs_hi, idx));
+            if (a.log_ns != 0 && t != 0) {
+                uint64_t k = (j0 + jj) & ns_mask;
+                if (k) x = fp_mul(x, two_level_pow(a.tw_lo, a.tw_hi, (k * t) << tw_shift));
+            }
+            tile[t * J + jj] = x;
+        }
     }
     __syncthreads();
     // ---- r radix-2 DIF levels in LDS (natural in, bit-reversed rows out)
