@@ -89,7 +89,7 @@ class ConstraintSystem:
                 for coeff, var in row:
                     col = self._col(var)
                     acc[col] = (acc.get(col, 0) + coeff) % R
-                out.append([(v, c) for c, v in acc.items() if v != 0])
+                out.append([(acc[c], c) for c in sorted(acc) if acc[c] != 0])  # LCs are kept sorted by variable
             return out
         return conv(self.a), conv(self.b), conv(self.c)
 
@@ -984,4 +984,40 @@ def synthetic_circuit(n, a, b):
     for _ in range(n - 1):
         cs.enforce_constraint([(1, va)], [(1, vb)], [(1, vc)])
     cs.enforce_constraint([(1, vc)], [(1, vb)], [(1, vd)])
+    return cs
+
+
+def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12):
+    """A small circuit with multi-term linear combinations, several public inputs, |K| != |H| and more non-zeros in B
+    than in A (so that the indexer's balance_matrices swap is taken): every row is
+    (sum of 1-3 terms) * (sum of 2-4 terms) = fresh product witness.  random.Random(seed) drives the shape, so the
+    product-side builder (simpleworks_amd/workloads.py) lays out the identical system."""
+    import random
+    rnd = random.Random(seed)
+    cs = ConstraintSystem()
+    vars_, vals = [cs.one()], [1]
+    for _ in range(num_inputs):
+        v = rnd.randrange(R)
+        vars_.append(cs.new_input_variable(v))
+        vals.append(v)
+    for _ in range(free_witnesses):
+        v = rnd.randrange(R)
+        vars_.append(cs.new_witness_variable(v))
+        vals.append(v)
+    for _ in range(num_constraints):
+        def lc(lo, hi):
+            terms, total = [], 0
+            for _ in range(rnd.randint(lo, hi)):
+                k = rnd.randrange(len(vars_))
+                coeff = rnd.choice([1, 2, R - 1, rnd.randrange(R)])
+                terms.append((coeff, vars_[k]))
+                total = (total + coeff * vals[k]) % R
+            return terms, total
+        a, va = lc(1, 3)
+        b, vb = lc(2, 4)
+        prod = va * vb % R
+        w = cs.new_witness_variable(prod)
+        vars_.append(w)
+        vals.append(prod)
+        cs.enforce_constraint(a, b, [(1, w)])
     return cs

@@ -2,6 +2,7 @@
 
 manual_constraints_circuit  config #1: /root/reference/examples/manual-constraints.rs:15-31 — one public input a, one
                             witness b, one row (a - b) * 1 = 0.
+random_sparse_circuit       parity case beyond the BASELINE shapes: multi-term rows, 5 public inputs, |K| != |H|, nnz(B) > nnz(A).
 synthetic_r1cs              configs #2-#4: the ark-marlin test/bench circuit shape — witnesses a, b, public c = a*b and
                             d = c*b, n - 1 rows a*b = c and one row c*b = d, padded with copies of a so that
                             |H| = |K| = n exactly (instance [1, c, d, 0-pad], n - 4 witnesses).  Built with numpy so that
@@ -35,6 +36,41 @@ def synthetic_circuit(n, a, b):
     for _ in range(n - 1):
         cs.enforce_constraint([(1, va)], [(1, vb)], [(1, vc)])
     cs.enforce_constraint([(1, vc)], [(1, vb)], [(1, vd)])
+    return cs
+
+
+def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12):
+    """Small circuit with multi-term linear combinations, several public inputs, |K| != |H| and nnz(B) > nnz(A): rows
+    (1-3 terms) * (2-4 terms) = fresh product witness, shape drawn from random.Random(seed).  The Python model
+    (oracle/pyref/marlin.py) builds the identical system from the same seed; tests/golden/marlin.json holds its proof."""
+    import random
+    rnd = random.Random(seed)
+    cs = ConstraintSystem()
+    vars_, vals = [cs.one()], [1]
+    for _ in range(num_inputs):
+        v = rnd.randrange(R_MODULUS)
+        vars_.append(cs.new_input_variable(v))
+        vals.append(v)
+    for _ in range(free_witnesses):
+        v = rnd.randrange(R_MODULUS)
+        vars_.append(cs.new_witness_variable(v))
+        vals.append(v)
+    for _ in range(num_constraints):
+        def lc(lo, hi):
+            terms, total = [], 0
+            for _ in range(rnd.randint(lo, hi)):
+                k = rnd.randrange(len(vars_))
+                coeff = rnd.choice([1, 2, R_MODULUS - 1, rnd.randrange(R_MODULUS)])
+                terms.append((coeff, vars_[k]))
+                total = (total + coeff * vals[k]) % R_MODULUS
+            return terms, total
+        a, va = lc(1, 3)
+        b, vb = lc(2, 4)
+        prod = va * vb % R_MODULUS
+        w = cs.new_witness_variable(prod)
+        vars_.append(w)
+        vals.append(prod)
+        cs.enforce_constraint(a, b, [(1, w)])
     return cs
 
 

@@ -223,6 +223,13 @@ def gen_marlin():
         run(out_name, cs, (n, n, n), cs.instance[1:])
         out[out_name]["a"] = hx(a)
         out[out_name]["b"] = hx(b)
+    cs = M.random_sparse_circuit(20261002)
+    assert cs.is_satisfied()
+    a_m, b_m, c_m = cs.to_matrices()
+    nnz = max(sum(len(r) for r in m) for m in (a_m, b_m, c_m))
+    nv = len(cs.instance) + len(cs.witness)
+    run("random_sparse", cs, (cs.num_constraints, nv, nnz), cs.instance[1:])
+    out["random_sparse"]["seed"] = 20261002
     dump("marlin.json", out)
 
 

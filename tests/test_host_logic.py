@@ -65,7 +65,7 @@ def _pub(case):
     return [h2i(x) for x in case["public_input"]]
 
 
-@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32"])
+@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32", "random_sparse"])
 def test_verifier_accepts_golden_proofs(name):
     case = golden("marlin.json")[name]
     vk = S.deserialize_verifying_key(bytes.fromhex(case["vk"]))
