@@ -987,7 +987,7 @@ def synthetic_circuit(n, a, b):
     return cs
 
 
-def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12):
+def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12, repeated_rows=0):
     """A small circuit with multi-term linear combinations, several public inputs, |K| != |H| and more non-zeros in B
     than in A (so that the indexer's balance_matrices swap is taken): every row is
     (sum of 1-3 terms) * (sum of 2-4 terms) = fresh product witness.  random.Random(seed) drives the shape, so the
@@ -1004,6 +1004,7 @@ def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=
         v = rnd.randrange(R)
         vars_.append(cs.new_witness_variable(v))
         vals.append(v)
+    rows = []
     for _ in range(num_constraints):
         def lc(lo, hi):
             terms, total = [], 0
@@ -1020,4 +1021,7 @@ def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=
         vars_.append(w)
         vals.append(prod)
         cs.enforce_constraint(a, b, [(1, w)])
+        rows.append((a, b, [(1, w)]))
+    for i in range(repeated_rows):  # more constraints than variables: |H| comes from the row count
+        cs.enforce_constraint(*rows[i % len(rows)])
     return cs

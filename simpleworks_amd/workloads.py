@@ -39,10 +39,10 @@ def synthetic_circuit(n, a, b):
     return cs
 
 
-def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12):
+def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=12, repeated_rows=0):
     """Small circuit with multi-term linear combinations, several public inputs, |K| != |H| and nnz(B) > nnz(A): rows
-    (1-3 terms) * (2-4 terms) = fresh product witness, shape drawn from random.Random(seed).  The Python model
-    (oracle/pyref/marlin.py) builds the identical system from the same seed; tests/golden/marlin.json holds its proof."""
+    (1-3 terms) * (2-4 terms) = fresh product witness, shape drawn from random.Random(seed).  The test suite's
+    reference model builds the identical system from the same arguments; tests/golden/marlin.json holds its proofs."""
     import random
     rnd = random.Random(seed)
     cs = ConstraintSystem()
@@ -55,6 +55,7 @@ def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=
         v = rnd.randrange(R_MODULUS)
         vars_.append(cs.new_witness_variable(v))
         vals.append(v)
+    rows = []
     for _ in range(num_constraints):
         def lc(lo, hi):
             terms, total = [], 0
@@ -71,6 +72,9 @@ def random_sparse_circuit(seed, num_inputs=5, free_witnesses=4, num_constraints=
         vars_.append(w)
         vals.append(prod)
         cs.enforce_constraint(a, b, [(1, w)])
+        rows.append((a, b, [(1, w)]))
+    for i in range(repeated_rows):  # more constraints than variables: |H| comes from the row count
+        cs.enforce_constraint(*rows[i % len(rows)])
     return cs
 
 

@@ -223,13 +223,15 @@ def gen_marlin():
         run(out_name, cs, (n, n, n), cs.instance[1:])
         out[out_name]["a"] = hx(a)
         out[out_name]["b"] = hx(b)
-    cs = M.random_sparse_circuit(20261002)
-    assert cs.is_satisfied()
-    a_m, b_m, c_m = cs.to_matrices()
-    nnz = max(sum(len(r) for r in m) for m in (a_m, b_m, c_m))
-    nv = len(cs.instance) + len(cs.witness)
-    run("random_sparse", cs, (cs.num_constraints, nv, nnz), cs.instance[1:])
-    out["random_sparse"]["seed"] = 20261002
+    for name, kw in (("random_sparse", dict(seed=20261002)),
+                     ("random_tall", dict(seed=77, num_inputs=0, free_witnesses=3, num_constraints=6, repeated_rows=30))):
+        cs = M.random_sparse_circuit(**kw)
+        assert cs.is_satisfied()
+        a_m, b_m, c_m = cs.to_matrices()
+        nnz = max(sum(len(r) for r in m) for m in (a_m, b_m, c_m))
+        nv = len(cs.instance) + len(cs.witness)
+        run(name, cs, (cs.num_constraints, nv, nnz), cs.instance[1:])
+        out[name]["circuit"] = kw
     dump("marlin.json", out)
 
 

@@ -33,7 +33,7 @@ def _affine(orc, xy):
     return orc.points_from_mont(np.ascontiguousarray(xy).reshape(1, 12))[0]
 
 
-@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32", "random_sparse"])
+@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "synthetic_16", "synthetic_32", "random_sparse", "random_tall"])
 def test_golden_proof_bytes(M, S, W, name):
     case = golden("marlin.json")[name]
     orc = Oracle()
@@ -44,8 +44,10 @@ def test_golden_proof_bytes(M, S, W, name):
     assert _affine(orc, srs.power_of_g(1)) == (h2i(case["srs_g1"][0]), h2i(case["srs_g1"][1]))
     if name == "manual_constraints":
         cs = W.manual_constraints_circuit(1, 1)
-    elif name == "random_sparse":  # multi-term rows, 5 public inputs, |K| = 64 != |H| = 32, nnz(B) > nnz(A)
-        cs = W.random_sparse_circuit(case["seed"])
+    elif name.startswith("random_"):
+        # random_sparse: multi-term rows, 5 public inputs, |K| = 64 != |H| = 32, nnz(B) > nnz(A)
+        # random_tall:   no public input (|X| = 1), 36 rows over 10 variables (|H| from the row count)
+        cs = W.random_sparse_circuit(**case["circuit"])
     else:
         cs = W.synthetic_circuit(case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
     assert cs.is_satisfied()
