@@ -30,6 +30,7 @@
 #include "fq28.cuh"
 #include "g1.cuh"
 #include "msm.h"
+#include <atomic>
 
 namespace swm {
 
@@ -618,8 +619,16 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __r
 }
 
 // ---------------------------------------------------------------------------------------------- host driver
-static int allow_big_lds(swm_ctx* ctx, const void* fn, size_t bytes) {
-    if (bytes > 64 * 1024) SWM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+// Kernels that want more than 64 KB of dynamic LDS need the attribute raised once per device; `slot` names the kernel
+// (0 hist, 1 scatter, 2 bucket_reduce) in a small process-wide cache so that the runtime call is not repeated per MSM.
+static int allow_big_lds(swm_ctx* ctx, int slot, const void* fn, size_t bytes) {
+    static std::atomic<size_t> granted[64][3];
+    if (bytes <= 64 * 1024) return SWM_OK;
+    const int dev = ctx->device & 63;
+    if (granted[dev][slot].load(std::memory_order_acquire) >= bytes) return SWM_OK;
+    SWM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    size_t cur = granted[dev][slot].load(std::memory_order_relaxed);
+    while (cur < bytes && !granted[dev][slot].compare_exchange_weak(cur, bytes)) {}
     return SWM_OK;
 }
 
@@ -739,8 +748,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
     unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
     size_t lds_sort = (size_t)pl.maxB * 4;
-    SWM_TRY(allow_big_lds(ctx, (const void*)msm_hist, lds_sort));
-    SWM_TRY(allow_big_lds(ctx, (const void*)msm_scatter, lds_sort));
+    SWM_TRY(allow_big_lds(ctx, 0, (const void*)msm_hist, lds_sort));
+    SWM_TRY(allow_big_lds(ctx, 1, (const void*)msm_scatter, lds_sort));
     SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, SORT_TILE, hist);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
@@ -758,7 +767,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
-    SWM_TRY(allow_big_lds(ctx, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
     SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
                (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
     SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
