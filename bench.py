@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="bracket EVERY kernel launch with HIP events (per-kernel table in the JSON line; costs ~2 %% of a "
+                         "2^20 proof) instead of the dominant kernel only")
     args = ap.parse_args()
 
     import torch
@@ -180,7 +183,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(1 if args.profile_all else 2)  # HIP events around msm_accumulate (roofline) or around everything
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -190,7 +190,9 @@ int swm_set_msm_sharding(swm_ctx *ctx, unsigned rank, unsigned world, swm_allgat
 
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
- * kernel launch is bracketed by hipEventRecord on the stream it is launched on.  swm_profile_json writes
+ * kernel launch is bracketed by hipEventRecord on the stream it is launched on (on = 1), or only the launches of the
+ * dominant kernel msm_accumulate (on = 2: what bench.py times its roofline from; bracketing all ~700 launches of a
+ * 2^20 proof costs ~2 % of the proof).  swm_profile_json writes
  * {"kernels":[{"name":..,"calls":..,"total_ms":..,"avg_ms":..}, ...],
  *  "work":{"msm_calls":..,"msm_points":..,"ntt_calls":..,"ntt_elements":..,"spmv_calls":..,"spmv_rows":..}} into buf. */
 int swm_profile_enable(swm_ctx *ctx, int on);

@@ -84,7 +84,10 @@ static hipEvent_t get_event(swm_ctx* ctx) {
     return e;
 }
 void prof_begin(swm_ctx* ctx, const char* name) {
+    ctx->prof_open = false;
     if (!ctx->profiling) return;
+    if (ctx->profiling == 2 && strcmp(name, "msm_accumulate") != 0) return;  // dominant kernel only
+    ctx->prof_open = true;
     ProfPending p;
     p.name = name;
     p.e0 = get_event(ctx);
@@ -93,7 +96,8 @@ void prof_begin(swm_ctx* ctx, const char* name) {
     ctx->pending.push_back(p);
 }
 void prof_end(swm_ctx* ctx) {
-    if (!ctx->profiling || ctx->pending.empty()) return;
+    if (!ctx->prof_open || ctx->pending.empty()) return;
+    ctx->prof_open = false;
     (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
     if (ctx->pending.size() > 4096) prof_flush(ctx);
 }
@@ -406,7 +410,7 @@ int swm_vec_mul_fr(swm_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t*
 int swm_profile_enable(swm_ctx* ctx, int on) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
     if (!on) prof_flush(ctx);
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 2 ? 2 : (on != 0);
     return SWM_OK;
 }
 int swm_profile_reset(swm_ctx* ctx) {

@@ -57,7 +57,8 @@ struct swm_ctx {
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
     uint64_t stat_msm_calls = 0, stat_msm_points = 0, stat_ntt_calls = 0, stat_ntt_elems = 0, stat_spmv_calls = 0,
              stat_spmv_rows = 0;
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every launch, 2 the dominant kernel (msm_accumulate) only
+    bool prof_open = false;
     std::map<std::string, swm::ProfAgg> prof;
     std::vector<swm::ProfPending> pending;
     std::vector<hipEvent_t> event_pool;
