@@ -231,3 +231,29 @@ def test_sharded_prover_matches_single_context_at_2p14(M, S, W):
         assert vk_b == vk1
         assert proof_b == proof1
     assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
+
+
+def test_interleaved_keys_on_one_context(M, S, W):
+    """Several proving keys of different shapes alive on one context, proofs issued alternately: scratch buffers, the
+    device pool and the MSM lanes are reused across sizes, results must not depend on what ran before."""
+    rng = M.generate_rand()
+    systems = []
+    for n in (1 << 10, 1 << 12):
+        srs = M.generate_universal_srs(n, n, n, rng)
+        cs, public = W.synthetic_r1cs(n, 0x51 + n, 0x77)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        systems.append((cs, public, pk, vk))
+    case = golden("marlin.json")["random_sparse"]
+    cs = W.random_sparse_circuit(**case["circuit"])
+    srs = M.generate_universal_srs(*case["srs"], M.generate_rand())
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
+    systems.append((cs, [h2i(x) for x in case["public_input"]], pk, vk))
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]
+    for _ in range(3):
+        for cs, public, pk, vk in systems:
+            proof = M.generate_proof(cs, pk, rng)
+            assert M.verify_proof(vk, public, proof, M.generate_rand())
+    for _, _, pk, _ in systems:
+        pk.free()
