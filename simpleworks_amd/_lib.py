@@ -280,6 +280,10 @@ class Context:
                                          _p64(out), rows, col.shape[0]), "swm_spmv_fr")
         return out
 
+    def spmv_fr_dev(self, d_rowptr, d_col, d_val, d_z, d_out, rows):
+        self._check(self.lib.swm_spmv_fr_dev(self.h, d_rowptr.ptr, d_col.ptr, d_val.ptr, d_z.ptr, d_out.ptr, rows),
+                    "swm_spmv_fr_dev")
+
     # ---- K4
     def batch_inverse_fr(self, data_mont):
         d = np.ascontiguousarray(data_mont, dtype=np.uint64).reshape(-1, 4).copy()

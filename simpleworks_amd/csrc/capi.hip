@@ -12,8 +12,9 @@
 namespace swm {
 
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+struct SpmvPlan;
 int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
-             size_t rows);
+             size_t rows, const SpmvPlan* plan = nullptr);
 int vec_mul_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n);
 int batch_inverse_run(swm_ctx* ctx, void* d, size_t n);
 int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void* out, size_t n);

@@ -15,8 +15,22 @@
 namespace swm {
 
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+// What is known about a CSR matrix once its row pointers have been seen on the host (spmv.hip): the longest row picks the
+// schedule; rows longer than the direct kernel handles are pre-cut into chunks (row, start, length) with one
+// (row, first chunk, chunk count) record per long row.
+struct SpmvPlanHost {
+    uint64_t nnz = 0, max_row = 0;
+    std::vector<uint32_t> chunks, lrows;
+};
+struct SpmvPlan {
+    uint64_t nnz = 0, max_row = 0;
+    const uint32_t* d_chunks = nullptr;
+    const uint32_t* d_lrows = nullptr;
+    uint32_t n_chunks = 0, n_lrows = 0;
+};
+void spmv_plan_build(const uint32_t* rowptr, size_t rows, SpmvPlanHost* plan);
 int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
-             size_t rows);
+             size_t rows, const SpmvPlan* plan = nullptr);
 int batch_inverse_run(swm_ctx* ctx, void* d, size_t n);
 
 inline void hip_check(swm_ctx* ctx, hipError_t e, const char* what) {

@@ -54,6 +54,8 @@ struct DevCsr {
     DBuf<uint32_t> rowptr, col;
     DVec val;
     size_t rows = 0, nnz = 0;
+    DBuf<uint32_t> plan_chunks, plan_lrows;  // SpMV plan recorded at upload (spmv.hip): no read-back inside a proof
+    SpmvPlan plan;
 };
 struct MatrixArith {
     DVec row, col, val, row_col;          // coefficient vectors (length K)
@@ -295,6 +297,20 @@ DevCsr upload_csr(swm_ctx* ctx, const HostCsr& m) {
     DevCsr d;
     d.rows = m.rows();
     d.nnz = m.nnz();
+    SpmvPlanHost ph;
+    spmv_plan_build(m.rowptr.data(), d.rows, &ph);
+    d.plan.nnz = ph.nnz;
+    d.plan.max_row = ph.max_row;
+    d.plan.n_chunks = (uint32_t)(ph.chunks.size() / 3);
+    d.plan.n_lrows = (uint32_t)(ph.lrows.size() / 3);
+    if (d.plan.n_chunks) {
+        d.plan_chunks = DBuf<uint32_t>(ctx, ph.chunks.size());
+        d.plan_chunks.upload(ph.chunks.data(), ph.chunks.size());
+        d.plan_lrows = DBuf<uint32_t>(ctx, ph.lrows.size());
+        d.plan_lrows.upload(ph.lrows.data(), ph.lrows.size());
+        d.plan.d_chunks = d.plan_chunks.p;
+        d.plan.d_lrows = d.plan_lrows.p;
+    }
     d.rowptr = DBuf<uint32_t>(ctx, m.rowptr.size());
     d.rowptr.upload(m.rowptr.data(), m.rowptr.size());
     d.col = DBuf<uint32_t>(ctx, std::max<size_t>(m.nnz(), 1));
@@ -758,8 +774,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         ew(ctx, "z_pad", pr.nwit - pr.nwit_orig, [=] __device__(size_t i) { zp[i] = fp_one<Fr>(); });
     }
     DVec za_evals = dv_zeros(ctx, H), zb_evals = dv_zeros(ctx, H);
-    rc_check(ctx, spmv_run(ctx, pk.a.rowptr.p, pk.a.col.p, pk.a.val.p, z.p, za_evals.p, pk.a.rows));
-    rc_check(ctx, spmv_run(ctx, pk.b.rowptr.p, pk.b.col.p, pk.b.val.p, z.p, zb_evals.p, pk.b.rows));
+    rc_check(ctx, spmv_run(ctx, pk.a.rowptr.p, pk.a.col.p, pk.a.val.p, z.p, za_evals.p, pk.a.rows, &pk.a.plan));
+    rc_check(ctx, spmv_run(ctx, pk.b.rowptr.p, pk.b.col.p, pk.b.val.p, z.p, zb_evals.p, pk.b.rows, &pk.b.plan));
 
     tr.mark("upload z, z_A, z_B");
     // ================= round 1
@@ -894,9 +910,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     DVec t_poly = dv_zeros(ctx, H);
     {
         DVec ta(ctx, nvars), tb(ctx, nvars), tc(ctx, nvars);
-        rc_check(ctx, spmv_run(ctx, pk.at.rowptr.p, pk.at.col.p, pk.at.val.p, r_alpha_evals.p, ta.p, nvars));
-        rc_check(ctx, spmv_run(ctx, pk.bt.rowptr.p, pk.bt.col.p, pk.bt.val.p, r_alpha_evals.p, tb.p, nvars));
-        rc_check(ctx, spmv_run(ctx, pk.ct.rowptr.p, pk.ct.col.p, pk.ct.val.p, r_alpha_evals.p, tc.p, nvars));
+        rc_check(ctx, spmv_run(ctx, pk.at.rowptr.p, pk.at.col.p, pk.at.val.p, r_alpha_evals.p, ta.p, nvars, &pk.at.plan));
+        rc_check(ctx, spmv_run(ctx, pk.bt.rowptr.p, pk.bt.col.p, pk.bt.val.p, r_alpha_evals.p, tb.p, nvars, &pk.bt.plan));
+        rc_check(ctx, spmv_run(ctx, pk.ct.rowptr.p, pk.ct.col.p, pk.ct.val.p, r_alpha_evals.p, tc.p, nvars, &pk.ct.plan));
         Fr* out = t_poly.p;
         const Fr *pa = ta.p, *pb = tb.p, *pc = tc.p;
         ew(ctx, "t_evals", nvars, [=] __device__(size_t c) {
@@ -1328,9 +1344,9 @@ void is_satisfied_impl(swm_ctx* ctx, const swm_r1cs* cs, int* ok, size_t* first_
     hip_check(ctx, hipMemcpyAsync(z.p, cs->instance, ninst * 32, hipMemcpyHostToDevice, ctx->stream), "h2d");
     if (nwit) hip_check(ctx, hipMemcpyAsync(z.p + ninst, cs->witness, nwit * 32, hipMemcpyHostToDevice, ctx->stream), "h2d");
     DVec za(ctx, std::max<size_t>(rows, 1)), zb(ctx, std::max<size_t>(rows, 1)), zc(ctx, std::max<size_t>(rows, 1));
-    rc_check(ctx, spmv_run(ctx, da.rowptr.p, da.col.p, da.val.p, z.p, za.p, rows));
-    rc_check(ctx, spmv_run(ctx, db.rowptr.p, db.col.p, db.val.p, z.p, zb.p, rows));
-    rc_check(ctx, spmv_run(ctx, dc.rowptr.p, dc.col.p, dc.val.p, z.p, zc.p, rows));
+    rc_check(ctx, spmv_run(ctx, da.rowptr.p, da.col.p, da.val.p, z.p, za.p, rows, &da.plan));
+    rc_check(ctx, spmv_run(ctx, db.rowptr.p, db.col.p, db.val.p, z.p, zb.p, rows, &db.plan));
+    rc_check(ctx, spmv_run(ctx, dc.rowptr.p, dc.col.p, dc.val.p, z.p, zc.p, rows, &dc.plan));
     DBuf<unsigned long long> bad(ctx, 1);
     unsigned long long init = ~0ull;
     bad.upload(&init, 1);

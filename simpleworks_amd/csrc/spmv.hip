@@ -6,19 +6,99 @@
 //
 // R1CS matrices are extremely ragged: gadget rows hold 0-3 non-zeros (src/gadgets/uint8.rs:117-118) while the
 // transposed matrices have a few rows with ~|H| entries (the constant-one column, a variable used by every row).
-// A row-per-lane CSR kernel serialises on those rows (measured: 1.4 s of a 1.57 s prove at 2^20), so the kernel is
-// non-zero-parallel instead, using the fact that (Fr, +) is a group:
-//     1. prod[k] = val[k] * z[col[k]]                     one lane per non-zero, coalesced val/col, gathered z
-//     2. T = suffix sums of prod                           blocked two-pass scan (devops.cuh suffix_recurrence)
-//     3. out[r] = T[rowptr[r]] - T[rowptr[r+1]]            one lane per row
-// Every step is balanced whatever the row-length distribution.  HBM-bound integer work, no LDS, no MFMA.
+// Two schedules, chosen per matrix from its longest row:
+//   * every row <= SPMV_DIRECT_MAX non-zeros (A, B, C of gadget-built systems): one lane per row, the row's products
+//     summed in registers — one launch, coalesced val/col, gathered z;
+//   * otherwise non-zero-parallel (a row-per-lane kernel serialised on the long rows: measured 1.4 s of a 1.57 s prove
+//     at 2^20), using the fact that (Fr, +) is a group:
+//       1. prod[k] = val[k] * z[col[k]]                     one lane per non-zero
+//       2. T = suffix sums of prod                           blocked scan (devops.cuh suffix_recurrence)
+//       3. out[r] = T[rowptr[r]] - T[rowptr[r+1]]            one lane per row
+//     balanced whatever the row-length distribution (the fallback when nothing is known about the matrix);
+//   * with a plan built when the matrix was uploaded (the prover's A, B, C and their transposes): short rows by the
+//     row-per-lane kernel, each long row cut into 2048-entry chunks that one workgroup each reduces in LDS, and a
+//     last kernel that adds a row's chunk sums — three launches instead of nine for the transposes.
+// Field addition is exact, so both schedules give identical bits.  HBM-bound integer work, no MFMA.
 // Algorithmic bytes: 68 B per non-zero + 36 B per row.
 #include "devops.cuh"
 
 namespace swm {
 
+static constexpr uint32_t SPMV_DIRECT_MAX = 64;
+
+__global__ void __launch_bounds__(256) spmv_row_stats(const uint32_t* __restrict__ rowptr, size_t rows,
+                                                      uint32_t* __restrict__ stats /* [0] = nnz, [1] = longest row */) {
+    size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    uint32_t len = r < rows ? rowptr[r + 1] - rowptr[r] : 0;
+    for (int off = 32; off > 0; off >>= 1) len = max(len, (uint32_t)__shfl_down((int)len, off));
+    if ((threadIdx.x & 63) == 0 && len) atomicMax(&stats[1], len);
+    if (r == 0) stats[0] = rowptr[rows];
+}
+
+static constexpr uint32_t SPMV_CHUNK = 2048;
+static constexpr int SPMV_BLOCK = 256;
+
+__device__ __forceinline__ Fr block_sum_fr(Fr acc, Fr* sm) {
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned stride = SPMV_BLOCK / 2; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) sm[threadIdx.x] = fp_add(sm[threadIdx.x], sm[threadIdx.x + stride]);
+        __syncthreads();
+    }
+    return sm[0];
+}
+// one workgroup per chunk (row, start, len <= SPMV_CHUNK): partial[chunk] = sum of its products
+__global__ void __launch_bounds__(SPMV_BLOCK) spmv_long_chunks(const uint32_t* __restrict__ chunks,
+                                                                const uint32_t* __restrict__ col, const Fr* __restrict__ val,
+                                                                const Fr* __restrict__ z, Fr* __restrict__ partial) {
+    __shared__ Fr sm[SPMV_BLOCK];
+    const uint32_t start = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2];
+    Fr acc = fp_zero<Fr>();
+    for (uint32_t k = threadIdx.x; k < len; k += SPMV_BLOCK) {
+        Fr c = val[start + k];
+        Fr zv = z[col[start + k]];
+        acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));
+    }
+    Fr total = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+// one workgroup per long row (row, first_chunk, n_chunks): out[row] = sum of its chunk sums
+__global__ void __launch_bounds__(SPMV_BLOCK) spmv_long_rows(const uint32_t* __restrict__ lrows, const Fr* __restrict__ partial,
+                                                              Fr* __restrict__ out) {
+    __shared__ Fr sm[SPMV_BLOCK];
+    const uint32_t row = lrows[3 * blockIdx.x], first = lrows[3 * blockIdx.x + 1], cnt = lrows[3 * blockIdx.x + 2];
+    Fr acc = fp_zero<Fr>();
+    for (uint32_t k = threadIdx.x; k < cnt; k += SPMV_BLOCK) acc = fp_add(acc, partial[first + k]);
+    Fr total = block_sum_fr(acc, sm);
+    if (threadIdx.x == 0) out[row] = total;
+}
+
+void spmv_plan_build(const uint32_t* rowptr, size_t rows, SpmvPlanHost* plan) {
+    plan->nnz = rowptr[rows];
+    plan->max_row = 0;
+    plan->chunks.clear();
+    plan->lrows.clear();
+    for (size_t r = 0; r < rows; r++) {
+        uint32_t s = rowptr[r], len = rowptr[r + 1] - s;
+        plan->max_row = std::max<uint64_t>(plan->max_row, len);
+        if (len <= SPMV_DIRECT_MAX) continue;
+        uint32_t first = (uint32_t)(plan->chunks.size() / 3), cnt = 0;
+        for (uint32_t o = 0; o < len; o += SPMV_CHUNK, cnt++) {
+            plan->chunks.push_back((uint32_t)r);
+            plan->chunks.push_back(s + o);
+            plan->chunks.push_back(std::min(SPMV_CHUNK, len - o));
+        }
+        plan->lrows.push_back((uint32_t)r);
+        plan->lrows.push_back(first);
+        plan->lrows.push_back(cnt);
+    }
+}
+
+// plan == nullptr: nothing is known about the matrix (the K3 ABI entry points) -> one small kernel + read-back picks
+// between the direct and the scan schedule; the prover passes the plan it recorded when the matrix was uploaded, so no
+// host synchronisation happens inside a proof.
 int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
-             size_t rows) {
+             size_t rows, const SpmvPlan* plan) {
     if (rows == 0) return SWM_OK;
     try {
         ctx->stat_spmv_calls++;
@@ -28,16 +108,58 @@ int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* 
         const Fr* val = (const Fr*)d_val;
         const Fr* z = (const Fr*)d_z;
         Fr* out = (Fr*)d_out;
-        uint32_t nnz = 0;
-        hip_check(ctx, hipMemcpyAsync(&nnz, rowptr + rows, 4, hipMemcpyDeviceToHost, ctx->stream), "d2h");
-        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        uint32_t nnz, max_row;
+        if (plan) {
+            nnz = (uint32_t)plan->nnz;
+            max_row = (uint32_t)plan->max_row;
+        } else {
+            DBuf<uint32_t> stats(ctx, 2);
+            stats.zero();
+            SWM_LAUNCH(ctx, "spmv_row_stats", spmv_row_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, rowptr, rows,
+                       stats.p);
+            std::vector<uint32_t> h = stats.download(0, 2);
+            nnz = h[0];
+            max_row = h[1];
+        }
+        if (plan && max_row > SPMV_DIRECT_MAX) {
+            // short rows directly (long ones are skipped), long rows by chunks
+            ew(ctx, "spmv_rows_direct", rows, [=] __device__(size_t r) {
+                uint32_t k = rowptr[r], e = rowptr[r + 1];
+                if (e - k > SPMV_DIRECT_MAX) return;
+                Fr acc = fp_zero<Fr>();
+                for (; k < e; k++) {
+                    Fr c = val[k];
+                    Fr zv = z[col[k]];
+                    acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));
+                }
+                out[r] = acc;
+            });
+            DVec partial(ctx, plan->n_chunks);
+            SWM_LAUNCH(ctx, "spmv_long_chunks", spmv_long_chunks, dim3(plan->n_chunks), dim3(SPMV_BLOCK), 0, plan->d_chunks, col, val,
+                       z, partial.p);
+            SWM_LAUNCH(ctx, "spmv_long_rows", spmv_long_rows, dim3(plan->n_lrows), dim3(SPMV_BLOCK), 0, plan->d_lrows,
+                       (const Fr*)partial.p, out);
+            return SWM_OK;
+        }
+        if (max_row <= SPMV_DIRECT_MAX) {
+            ew(ctx, "spmv_rows_direct", rows, [=] __device__(size_t r) {
+                Fr acc = fp_zero<Fr>();
+                for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) {
+                    Fr c = val[k];
+                    Fr zv = z[col[k]];
+                    acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));  // coeff.is_one() shortcut as in prover_init
+                }
+                out[r] = acc;
+            });
+            return SWM_OK;
+        }
         DVec prod(ctx, (size_t)nnz + 1);
         Fr* pp = prod.p;
         ew(ctx, "spmv_products", (size_t)nnz + 1, [=] __device__(size_t k) {
             if (k < nnz) {
                 Fr c = val[k];
                 Fr zv = z[col[k]];
-                pp[k] = fp_is_one(c) ? zv : fp_mul(zv, c);  // coeff.is_one() shortcut as in prover_init
+                pp[k] = fp_is_one(c) ? zv : fp_mul(zv, c);
             } else {
                 pp[k] = fp_zero<Fr>();  // T[nnz] = 0
             }
