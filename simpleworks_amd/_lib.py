@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswmarlin.so")
+LIB_PATH = os.environ.get("SWM_LIB_PATH") or os.path.join(_HERE, "libswmarlin.so")  # override: A/B runs of two builds
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)

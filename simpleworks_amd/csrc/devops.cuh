@@ -192,6 +192,29 @@ static __global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
 // Lanes own 8 consecutive elements; tiles travel through a padded LDS image so that global traffic stays coalesced.
 static constexpr int RT_PER = 8;
 static constexpr int RT_TILE = 256 * RT_PER;
+// out[i] = base^i, i < 256, built on the device from the eight squarings base^(2^b) (passed by value): a host-built
+// table would have to be uploaded and waited for, i.e. a host synchronisation in the middle of a proof.
+struct Pow256Args {
+    Fr sq[8];
+};
+static __global__ void __launch_bounds__(256) pow256_kernel(Pow256Args a, Fr* __restrict__ out) {
+    const unsigned i = threadIdx.x;
+    Fr r = fp_one<Fr>();
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+        if ((i >> b) & 1) r = fp_mul(r, a.sq[b]);
+    out[i] = r;
+}
+// returns base^256
+inline Fr dv_pow256(swm_ctx* ctx, const Fr& base, Fr* d_out) {
+    Pow256Args a;
+    a.sq[0] = base;
+    for (int b = 1; b < 8; b++) a.sq[b] = fp_sqr(a.sq[b - 1]);
+    hipLaunchKernelGGL(pow256_kernel, dim3(1), dim3(256), 0, ctx->stream, a, d_out);
+    hip_check(ctx, hipGetLastError(), "pow256");
+    return fp_sqr(a.sq[7]);
+}
+
 struct RecConsts {
     Fr zpow[RT_PER + 1];  // z^0 .. z^8
     Fr zstep[9];          // (z^8)^(2^k), k = 0..8
@@ -275,12 +298,8 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     for (int i = 1; i <= RT_PER; i++) rc.zpow[i] = fp_mul(rc.zpow[i - 1], z);
     rc.zstep[0] = rc.zpow[RT_PER];
     for (int k = 1; k < 9; k++) rc.zstep[k] = fp_sqr(rc.zstep[k - 1]);
-    std::vector<Fr> low(256);
-    low[0] = fp_one<Fr>();
-    for (int i = 1; i < 256; i++) low[i] = fp_mul(low[i - 1], z);
-    rc.z256 = fp_mul(low[255], z);
     DVec zlow(ctx, 256), totals(ctx, ntiles);
-    zlow.upload(low.data(), 256);
+    rc.z256 = dv_pow256(ctx, z, zlow.p);
     prof_begin(ctx, "rec_tile_total");
     hipLaunchKernelGGL(rec_tile_total, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc, (const Fr*)zlow.p,
                        totals.p);
@@ -381,21 +400,13 @@ struct EvalPoint {
 };
 inline EvalPoint eval_point(swm_ctx* ctx, Fr x) {
     EvalPoint ep;
-    std::vector<Fr> host(3 * 256);
     for (int l = 0; l < 3; l++) {
-        Fr* pw = host.data() + 256 * l;
-        pw[0] = fp_one<Fr>();
-        for (int i = 1; i < 256; i++) pw[i] = fp_mul(pw[i - 1], x);
-        ep.y256[l] = fp_mul(pw[255], x);
+        ep.pw[l] = DVec(ctx, 256);
+        ep.y256[l] = dv_pow256(ctx, x, ep.pw[l].p);
         x = ep.y256[l];
         for (int i = 0; i < 4; i++) x = fp_sqr(x);  // y^(256 * 16)
         static_assert(EVAL_PER == 16, "x exponent");
     }
-    for (int l = 0; l < 3; l++) {
-        ep.pw[l] = DVec(ctx, 256);
-        hip_check(ctx, hipMemcpyAsync(ep.pw[l].p, host.data() + 256 * l, 256 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
-    }
-    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");  // `host` goes out of scope
     return ep;
 }
 // p(x) for a device polynomial, written to the device word *d_result (no host synchronisation)
