@@ -315,6 +315,16 @@ def test_spmv_golden_and_random(ctx, orc):
     val[::3] = one
     z = orc.fr_to_mont(fr_array(cols, 42))
     assert np.array_equal(ctx.spmv_fr(rowptr, col, val, z), orc.spmv(rowptr, col, val, z))
+    # a few very long rows among short ones (the shape of a transposed R1CS matrix): the schedule picked from the longest
+    # row changes, the bits must not
+    cnt = rng.poisson(2, rows).astype(np.uint32)
+    cnt[0], cnt[5], cnt[777], cnt[rows - 1] = 30000, 100, 65, 2049
+    rowptr[1:] = np.cumsum(cnt)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, cols, nnz, dtype=np.uint32)
+    val = orc.fr_to_mont(fr_array(nnz, 43))
+    val[::5] = one
+    assert np.array_equal(ctx.spmv_fr(rowptr, col, val, z), orc.spmv(rowptr, col, val, z))
     # empty matrix
     assert ctx.spmv_fr(np.zeros(5, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros((0, 4), np.uint64), z).sum() == 0
 
@@ -331,6 +341,14 @@ def test_batch_inverse_and_vec_mul(ctx, orc):
     ref = x.copy()
     orc.lib.oracle_batch_inverse_fr(p64(ref), ref.shape[0])
     assert np.array_equal(ctx.batch_inverse_fr(x), ref)
+    # whole lanes / whole workgroups of zeros, a single element, an all-zero vector (zeros stay zero)
+    x2 = orc.fr_to_mont(fr_array(3 * 4096 + 5, 53))
+    x2[32:64] = 0
+    x2[4096:8192] = 0
+    for v in (x2, x2[:1].copy(), np.zeros((77, 4), dtype=np.uint64)):
+        ref = v.copy()
+        orc.lib.oracle_batch_inverse_fr(p64(ref), ref.shape[0])
+        assert np.array_equal(ctx.batch_inverse_fr(v), ref)
     y = orc.fr_to_mont(fr_array(100003, 52))
     ref = np.empty_like(x)
     orc.lib.oracle_fr_mul(p64(x), p64(y), p64(ref), x.shape[0])

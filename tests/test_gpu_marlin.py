@@ -257,3 +257,34 @@ def test_interleaved_keys_on_one_context(M, S, W):
             assert M.verify_proof(vk, public, proof, M.generate_rand())
     for _, _, pk, _ in systems:
         pk.free()
+
+
+def test_long_row_circuit(M, S, W):
+    """A constraint whose left side sums 5000 witnesses: A has one very long row and A^T none, B^T / C^T have long rows
+    through the constant-one and the sum variable — the planned SpMV schedule (row-per-lane + chunked long rows) on both
+    the direct and the transposed side, checked through is_satisfied and a full prove + verify."""
+    import random
+    rnd = random.Random(9)
+    cs = M.ConstraintSystem()
+    ws, total = [], 0
+    for _ in range(5000):
+        v = rnd.randrange(M.R_MODULUS)
+        ws.append(cs.new_witness_variable(v))
+        total = (total + v) % M.R_MODULUS
+    s_pub = cs.new_input_variable(total)
+    cs.enforce_constraint([(1, w) for w in ws], [(1, cs.one())], [(1, s_pub)])
+    for w in ws[:200]:  # many rows sharing the constant-one column: long rows in the transposes
+        cs.enforce_constraint([(1, w)], [(1, cs.one())], [(1, w)])
+    assert cs.is_satisfied()
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(8192, 8192, 8192, rng)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    proof = M.generate_proof(cs, pk, rng)
+    assert M.verify_proof(vk, [total], proof, M.generate_rand())
+    assert not M.verify_proof(vk, [(total + 1) % M.R_MODULUS], proof, M.generate_rand())
+    bad = M.ConstraintSystem()
+    bad.instance, bad.witness, bad.rows = list(cs.instance), list(cs.witness), cs.rows
+    bad.witness[4999] = (bad.witness[4999] + 1) % M.R_MODULUS
+    assert not bad.is_satisfied()
+    pk.free()
+    srs.free()
