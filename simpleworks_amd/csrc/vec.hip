@@ -18,9 +18,84 @@ __global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, 
 
 // Montgomery-trick inversion, two levels (zeros stay zero, like ark_ff::batch_inversion): a lane multiplies up its
 // BINV_CHUNK elements, the workgroup combines the 256 lane products with a prefix and a suffix product scan in LDS,
-// ONE lane pays the Fermat inversion (~380 multiplications) for all 4096 elements, and every lane rebuilds the inverse
+// ONE lane pays the inversion (binary extended Euclid, fr_inv_single) for all 4096 elements, and every lane rebuilds the inverse
 // of its own chunk product as total^-1 x prefix x suffix before walking its chunk backwards.
 // (One inversion per lane made the inversion 89 % of the kernel's multiplications.)
+// Inverse of ONE element by the binary extended Euclidean algorithm (the serial tail of a batch inversion, run by a
+// single lane: its data-dependent branches cost nothing there, and ~500 shift/subtract steps on 8 limbs are 4-5x
+// shorter than the ~380 Montgomery multiplications of a Fermat inversion).  In and out: Montgomery form, a != 0.
+__device__ __forceinline__ bool limbs_is_one(const uint32_t (&x)[8]) {
+    uint32_t acc = x[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; i++) acc |= x[i];
+    return acc == 0;
+}
+__device__ __forceinline__ void limbs_shr1(uint32_t (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[7] >>= 1;
+}
+// x = x / 2 mod p (x < p; p odd; x + p < 2^254 fits the 8 limbs)
+__device__ __forceinline__ void limbs_half_mod(uint32_t (&x)[8]) {
+    if (x[0] & 1u) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)x[i] + FrParams::P[i] + carry;
+            x[i] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+    }
+    limbs_shr1(x);
+}
+__device__ __forceinline__ bool limbs_geq(const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    for (int i = 7; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return true;
+}
+__device__ __forceinline__ void limbs_sub(uint32_t (&a)[8], const uint32_t (&b)[8]) {  // a -= b, a >= b
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)a[i] - b[i] - borrow;
+        a[i] = (uint32_t)t;
+        borrow = (uint32_t)(t >> 63);
+    }
+}
+__device__ __noinline__ Fr fr_inv_single(const Fr a_mont) {
+    uint32_t u[8], v[8];
+    Fr x1 = fp_zero<Fr>(), x2 = fp_zero<Fr>();  // plain integers mod p, kept < p; fp_sub is the modular subtraction
+    x1.v[0] = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u[i] = a_mont.v[i];
+        v[i] = FrParams::P[i];
+    }
+    while (!limbs_is_one(u) && !limbs_is_one(v)) {
+        while ((u[0] & 1u) == 0) {
+            limbs_shr1(u);
+            limbs_half_mod(x1.v);
+        }
+        while ((v[0] & 1u) == 0) {
+            limbs_shr1(v);
+            limbs_half_mod(x2.v);
+        }
+        if (limbs_geq(u, v)) {
+            limbs_sub(u, v);
+            x1 = fp_sub(x1, x2);
+        } else {
+            limbs_sub(v, u);
+            x2 = fp_sub(x2, x1);
+        }
+    }
+    Fr inv_plain = limbs_is_one(u) ? x1 : x2;  // (a R)^-1 as a plain residue = a^-1 R^-1
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = FrParams::R2[i];
+    return fp_mul(fp_mul(inv_plain, r2), r2);    // x R^-1 * R^2 * R^-1 = x; twice: a^-1 R^-1 -> a^-1 -> a^-1 R
+}
+
 static constexpr int BINV_CHUNK = 16;
 static constexpr int BINV_THREADS = 256;
 __global__ void __launch_bounds__(BINV_THREADS) batch_inverse_kernel(Fr* __restrict__ v, size_t n) {
@@ -52,7 +127,7 @@ __global__ void __launch_bounds__(BINV_THREADS) batch_inverse_kernel(Fr* __restr
         if (hs) ss[tid] = fp_mul(ms, b);
         __syncthreads();
     }
-    if (tid == 0) s_inv = fp_inv(ss[0]);  // lane products are never zero (zeros are skipped), so neither is the total
+    if (tid == 0) s_inv = fr_inv_single(ss[0]);  // lane products are never zero (zeros are skipped), so neither is the total
     __syncthreads();
     Fr inv = s_inv;
     if (tid > 0) inv = fp_mul(inv, sp[tid - 1]);
