@@ -671,7 +671,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const size_t total = n * (size_t)pl.nwin;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
     // buckets per lane in the reduction: at most 16 workgroups per window (the host folds one (A, R) pair per workgroup)
-    unsigned log_m = 2;
+    unsigned log_m = pl.maxB <= 2048 ? 0 : 2;  // small windows: one bucket per lane shortens the serial walk (r01 sweep)
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > 16) log_m++;  // 16 (A, R) pairs per window fit a result slot
     unsigned red_blocks = ((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK;
