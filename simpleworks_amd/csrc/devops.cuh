@@ -7,6 +7,7 @@
 // /root/reference/src/marlin/mod.rs:75 reaches (sources not vendored; behaviour from SURVEY.md A.3, A.5-A.7).
 #pragma once
 #include <utility>
+#include <atomic>
 #include "context.h"
 #include "ff.cuh"
 #include "host/chacha.h"
@@ -310,10 +311,10 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     static_assert(RT_TILE == 2048, "tile exponent");
     suffix_recurrence(ctx, totals.p, ntiles, 1, ztile);  // totals[b] <- true value at the first element of tile b
     size_t lds = (size_t)(RT_TILE + 256 + 257) * sizeof(Fr);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[64];  // per device: the attribute belongs to the device's copy of the kernel
+    if (!attr_set[ctx->device & 63].load(std::memory_order_acquire)) {
         hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
-        attr_set = true;
+        attr_set[ctx->device & 63].store(true, std::memory_order_release);
     }
     prof_begin(ctx, "rec_tile_scan");
     hipLaunchKernelGGL(rec_tile_scan, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc, (const Fr*)totals.p, ntiles);
