@@ -25,6 +25,7 @@
 //
 // Algorithmic bytes per point: 96 B base + 32 B scalar = 128 B.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include "context.h"
 #include "fq28.cuh"
@@ -141,9 +142,11 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_hist(const uint32_t* __restr
 __global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __restrict__ digits, size_t n, WinLayout L,
                                                             uint32_t SORT_TILE, const uint32_t* __restrict__ bucket_off,
                                                             uint32_t* __restrict__ cursor,
-                                                            uint32_t* __restrict__ sorted) {
+                                                            uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ two_level_bad /* null: always run */) {
     extern __shared__ uint32_t lh[];
     const uint32_t w = blockIdx.y;
+    if (two_level_bad && two_level_bad[w] == 0) return;  // the two-level scatter below handles this window
     const uint32_t B = 1u << (L.c[w] - 1), boff = L.boff[w];
     const size_t lo = (size_t)blockIdx.x * SORT_TILE, hi = min(lo + (size_t)SORT_TILE, n);
     for (uint32_t b = threadIdx.x; b < B; b += SORT_THREADS) lh[b] = 0;
@@ -180,6 +183,119 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_scatter(const uint32_t* __re
                 sorted[pos] = (uint32_t)(i + u * SORT_THREADS) | (((c[u] - 1) & 1u) << 31);
             }
     }
+}
+
+// ---- two-level scatter for large MSMs
+// The one-level scatter above writes every entry to its final position with a 4-byte store; at ~2 entries per
+// (tile, bucket) those stores are scattered over the whole array and the kernel is bound by write sectors (73 G
+// digits/s whatever the tile size).  Two levels keep every store in a run:
+//   msm_partition : a workgroup groups the (entry, bucket) pairs of an 8192-digit tile by COARSE bin (bucket >> fb[w])
+//                   in LDS, reserves one run per (tile, bin) with a global atomic and copies the tile out run by run
+//                   (~32 pairs = 256 B each);
+//   msm_bin_sort  : one workgroup per bin (<= BIN_CAP entries: the region of `sorted` between the offsets of its
+//                   first and last bucket) places the entries by fine bucket in LDS — the per-bucket offsets are
+//                   already known from the prefix sums — and copies the region out in order.
+// Bins are sized per window (BinPlan): the top window only sees digits up to r >> bit, i.e. much denser buckets.
+// A bin larger than BIN_CAP (skewed digits: many equal scalars) marks its WINDOW bad and that window takes the
+// one-level path: both sets of kernels are launched and the unused one returns at once — no host read-back.
+static constexpr uint32_t BIN_CAP = 24576;   // entries per bin (96 KB of LDS in msm_bin_sort)
+static constexpr int BIN_THREADS = 1024;
+static constexpr uint32_t PART_TILE = 8192;  // digits per workgroup in msm_partition (64 KB of LDS for the pairs)
+static constexpr uint32_t PART_MAX_BINS = 1024;
+struct BinPlan {
+    uint8_t fb[MAX_WIN];      // fine bits of window w: bin = bucket >> fb[w], at most 128 buckets per bin
+    uint16_t nbins[MAX_WIN];  // bins that can be non-empty in window w
+    uint32_t max_nbins;
+};
+__global__ void __launch_bounds__(256) msm_bin_check(const uint32_t* __restrict__ bucket_off, WinLayout L, BinPlan P,
+                                                     uint32_t* __restrict__ bad) {
+    const uint32_t w = blockIdx.y, bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= P.nbins[w]) return;
+    const uint32_t B = 1u << (L.c[w] - 1), fb = P.fb[w], first = bin << fb, last = min(first + (1u << fb), B);
+    uint32_t size = bucket_off[L.boff[w] + last] - bucket_off[L.boff[w] + first];
+    if (bin + 1 == P.nbins[w]) size = bucket_off[L.boff[w] + B] - bucket_off[L.boff[w] + first];  // nothing may lie beyond
+    if (size > BIN_CAP || (bin + 1 == P.nbins[w] && last < B && bucket_off[L.boff[w] + B] != bucket_off[L.boff[w] + last]))
+        bad[w] = 1u;
+}
+__global__ void __launch_bounds__(1024) msm_partition(const uint32_t* __restrict__ digits, size_t n, WinLayout L, BinPlan P,
+                                                      const uint32_t* __restrict__ bucket_off,
+                                                      uint32_t* __restrict__ bin_cursor, const uint32_t* __restrict__ bad,
+                                                      uint2* __restrict__ tmp) {
+    __shared__ uint32_t cnt[PART_MAX_BINS], start[PART_MAX_BINS], gpos[PART_MAX_BINS];
+    extern __shared__ uint2 stage[];  // PART_TILE pairs
+    const uint32_t w = blockIdx.y;
+    if (bad[w]) return;
+    const uint32_t nb = P.nbins[w], fb = P.fb[w], boff = L.boff[w], t = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * PART_TILE;
+    for (uint32_t b = t; b < nb; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)w * n;
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        size_t i = lo + t + (size_t)u * 1024;
+        c[u] = i < n ? d[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        if (c[u]) atomicAdd(&cnt[((c[u] - 1) >> 1) >> fb], 1u);
+    __syncthreads();
+    // exclusive scan of cnt over the (<= 1024) bins: one bin per lane, Hillis-Steele in `start`
+    uint32_t mine = t < nb ? cnt[t] : 0u;
+    start[t] = mine;
+    __syncthreads();
+    for (uint32_t dd = 1; dd < 1024; dd <<= 1) {
+        uint32_t v = t >= dd ? start[t - dd] : 0u;
+        __syncthreads();
+        start[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = start[t] - mine;
+    __syncthreads();
+    start[t] = excl;
+    if (t < nb) {
+        cnt[t] = excl;  // running cursor of the bin inside the staged tile
+        gpos[t] = mine ? bucket_off[boff + (t << fb)] + atomicAdd(&bin_cursor[w * PART_MAX_BINS + t], mine) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        if (c[u]) {
+            const uint32_t bucket = (c[u] - 1) >> 1;
+            const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
+            stage[p] = make_uint2((uint32_t)(lo + t + (size_t)u * 1024) | (((c[u] - 1) & 1u) << 31), bucket);
+        }
+    __syncthreads();
+    const uint32_t total = start[nb - 1] + (cnt[nb - 1] - start[nb - 1]);  // pairs staged by this tile
+    for (uint32_t i = t; i < total; i += 1024) {
+        uint2 e = stage[i];
+        uint32_t b = e.y >> fb;
+        tmp[gpos[b] + (i - start[b])] = e;
+    }
+}
+__global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort(const uint2* __restrict__ tmp, WinLayout L, BinPlan P,
+                                                            const uint32_t* __restrict__ bucket_off,
+                                                            const uint32_t* __restrict__ bad, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t stage32[];  // BIN_CAP entries
+    __shared__ uint32_t fc[128];
+    const uint32_t w = blockIdx.y, bin = blockIdx.x;
+    if (bad[w] || bin >= P.nbins[w]) return;
+    const uint32_t B = 1u << (L.c[w] - 1), fb = P.fb[w], first = bin << fb, nf = min(1u << fb, B - first);
+    const uint32_t* off = bucket_off + L.boff[w] + first;
+    const uint32_t lo = off[0], cnt = off[nf] - lo;
+    for (uint32_t f = threadIdx.x; f < nf; f += BIN_THREADS) fc[f] = off[f] - lo;
+    __syncthreads();
+    const uint32_t fmask = (1u << fb) - 1;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 4 * BIN_THREADS) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i + u * BIN_THREADS < cnt) stage32[atomicAdd(&fc[e[u].y & fmask], 1u)] = e[u].x;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage32[i];
 }
 
 __device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
@@ -620,9 +736,9 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __r
 
 // ---------------------------------------------------------------------------------------------- host driver
 // Kernels that want more than 64 KB of dynamic LDS need the attribute raised once per device; `slot` names the kernel
-// (0 hist, 1 scatter, 2 bucket_reduce) in a small process-wide cache so that the runtime call is not repeated per MSM.
+// (0 hist, 1 scatter, 2 bucket_reduce, 3 partition, 4 bin_sort) in a small process-wide cache so that the runtime call is not repeated per MSM.
 static int allow_big_lds(swm_ctx* ctx, int slot, const void* fn, size_t bytes) {
-    static std::atomic<size_t> granted[64][3];
+    static std::atomic<size_t> granted[64][5];
     if (bytes <= 64 * 1024) return SWM_OK;
     const int dev = ctx->device & 63;
     if (granted[dev][slot].load(std::memory_order_acquire) >= bytes) return SWM_OK;
@@ -707,9 +823,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         ~StreamSwap() { c->stream = old; }
     } swap{ctx, main_stream};
     ctx->stream = st;
-    char nm[9][32];
-    const char* base[9] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points"};
-    for (int i = 0; i < 9; i++) snprintf(nm[i], sizeof(nm[i]), "msm%d.%s", lane < 0 ? 9 : lane, base[i]);
+    char nm[10][32];
+    const char* base[10] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points", "pairs"};
+    for (int i = 0; i < 10; i++) snprintf(nm[i], sizeof(nm[i]), "msm%d.%s", lane < 0 ? 9 : lane, base[i]);
 
     // Segment bound.  Long segments mean one partial sum per bucket (the bucket stage walks fewer partials) but fewer,
     // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
@@ -718,11 +834,52 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1);
+    // two-level scatter for large MSMs (see msm_partition): bins of ~8 k entries, sized per window
+    bool two_level = n >= 262144 && pl.maxB >= 8192 && !getenv("SWM_MSM_ONE_LEVEL");
+    BinPlan bp;
+    memset(&bp, 0, sizeof(bp));
+    if (two_level) {
+        uint32_t target = 64;  // bins per full window: next power of two >= n / 8192, within [64, PART_MAX_BINS]
+        while (target < PART_MAX_BINS && (size_t)target * 8192 < n) target <<= 1;
+        for (unsigned w = 0; w < pl.nwin; w++) {
+            uint32_t B = 1u << (pl.c[w] - 1), beff = B;
+            if (w + 1 == pl.nwin) {  // top window: digits only reach (r - 1) >> bit (+ 1 for the carry), never negative
+                uint64_t top = 0;
+                for (int i = 7; i >= 0; i--) {
+                    int sh = 32 * i - (int)pl.bit[w];
+                    if (sh >= 0 && sh < 64) top |= (uint64_t)FrParams::P[i] << sh;
+                    else if (sh < 0 && sh > -32) top |= (uint64_t)FrParams::P[i] >> (-sh);
+                }
+                beff = (uint32_t)std::min<uint64_t>(B, top + 2);
+            }
+            unsigned lb = 0;
+            while ((1u << lb) < beff) lb++;
+            unsigned lt = 0;
+            while ((1u << lt) < target) lt++;
+            // a window with 2^lb possible buckets out of the nominal 2^(c-1) holds 2^(c-1-lb) times denser buckets:
+            // give it proportionally more bins so that a bin still holds ~n / target entries
+            unsigned fb = lb > lt ? lb - lt : 0;
+            if (fb > 7) fb = 7;
+            uint32_t nb = (beff + (1u << fb) - 1) >> fb;
+            if (nb > PART_MAX_BINS) {
+                two_level = false;
+                break;
+            }
+            bp.fb[w] = (uint8_t)fb;
+            bp.nbins[w] = (uint16_t)nb;
+            bp.max_nbins = std::max(bp.max_nbins, nb);
+        }
+    }
+    const uint32_t maxbins = two_level ? PART_MAX_BINS : 0;
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1) + MAX_WIN + (size_t)pl.nwin * maxbins;
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
+    uint32_t* two_level_bad = len_hist + (SEG_MAX + 1);  // one flag per window, then the per-(window, bin) cursors
+    uint32_t* bin_cursor = two_level_bad + MAX_WIN;
+    uint2* pairs = nullptr;
+    if (two_level) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
     seg_len = seg_start + nseg_max;
     order = seg_len + nseg_max;
@@ -755,8 +912,18 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
     SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
                scan_tiles, bucket_off, seg_off, big_count, big_list);
+    if (two_level) {
+        SWM_TRY(allow_big_lds(ctx, 3, (const void*)msm_partition, (size_t)PART_TILE * sizeof(uint2)));
+        SWM_TRY(allow_big_lds(ctx, 4, (const void*)msm_bin_sort, (size_t)BIN_CAP * 4));
+        SWM_LAUNCH(ctx, "msm_bin_check", msm_bin_check, dim3((bp.max_nbins + 255) / 256, pl.nwin), dim3(256), 0, bucket_off, pl, bp,
+                   two_level_bad);
+        SWM_LAUNCH(ctx, "msm_partition", msm_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin), dim3(1024),
+                   (size_t)PART_TILE * sizeof(uint2), digits, n, pl, bp, bucket_off, bin_cursor, two_level_bad, pairs);
+        SWM_LAUNCH(ctx, "msm_bin_sort", msm_bin_sort, dim3(bp.max_nbins, pl.nwin), dim3(BIN_THREADS), (size_t)BIN_CAP * 4,
+                   (const uint2*)pairs, pl, bp, bucket_off, two_level_bad, sorted);
+    }
     SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
-               SORT_TILE, bucket_off, cursor, sorted);
+               SORT_TILE, bucket_off, cursor, sorted, two_level ? (const uint32_t*)two_level_bad : (const uint32_t*)nullptr);
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                SEG, seg_start, seg_len, len_hist);
