@@ -5,7 +5,7 @@
 // out, root = TWO_ADIC_ROOT^(2^(47-log n)), inverse scales by 1/n, coset variants scale coefficient i by 22^i
 // (before a forward transform) or 22^-i (after an inverse one).
 //
-// MI355X design: Stockham autosort in ceil(log n / 8) passes.  A workgroup stages a tile of R = 2^r strided
+// MI355X design: Stockham autosort in ceil(log n / 10) passes.  A workgroup stages a tile of R = 2^r strided
 // rows x 8 contiguous columns (256-B coalesced runs of 32-B elements, 64 KB of LDS at r = 8) and runs all r
 // butterfly levels of that tile in LDS; the inter-pass twiddle w_n^(k t), the coset scaling and the 1/n factor
 // are fused into the tile load / store, so each pass reads and writes every element exactly once
@@ -20,7 +20,7 @@ namespace swm {
 // contiguous columns per tile: chosen per pass so that a workgroup holds ~1024 elements (32 KB of LDS: four to five
 // workgroups per CU, every lane busy in every butterfly level) — 512 when the transform is too small to fill the chip
 static constexpr int NTT_THREADS = 256;
-static constexpr unsigned NTT_MAX_LOG_R = 8;
+static constexpr unsigned NTT_MAX_LOG_R = 10;  // 2^20 in two passes (10 + 10); 11 + 11 for 2^22 loses to 8 + 7 + 7 (r01 sweep)
 
 struct NttPassArgs {
     const Fr* src;
@@ -58,16 +58,16 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
     const unsigned tw_shift = a.log_n - a.log_ns - a.log_r;  // w_{Ns R} = w_n^(2^tw_shift)
     // ---- load (+ inter-pass twiddle, + coset scaling).  A tile has at most 1024 elements (ntt_run): four per lane, all
     // four global loads issued before the first twiddle multiplication so that their latencies overlap.
-    {
+    for (unsigned e0 = 0; e0 < R * J; e0 += 4 * NTT_THREADS) {
         Fr xs[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            unsigned e = threadIdx.x + u * NTT_THREADS;
+            unsigned e = e0 + threadIdx.x + u * NTT_THREADS;
             if (e < R * J) xs[u] = a.src[j0 + e % J + (uint64_t)(e / J) * stride];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            unsigned e = threadIdx.x + u * NTT_THREADS;
+            unsigned e = e0 + threadIdx.x + u * NTT_THREADS;
             if (e >= R * J) break;
             unsigned jj = e % J, t = e / J;
             uint64_t idx = j0 + jj + (uint64_t)t * stride;
@@ -210,7 +210,9 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
     Fr n_inv = fp_one<Fr>();
     if (inverse) n_inv = fp_inv(fp_from_u64<Fr>(n));
     // pass plan
-    unsigned npass = log_n <= NTT_MAX_LOG_R ? 1 : (log_n + NTT_MAX_LOG_R - 1) / NTT_MAX_LOG_R;
+    unsigned maxr = NTT_MAX_LOG_R;
+    if (const char* e = getenv("SWM_NTT_MAXR")) maxr = (unsigned)atoi(e);
+    unsigned npass = log_n <= maxr ? 1 : (log_n + maxr - 1) / maxr;
     unsigned radices[8];
     {
         unsigned rem = log_n;
