@@ -108,6 +108,9 @@ def main():
     import simpleworks_amd as swm
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SWM_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, collectives) even with one rank —
+    # lets a single-GPU box exercise the RCCL calls the N > 1 runs make
+    use_dist = world > 1 or bool(os.environ.get("SWM_BENCH_FORCE_DIST"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Test hook for single-GPU boxes: SWM_BENCH_BACKEND=gloo SWM_BENCH_DEVICE=0 runs all ranks on one device (the
@@ -115,7 +118,7 @@ def main():
     backend = os.environ.get("SWM_BENCH_BACKEND", "nccl")
     device_index = int(os.environ.get("SWM_BENCH_DEVICE", local_rank))
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    if use_dist:
         torch.cuda.set_device(device_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
@@ -139,7 +142,7 @@ def main():
 
         def step():
             part = ctx.msm_g1_dev(bh, d_sc, n, True)
-            if world > 1:
+            if use_dist:
                 t = torch.from_numpy(part.view(np.int64)).to(coll_dev)
                 out = [torch.empty_like(t) for _ in range(world)]
                 dist.all_gather(out, t)
@@ -156,7 +159,7 @@ def main():
         from simpleworks_amd import workloads as W
         M.set_default_context(ctx)
         sharded = args.workload == "prove_sharded"
-        if sharded and world > 1:
+        if sharded and use_dist:
             from simpleworks_amd.dist import enable_sharded_prover
             enable_sharded_prover(ctx)
         rng = M.generate_rand()
@@ -176,7 +179,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -194,7 +197,7 @@ def main():
     prof = ctx.profile()
     if args.workload != "msm":
         assert M.verify_proof(vk, public, last["proof"], M.generate_rand()), "bench: proof does not verify"
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -241,7 +244,7 @@ def main():
             else:
                 out["cpu_baseline"] = cpu_baseline_prove(args.cpu_log_n or 14)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
