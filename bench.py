@@ -103,6 +103,13 @@ def main():
                          "2^20 proof) instead of the dominant kernel only")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a banner (hostname, library path, ...) to stdout when its
+    # communicator comes up, so everything written to file descriptor 1 from here on is sent to stderr and the JSON line
+    # goes to a private duplicate of the original stdout at the very end.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import simpleworks_amd as swm
@@ -243,7 +250,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_msm(args.cpu_log_n or 18)
             else:
                 out["cpu_baseline"] = cpu_baseline_prove(args.cpu_log_n or 14)
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if use_dist:
         dist.destroy_process_group()
 
