@@ -830,7 +830,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // Segment bound.  Long segments mean one partial sum per bucket (the bucket stage walks fewer partials) but fewer,
     // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
     // 32 by 10 % at 2^20 and 2^22, loses at 2^16 where 45 k buckets cannot fill 196 k lane slots).
-    const uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;
+    uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;  // smaller bounds for small MSMs measured within run-to-run noise
+    if (const char* e = getenv("SWM_MSM_SEG")) SEG = std::min<uint32_t>(SEG_MAX, std::max(1, atoi(e)));
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
