@@ -241,7 +241,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # explanatory figure: the kernel is bound by integer issue, not by HBM —
+                         # mixed additions per second against the ceiling its instruction mix allows
+                         # (3423 v_mad_u64_u32 + 677 64-bit shift/adds at 4.2 cycles, ~870 32-bit ops at 2.3, per
+                         # wave-addition; 1024 SIMDs at 2.4 GHz)
+                         "mixed_adds_per_s": work["msm_digits"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
+                         "issue_ceiling_mixed_adds_per_s": 8.2e9},
             "work_per_step": {k: v / args.steps for k, v in work.items()},
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }

@@ -418,7 +418,7 @@ int swm_profile_reset(swm_ctx* ctx) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
     prof_flush(ctx);
     ctx->prof.clear();
-    ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
+    ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_msm_digits = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
     ctx->stat_spmv_calls = ctx->stat_spmv_rows = 0;
     return SWM_OK;
 }
@@ -435,11 +435,12 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
         s += line;
         first = false;
     }
-    char tail[320];
+    char tail[400];
     snprintf(tail, sizeof(tail),
-             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"ntt_calls\":%llu,\"ntt_elements\":%llu,"
+             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"msm_digits\":%llu,\"ntt_calls\":%llu,\"ntt_elements\":%llu,"
              "\"spmv_calls\":%llu,\"spmv_rows\":%llu}}",
              (unsigned long long)ctx->stat_msm_calls, (unsigned long long)ctx->stat_msm_points,
+             (unsigned long long)ctx->stat_msm_digits,
              (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
              (unsigned long long)ctx->stat_spmv_calls, (unsigned long long)ctx->stat_spmv_rows);
     s += tail;

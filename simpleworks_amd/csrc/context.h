@@ -55,6 +55,7 @@ struct swm_ctx {
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
+    uint64_t stat_msm_digits = 0;  // points x windows: the mixed additions the accumulation performs (zero digits included)
     uint64_t stat_msm_calls = 0, stat_msm_points = 0, stat_ntt_calls = 0, stat_ntt_elems = 0, stat_spmv_calls = 0,
              stat_spmv_rows = 0;
     int profiling = 0;  // 0 off, 1 every launch, 2 the dominant kernel (msm_accumulate) only

@@ -785,6 +785,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stat_msm_points += n;
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
+    ctx->stat_msm_digits += total;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
     // buckets per lane in the reduction: at most 16 workgroups per window (the host folds one (A, R) pair per workgroup)
     unsigned log_m = pl.maxB <= 2048 ? 0 : 2;  // small windows: one bucket per lane shortens the serial walk (r01 sweep)
