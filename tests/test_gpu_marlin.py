@@ -288,3 +288,28 @@ def test_long_row_circuit(M, S, W):
     assert not bad.is_satisfied()
     pk.free()
     srs.free()
+
+
+def test_error_paths_return_status_codes(M, S, W):
+    """Failures become error codes (the reference turns every failure into anyhow!(..), src/marlin/mod.rs:53,76,85,93):
+    a circuit that does not match the key, a key of the wrong size, bad kernel arguments."""
+    import simpleworks_amd as swm
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(64, 64, 64, rng)
+    cs16 = W.synthetic_circuit(16, 3, 5)
+    cs32 = W.synthetic_circuit(32, 3, 5)
+    pk16, vk16 = M.generate_proving_and_verifying_keys(srs, cs16)
+    with pytest.raises(M.MarlinError):
+        M.generate_proof(cs32, pk16, rng)        # shape of the system differs from the indexed one
+    proof = M.generate_proof(cs16, pk16, rng)
+    assert not M.verify_proof(vk16, [1, 2, 3, 4, 5], proof, M.generate_rand())  # wrong number of public inputs: rejected
+    ctx = M.default_context()
+    d = ctx.to_device(np.zeros((8, 4), dtype=np.uint64))
+    with pytest.raises(swm.SwmError):
+        ctx.ntt_fr_dev(d, 31)                               # log_n out of range
+    d.free()
+    with pytest.raises(swm.SwmError):
+        ctx.spmv_fr(np.array([0, 1], dtype=np.uint32), np.array([7], dtype=np.uint32), np.zeros((1, 4), np.uint64),
+                    np.zeros((3, 4), np.uint64))            # column index beyond z
+    pk16.free()
+    srs.free()
