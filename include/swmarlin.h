@@ -49,6 +49,8 @@ const char *swm_strerror(int code);
 /* Creates a context on HIP device `device` with its own stream. */
 int swm_init(int device, swm_ctx **out);
 void swm_destroy(swm_ctx *ctx);
+/* detail of the last failure on this context; ctx == NULL: of the last context-free call (verify, codecs) on the
+ * calling thread */
 const char *swm_last_error(swm_ctx *ctx);
 /* Enqueue on an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own stream. */
 int swm_set_stream(swm_ctx *ctx, void *hip_stream);
@@ -63,12 +65,15 @@ int swm_memcpy_d2h(swm_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * Replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) (ark-ec 0.3.0), reached from
  * src/marlin/mod.rs:75 (prove) and :92 (index) through ark_poly_commit::kzg10::KZG10::commit / open.
  * The result is the same group element arkworks computes (compare after affine normalisation). */
-/* Upload n affine bases (n x 12 limbs, Montgomery) once; they stay resident in HBM (SRS powers [tau^i]G). */
+/* Upload n affine bases (n x 12 limbs, Montgomery) once; they stay resident in HBM (SRS powers [tau^i]G).
+ * x = y = 0 encodes the point at infinity. */
 int swm_srs_upload(swm_ctx *ctx, const uint64_t *xy, size_t n, swm_bases **out);
 int swm_srs_free(swm_ctx *ctx, swm_bases *bases);
 size_t swm_srs_len(const swm_bases *bases);
 /* out_jac = sum_i scalars[i] * bases[offset + i].  scalars: n x 4 limbs, STANDARD form (what arkworks passes:
- * p.coeffs.map(|s| s.into_repr())), host memory; every scalar must be a canonical field element (< r). */
+ * p.coeffs.map(|s| s.into_repr())), host memory.  Every scalar must be a canonical field element (< r), as arkworks'
+ * BigInteger256 scalars are: a scalar >= r makes the call fail with SWM_ERR_INVALID_ARG (checked on the device, no
+ * result is written).  Bases that are the point at infinity (x = y = 0) contribute nothing, as in arkworks. */
 int swm_msm_g1(swm_ctx *ctx, const swm_bases *bases, size_t offset, const uint64_t *scalars, size_t n,
                uint64_t out_jac[18]);
 /* same with the scalars already in HBM; scalars_montgomery != 0 means they are Montgomery-form Fr (polynomial
@@ -117,6 +122,17 @@ typedef struct swm_vk swm_vk;   /* VerifyingKey = IndexVerifierKey */
 int swm_rng_test_new(swm_rng **out);
 /* StdRng::from_seed(seed) for callers that want their own randomness */
 int swm_rng_from_seed(const uint8_t seed[32], swm_rng **out);
+/* The CALLER's generator behind the same handle: the reference's functions take `&mut StdRng`
+ * (src/marlin/mod.rs:49,73,83); a shim that wants to keep that signature AND the draw stream wraps its rng in a
+ * fill_bytes trampoline.  Every draw the library makes is then a call fill_bytes(user, dest, 4 | 8 | 32 n) and consumes
+ * the caller's stream word for word as arkworks would (rand_core BlockRng: next_u32 = 4 bytes, next_u64 = 8 bytes,
+ * both little-endian, consecutive words).  The callback is invoked on the calling thread, only from inside
+ * swm_generate_universal_srs / swm_generate_proof / swm_verify_proof / swm_rng_next_u64 / swm_rng_rand_fr, and must not
+ * call back into the library.  `user` must stay valid until swm_rng_free.  Bulk draws (the 3|H| mask coefficients of a
+ * proof) travel through the callback too (~170 MB at |H| = 2^20): slower than the built-in ChaCha12, which produces
+ * them on the GPU. */
+typedef void (*swm_fill_bytes_fn)(void *user, uint8_t *dest, size_t len);
+int swm_rng_from_callback(swm_fill_bytes_fn fill_bytes, void *user, swm_rng **out);
 void swm_rng_free(swm_rng *rng);
 int swm_rng_next_u64(swm_rng *rng, uint64_t *out);
 int swm_rng_rand_fr(swm_rng *rng, uint64_t out_mont[4]); /* ark_ff UniformRand for Fr (Montgomery limbs) */

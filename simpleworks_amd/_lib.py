@@ -46,6 +46,7 @@ ABI = {
     "swm_vec_mul_fr_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "swm_rng_test_new": (_int, [ctypes.POINTER(_vp)]),
     "swm_rng_from_seed": (_int, [ctypes.c_void_p, ctypes.POINTER(_vp)]),
+    "swm_rng_from_callback": (_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "swm_rng_free": (None, [_vp]),
     "swm_rng_next_u64": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "swm_rng_rand_fr": (_int, [_vp, _u64p]),

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include "context.h"
 #include "g1.cuh"
 #include "msm.h"
@@ -21,14 +22,24 @@ int selftest_mul_run(swm_ctx* ctx, int which, const void* a, const void* b, void
 int selftest_chain_run(swm_ctx* ctx, int which, void* out, size_t threads, int iters);
 int selftest_g1_add_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n);
 
+// detail of the last failure of a context-free entry point (verify / codecs), per calling thread
+static thread_local char tls_err[512] = {0};
+
 int set_err(swm_ctx* ctx, int code, const char* fmt, ...) {
-    if (ctx) {
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
-        va_end(ap);
-    }
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx ? ctx->err : tls_err, sizeof(tls_err), fmt, ap);
+    va_end(ap);
     return code;
+}
+
+void drain_streams(swm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (int i = 0; i < swm_ctx::MSM_LANES; i++)
+        if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
+    for (int i = 0; i < swm_ctx::MSM_SLOTS; i++) ctx->slot_busy[i] = false;
 }
 
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -187,7 +198,7 @@ void swm_destroy(swm_ctx* ctx) {
     delete ctx;
 }
 
-const char* swm_last_error(swm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+const char* swm_last_error(swm_ctx* ctx) { return ctx ? ctx->err : tls_err; }
 
 int swm_set_msm_sharding(swm_ctx* ctx, unsigned rank, unsigned world, swm_allgather_fn allgather, void* user) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
@@ -208,35 +219,40 @@ int swm_set_msm_sharding(swm_ctx* ctx, unsigned rank, unsigned world, swm_allgat
 
 int swm_set_stream(swm_ctx* ctx, void* hip_stream) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return SWM_OK;
 }
 int swm_synchronize(swm_ctx* ctx) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SWM_OK;
 }
 int swm_malloc(swm_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return SWM_ERR_INVALID_ARG;
-    SWM_HIP(ctx, hipSetDevice(ctx->device));
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 1));
     return SWM_OK;
 }
 int swm_free(swm_ctx* ctx, void* dptr) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SWM_HIP(ctx, hipFree(dptr));
     return SWM_OK;
 }
 int swm_memcpy_h2d(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SWM_OK;
 }
 int swm_memcpy_d2h(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SWM_OK;
@@ -245,6 +261,7 @@ int swm_memcpy_d2h(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
 // ------------------------------------------------------------------------------------------------ K1
 int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) {
     if (!ctx || !xy || !out || n == 0) return set_err(ctx, SWM_ERR_INVALID_ARG, "srs_upload: bad arguments");
+    SWM_ON_DEVICE(ctx);
     swm_bases* b = new swm_bases();
     b->n = n;
     hipError_t e = hipMalloc(&b->d_points, n * sizeof(G1Affine));
@@ -260,22 +277,41 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
         delete b;
         return set_err(ctx, SWM_ERR_HIP, "srs_upload: %s", hipGetErrorString(e));
     }
-    int rc = msm_scale_bases_run(ctx, (const G1Affine*)b->d_points, n, (G1Affine*)b->d_points28);
-    if (rc == SWM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SWM_ERR_HIP;
+    // bit mask of the bases that are the point at infinity (x = y = 0, a valid input as in arkworks); it is kept only
+    // when at least one exists, so the common case pays nothing per MSM
+    const size_t mask_words = (n + 31) / 32;
+    int rc = SWM_OK;
+    if (hipMalloc((void**)&b->d_inf_mask, mask_words * 4) != hipSuccess ||
+        hipMemsetAsync(b->d_inf_mask, 0, mask_words * 4, ctx->stream) != hipSuccess)
+        rc = set_err(ctx, SWM_ERR_OOM, "srs_upload: infinity mask");
+    if (rc == SWM_OK) rc = msm_scale_bases_run(ctx, (const G1Affine*)b->d_points, n, (G1Affine*)b->d_points28, b->d_inf_mask);
+    std::vector<uint32_t> hmask(mask_words);
+    if (rc == SWM_OK && (hipMemcpyAsync(hmask.data(), b->d_inf_mask, mask_words * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = set_err(ctx, SWM_ERR_HIP, "srs_upload: infinity mask download");
     if (rc != SWM_OK) {
         (void)hipFree(b->d_points);
         (void)hipFree(b->d_points28);
+        if (b->d_inf_mask) (void)hipFree(b->d_inf_mask);
         delete b;
         return rc;
+    }
+    bool any_inf = false;
+    for (uint32_t w : hmask) any_inf |= w != 0;
+    if (!any_inf) {
+        (void)hipFree(b->d_inf_mask);
+        b->d_inf_mask = nullptr;
     }
     *out = b;
     return SWM_OK;
 }
 int swm_srs_free(swm_ctx* ctx, swm_bases* bases) {
     if (!ctx || !bases) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SWM_HIP(ctx, hipFree(bases->d_points));
     SWM_HIP(ctx, hipFree(bases->d_points28));
+    if (bases->d_inf_mask) SWM_HIP(ctx, hipFree(bases->d_inf_mask));
     delete bases;
     return SWM_OK;
 }
@@ -289,11 +325,13 @@ static void write_jac(const G1XYZZ& r, uint64_t out_jac[18]) {
 int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const void* d_scalars, size_t n,
                    int scalars_montgomery, uint64_t out_jac[18]) {
     if (!ctx || !bases || !out_jac || (n && !d_scalars)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: bad arguments");
+    SWM_ON_DEVICE(ctx);
     if (offset > bases->n || n > bases->n - offset)
         return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: %zu scalars at offset %zu exceed %zu bases", n, offset, bases->n);
     G1XYZZ r;
     SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset,
-                    reinterpret_cast<const G1Affine*>(bases->d_points28) + offset, d_scalars, n, scalars_montgomery, &r));
+                    reinterpret_cast<const G1Affine*>(bases->d_points28) + offset, d_scalars, n, scalars_montgomery, &r,
+                    MsmInfMask{bases->d_inf_mask, offset}));
     write_jac(r, out_jac);
     return SWM_OK;
 }
@@ -301,6 +339,7 @@ int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const vo
 int swm_msm_g1(swm_ctx* ctx, const swm_bases* bases, size_t offset, const uint64_t* scalars, size_t n,
                uint64_t out_jac[18]) {
     if (!ctx || !bases || !out_jac || (n && !scalars)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: bad arguments");
+    SWM_ON_DEVICE(ctx);
     void* d = nullptr;
     SWM_TRY(scratch(ctx, "stage.scalars", n * 32 + 32, &d));
     if (n) SWM_HIP(ctx, hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -331,10 +370,12 @@ int swm_g1_add_jac(const uint64_t a[18], const uint64_t b[18], uint64_t out[18])
 // ------------------------------------------------------------------------------------------------ K2
 int swm_ntt_fr_dev(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
     if (!ctx || !d_data) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");
+    SWM_ON_DEVICE(ctx);
     return ntt_run(ctx, d_data, log_n, inverse, coset);
 }
 int swm_ntt_fr(swm_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
     if (!ctx || !data || log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");
+    SWM_ON_DEVICE(ctx);
     size_t bytes = (size_t)32 << log_n;
     void* d = nullptr;
     SWM_TRY(scratch(ctx, "stage.ntt", bytes, &d));
@@ -349,12 +390,14 @@ int swm_ntt_fr(swm_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int co
 int swm_spmv_fr_dev(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z,
                     void* d_out, size_t rows) {
     if (!ctx || !d_rowptr || !d_out) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: bad arguments");
+    SWM_ON_DEVICE(ctx);
     return spmv_run(ctx, d_rowptr, d_col, d_val, d_z, d_out, rows);
 }
 int swm_spmv_fr(swm_ctx* ctx, const uint32_t* rowptr, const uint32_t* col, const uint64_t* val, const uint64_t* z,
                 size_t z_len, uint64_t* out, size_t rows, size_t nnz) {
     if (!ctx || !rowptr || !out || (nnz && (!col || !val || !z)))
         return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: bad arguments");
+    SWM_ON_DEVICE(ctx);
     if (rowptr[rows] != nnz) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: rowptr[rows] != nnz");
     for (size_t k = 0; k < nnz; k++)
         if (col[k] >= z_len) return set_err(ctx, SWM_ERR_INVALID_ARG, "spmv: column index out of range");
@@ -378,10 +421,12 @@ int swm_spmv_fr(swm_ctx* ctx, const uint32_t* rowptr, const uint32_t* col, const
 // ------------------------------------------------------------------------------------------------ K4
 int swm_batch_inverse_fr_dev(swm_ctx* ctx, void* d_data, size_t n) {
     if (!ctx || (n && !d_data)) return set_err(ctx, SWM_ERR_INVALID_ARG, "batch_inverse: bad arguments");
+    SWM_ON_DEVICE(ctx);
     return batch_inverse_run(ctx, d_data, n);
 }
 int swm_batch_inverse_fr(swm_ctx* ctx, uint64_t* data, size_t n) {
     if (!ctx || (n && !data)) return set_err(ctx, SWM_ERR_INVALID_ARG, "batch_inverse: bad arguments");
+    SWM_ON_DEVICE(ctx);
     void* d = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", n * 32 + 32, &d));
     SWM_HIP(ctx, hipMemcpyAsync(d, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -392,10 +437,12 @@ int swm_batch_inverse_fr(swm_ctx* ctx, uint64_t* data, size_t n) {
 }
 int swm_vec_mul_fr_dev(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
     if (!ctx || (n && (!a || !b || !out))) return set_err(ctx, SWM_ERR_INVALID_ARG, "vec_mul: bad arguments");
+    SWM_ON_DEVICE(ctx);
     return vec_mul_run(ctx, a, b, out, n);
 }
 int swm_vec_mul_fr(swm_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!ctx || (n && (!a || !b || !out))) return set_err(ctx, SWM_ERR_INVALID_ARG, "vec_mul: bad arguments");
+    SWM_ON_DEVICE(ctx);
     char *da = nullptr, *db = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", n * 32 + 32, (void**)&da));
     SWM_TRY(scratch(ctx, "stage.b", n * 32 + 32, (void**)&db));
@@ -410,12 +457,14 @@ int swm_vec_mul_fr(swm_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t*
 // ------------------------------------------------------------------------------------------------ measurement
 int swm_profile_enable(swm_ctx* ctx, int on) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     if (!on) prof_flush(ctx);
     ctx->profiling = on == 2 ? 2 : (on != 0);
     return SWM_OK;
 }
 int swm_profile_reset(swm_ctx* ctx) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     prof_flush(ctx);
     ctx->prof.clear();
     ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_msm_digits = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
@@ -424,6 +473,7 @@ int swm_profile_reset(swm_ctx* ctx) {
 }
 int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
     if (!ctx || !buf || buflen < 32) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     prof_flush(ctx);
     std::string s = "{\"kernels\":[";
     bool first = true;
@@ -452,6 +502,7 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
 // ------------------------------------------------------------------------------------------------ self-tests
 int swm_selftest_mul(swm_ctx* ctx, int which, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!ctx || !a || !b || !out) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     size_t es = which == 1 ? 32 : 48;
     char *da = nullptr, *db = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", n * es + 64, (void**)&da));
@@ -465,6 +516,7 @@ int swm_selftest_mul(swm_ctx* ctx, int which, const uint64_t* a, const uint64_t*
 }
 int swm_selftest_g1_add(swm_ctx* ctx, const uint64_t* a_xy, const uint64_t* b_xy, uint64_t* out_jac, size_t n) {
     if (!ctx || !a_xy || !b_xy || !out_jac) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     char *da = nullptr, *db = nullptr, *dc = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", n * 96 + 64, (void**)&da));
     SWM_TRY(scratch(ctx, "stage.b", n * 96 + 64, (void**)&db));
@@ -478,6 +530,7 @@ int swm_selftest_g1_add(swm_ctx* ctx, const uint64_t* a_xy, const uint64_t* b_xy
 }
 int swm_selftest_mul_throughput(swm_ctx* ctx, int which, size_t threads, int iters, float* ms) {
     if (!ctx || !ms || threads % 256) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     void* d = nullptr;
     SWM_TRY(scratch(ctx, "stage.a", threads * 48 + 64, &d));
     SWM_TRY(selftest_chain_run(ctx, which, d, threads, 8));  // warm-up

@@ -52,6 +52,7 @@ struct swm_ctx {
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
+    bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
@@ -73,12 +74,37 @@ struct swm_ctx {
 struct swm_bases {
     void* d_points = nullptr;    // n x G1Affine (96 B, Montgomery radix 2^384)
     void* d_points28 = nullptr;  // same points, coordinates x 2^8 (radix 2^392) for the MSM inner loop
+    uint32_t* d_inf_mask = nullptr;  // n bits, allocated only when some base is the point at infinity
     size_t n = 0;
 };
 
 namespace swm {
 
 int set_err(swm_ctx* ctx, int code, const char* fmt, ...);
+// Waits for everything enqueued on the context's stream and on its auxiliary MSM streams, and forgets the jobs that
+// were in flight.  Error paths call it before buffers that queued kernels may still read go back to the pool.
+void drain_streams(swm_ctx* ctx);
+
+// Every extern "C" entry point that takes a context runs on that context's GPU, whatever device the calling thread had
+// current (another context, torch, a thread that never called hipSetDevice); the caller's device is restored on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true, switched = false;
+    explicit DeviceGuard(const swm_ctx* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) {
+            ok = hipSetDevice(ctx->device) == hipSuccess;
+            switched = ok && prev >= 0;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define SWM_ON_DEVICE(ctx)                                                                             \
+    swm::DeviceGuard dev_guard__(ctx);                                                                 \
+    if (!dev_guard__.ok) return swm::set_err(ctx, SWM_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
 // returns device pointer of a scratch buffer with at least `bytes` capacity (contents undefined)
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out);
 // pooled device allocations for the prover's polynomial temporaries

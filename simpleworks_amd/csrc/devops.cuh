@@ -6,6 +6,7 @@
 // Replaces the cfg_iter!/rayon loops of ark-marlin's ahp/prover.rs and ark-poly's DensePolynomial helpers that
 // /root/reference/src/marlin/mod.rs:75 reaches (sources not vendored; behaviour from SURVEY.md A.3, A.5-A.7).
 #pragma once
+#include <exception>
 #include <utility>
 #include <atomic>
 #include "context.h"
@@ -69,7 +70,12 @@ struct DBuf {
     }
     ~DBuf() { release(); }
     void release() {
-        if (p) pool_free(ctx, p, cap);
+        if (p) {
+            // unwinding after a failure: kernels queued on the main or the auxiliary MSM streams may still read this
+            // block; wait for them before it returns to the pool (idle streams make this a no-op)
+            if (std::uncaught_exceptions() > 0) drain_streams(ctx);
+            pool_free(ctx, p, cap);
+        }
         p = nullptr;
     }
     void zero() { hip_check(ctx, hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream), "memset"); }
@@ -556,6 +562,33 @@ static __global__ void __launch_bounds__(256) sample_compact(const Fr* __restric
 // Draws `need` field elements from rng's stream into out[0..need) (device), advancing rng exactly as `need`
 // successive Fr::rand(rng) calls would.
 inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need) {
+    if (rng.ext) {
+        // caller-owned generator: the candidates come from its fill_bytes in runs of exactly the number still missing,
+        // so the stream stops right behind the candidate that completes the draw (as `need` successive Fr::rand calls
+        // would); rejection on the host, one upload.  ~170 MB through the callback for 3 * 2^20 elements.
+        std::vector<Fr> acc;
+        acc.reserve(need);
+        std::vector<uint8_t> buf;
+        while (acc.size() < need) {
+            size_t want = need - acc.size();
+            buf.resize(want * 32);
+            rng.ext(rng.ext_user, buf.data(), buf.size());
+            for (size_t i = 0; i < want; i++) {
+                Fr r;
+                memcpy(r.v, buf.data() + 32 * i, 32);  // little-endian host: 4 x u64 limbs, low first
+                r.v[7] &= 0xffffffffu >> 3;
+                bool lt = false;
+                for (int k = 7; k >= 0; k--) {
+                    if (r.v[k] < FrParams::P[k]) { lt = true; break; }
+                    if (r.v[k] > FrParams::P[k]) break;
+                }
+                if (lt) acc.push_back(r);
+            }
+        }
+        hip_check(ctx, hipMemcpyAsync(out, acc.data(), need * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
+        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        return;
+    }
     size_t done = 0;
     while (done < need) {
         size_t want = need - done;

@@ -33,7 +33,6 @@ struct Fq28Consts {
     static constexpr uint32_t SPREAD8[14] = SWM_FQ28_SPREAD8_1;
     static constexpr uint32_t SPREAD16_3[14] = SWM_FQ28_SPREAD16_3;
     static constexpr uint32_t SPREAD32[14] = SWM_FQ28_SPREAD32_1;
-    static constexpr uint32_t SPREAD64[14] = SWM_FQ28_SPREAD64_1;
 };
 
 // 12 x 32-bit words (value < 2^384) -> 14 x 28-bit limbs (top limb holds bits 364..383)
@@ -82,13 +81,6 @@ __device__ __forceinline__ Fq28 fq28_add(const Fq28& a, const Fq28& b) {  // laz
     return r;
 }
 // a - b + k p  (b limbs must not exceed the spread's borrow: < 2^28 for the _1 spreads, < 3 * 2^28 for SPREAD16_3)
-template <const uint32_t* SP>
-__device__ __forceinline__ Fq28 fq28_sub(const Fq28& a, const Fq28& b, const uint32_t (&sp)[14]) {
-    Fq28 r;
-#pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + sp[i] - b.l[i];
-    return r;
-}
 #define FQ28_SUB(a, b, SPREAD) fq28_sub_impl((a), (b), Fq28Consts::SPREAD)
 __device__ __forceinline__ Fq28 fq28_sub_impl(const Fq28& a, const Fq28& b, const uint32_t (&sp)[14]) {
     Fq28 r;
@@ -189,23 +181,11 @@ __device__ __forceinline__ Fq28 fq28_sqr(const Fq28& a) {
     r.l[13] = (uint32_t)acc;
     return r;
 }
-// Out-of-line form: ~4 KB of code reached through s_swappc instead of ~4 KB inlined at every call site.  A group
-// operation is 9-14 multiplications, i.e. 40-60 KB of straight-line code when inlined: more than the 64 KB instruction
-// cache two CUs share, so kernels that execute each adder once per step (bucket stage) stream their code from L2 on
-// every operation (measured ~28 us per addition instead of ~12).  Operands travel in VGPRs (2 x 14 dwords).
-__device__ __noinline__ Fq28 fq28_mul_call(const Fq28 a, const Fq28 b) { return fq28_mul(a, b); }
 struct MulInline {
     static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul(a, b); }
     // the dedicated squarer (fq28_sqr, 105 instead of 196 a*a products) measured no faster inside the adders on
     // gfx950 (r01: 2.74 vs 2.63 ms per 2^20-point accumulation), so the policies square with the multiplier
     static __device__ __forceinline__ Fq28 sqr(const Fq28& a) { return fq28_mul(a, a); }
-    static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
-        return fq28_mul2(a, b, c, d);
-    }
-};
-struct MulCall {
-    static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul_call(a, b); }
-    static __device__ __forceinline__ Fq28 sqr(const Fq28& a) { return fq28_mul_call(a, a); }
     static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
         return fq28_mul2(a, b, c, d);
     }

@@ -34,6 +34,13 @@ SWM_HD void chacha_block(const uint32_t key[8], uint64_t counter, int rounds, ui
     for (int i = 0; i < 16; i++) out[i] = s[i] + in[i];
 }
 
+// Caller-owned randomness (swm_rng_from_callback): the reference passes `&mut StdRng` into setup / prove / verify
+// (src/marlin/mod.rs:49,73,83), so a drop-in has to draw from THAT generator.  rand_core's BlockRng serves
+// next_u32 / next_u64 / fill_bytes from one flat stream of 32-bit words (a u64 is two consecutive words, low first;
+// fill_bytes(4 k) is k consecutive words), so every draw below is expressed as fill(4) / fill(8) / fill(32 n) and the
+// caller's generator advances exactly as it would under arkworks.
+typedef void (*RngFillFn)(void* user, uint8_t* dest, size_t len);
+
 struct ChaChaRng {
     uint32_t key[8];
     int rounds;
@@ -41,6 +48,8 @@ struct ChaChaRng {
     uint64_t cached_blk; // block currently in `block`
     uint32_t block[16];
     bool have;
+    RngFillFn ext = nullptr;  // non-null: every draw is forwarded to the caller's generator
+    void* ext_user = nullptr;
 
     void seed(const uint8_t s[32], int nrounds) {
         for (int i = 0; i < 8; i++)
@@ -52,6 +61,11 @@ struct ChaChaRng {
         cached_blk = 0;
     }
     uint32_t next_u32() {
+        if (ext) {
+            uint8_t b[4];
+            ext(ext_user, b, 4);
+            return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        }
         uint64_t blk = pos >> 4;
         if (!have || blk != cached_blk) {
             chacha_block(key, blk, rounds, block);
@@ -61,6 +75,13 @@ struct ChaChaRng {
         return block[pos++ & 15];
     }
     uint64_t next_u64() {
+        if (ext) {
+            uint8_t b[8];
+            ext(ext_user, b, 8);
+            uint64_t v = 0;
+            for (int i = 7; i >= 0; i--) v = (v << 8) | b[i];
+            return v;
+        }
         uint64_t lo = next_u32();
         uint64_t hi = next_u32();
         return (hi << 32) | lo;

@@ -148,9 +148,11 @@ struct ByteReader {
         memcpy(t, take(48), 48);
         uint8_t flags = t[47] & 0xC0;
         t[47] &= 0x3F;
-        if (flags & 0x40) return g1_affine_identity();
+        // ark-serialize 0.3 SWFlags::from_u8: 0xC0 (infinity AND sign) is not a valid flag combination -> InvalidData
+        if (flags == 0xC0) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 invalid flags");
         G1Affine r;
         if (!fp_from_bytes(t, &r.x)) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 x out of range");
+        if (flags & 0x40) return g1_affine_identity();  // ark-ec reads x (must be a field element) and then ignores it
         Fq y2 = fp_add(fp_mul(fp_sqr(r.x), r.x), fp_one<Fq>());
         Fq y;
         if (!fq_sqrt(y2, &y)) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 x not on curve");
@@ -158,6 +160,9 @@ struct ByteReader {
         bool y_is_larger = fp_cmp(y, ny) > 0;
         bool want_larger = (flags & 0x80) != 0;
         r.y = (y_is_larger == want_larger) ? y : ny;
+        // CanonicalDeserialize::deserialize is the CHECKED form: the point must lie in the prime-order subgroup
+        // (BLS12-377 G1 has a ~2^125 cofactor); ark-ec tests [r]P == O
+        if (!g1_is_inf(g1_mul_limbs(r, FrParams::P, 8))) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 point not in the prime-order subgroup");
         return r;
     }
     G2Affine g2() {
@@ -165,17 +170,19 @@ struct ByteReader {
         memcpy(t, take(96), 96);
         uint8_t flags = t[95] & 0xC0;
         t[95] &= 0x3F;
-        if (flags & 0x40) return g2_identity();
+        if (flags == 0xC0) throw MarlinError(SWM_ERR_SERIALIZATION, "G2 invalid flags");
         G2Affine r;
         r.inf = false;
         if (!fp_from_bytes(t, &r.x.c0) || !fp_from_bytes(t + 48, &r.x.c1))
             throw MarlinError(SWM_ERR_SERIALIZATION, "G2 x out of range");
+        if (flags & 0x40) return g2_identity();
         Fq2 y;
         if (!fq2_sqrt(r.x.square() * r.x + g2_coeff_b(), &y)) throw MarlinError(SWM_ERR_SERIALIZATION, "G2 x not on curve");
         Fq2 ny = -y;
         bool y_is_larger = fq2_less(ny, y);
         bool want_larger = (flags & 0x80) != 0;
         r.y = (y_is_larger == want_larger) ? y : ny;
+        if (!g2_mul(r, FrParams::P, 8).inf) throw MarlinError(SWM_ERR_SERIALIZATION, "G2 point not in the prime-order subgroup");
         return r;
     }
     Commitment commitment() {
@@ -228,12 +235,11 @@ inline Proof deserialize_proof(const uint8_t* data, size_t len) {
     for (uint64_t i = 0; i < ne; i++) pr.evaluations.push_back(r.fr());
     uint64_t nm = r.u64();
     if (nm > 16) throw MarlinError(SWM_ERR_SERIALIZATION, "bad message count");
+    // ark-marlin 0.3 provers only ever send ProverMsg::EmptyMessage (Option::None on the wire).  A FieldElements
+    // message would be absorbed into the Fiat-Shamir transcript by the reference verifier; this verifier has no such
+    // absorb, so a proof carrying one is refused instead of being verified against a different transcript.
     for (uint64_t i = 0; i < nm; i++)
-        if (r.boolean()) {
-            uint64_t k = r.u64();
-            if (k > (1u << 20)) throw MarlinError(SWM_ERR_SERIALIZATION, "bad message length");
-            for (uint64_t j = 0; j < k; j++) r.fr();
-        }
+        if (r.boolean()) throw MarlinError(SWM_ERR_SERIALIZATION, "non-empty prover message");
     uint64_t np = r.u64();
     if (np > 16) throw MarlinError(SWM_ERR_SERIALIZATION, "bad opening count");
     for (uint64_t i = 0; i < np; i++) {

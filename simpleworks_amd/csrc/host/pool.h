@@ -5,6 +5,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -27,35 +28,46 @@ public:
     HostPool(const HostPool&) = delete;
     HostPool& operator=(const HostPool&) = delete;
 
-    // runs fn(0) .. fn(n-1), returns when all have finished
+    // runs fn(0) .. fn(n-1), returns when all have finished.  Each call publishes its own Job object; a worker only
+    // ever touches the Job it copied (under the lock) when it woke up, so a worker that wakes late for an earlier
+    // call finds that call's counter exhausted and cannot claim an index of the next one.
     void parallel_for(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         if (th_.empty() || n == 1) {
             for (int i = 0; i < n; i++) fn(i);
             return;
         }
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->n = n;
+        job->left.store(n, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> g(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0, std::memory_order_relaxed);
-            left_.store(n, std::memory_order_relaxed);
+            job_ = job;
             gen_++;
         }
         cv_.notify_all();
-        drain();
+        drain(*job);
         std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return left_.load(std::memory_order_acquire) == 0 && busy_ == 0; });
-        fn_ = nullptr;
+        done_.wait(g, [&] { return job->left.load(std::memory_order_acquire) == 0; });
+        job_.reset();  // fn dies with the caller's frame: nobody may start on it any more (late wakers see a null job)
     }
 
 private:
-    void drain() {
+    struct Job {
+        const std::function<void(int)>* fn = nullptr;
+        int n = 0;
+        std::atomic<int> next{0}, left{0};
+    };
+    void drain(Job& j) {
         for (;;) {
-            int i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_) break;
-            (*fn_)(i);
-            left_.fetch_sub(1, std::memory_order_release);
+            int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) break;
+            (*j.fn)(i);
+            if (j.left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> g(m_);  // pairs with the waiter's predicate check
+                done_.notify_all();
+            }
         }
     }
     void worker() {
@@ -65,21 +77,17 @@ private:
             cv_.wait(g, [&] { return stop_ || gen_ != seen; });
             if (stop_) return;
             seen = gen_;
-            busy_++;
+            std::shared_ptr<Job> job = job_;  // snapshot under the lock
+            if (!job) continue;
             g.unlock();
-            drain();
+            drain(*job);
             g.lock();
-            busy_--;
-            if (busy_ == 0 && left_.load(std::memory_order_acquire) == 0) done_.notify_all();
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_, done_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0;
-    std::atomic<int> next_{0}, left_{0};
-    int busy_ = 0;
+    std::shared_ptr<Job> job_;
     uint64_t gen_ = 0;
     bool stop_ = false;
 };

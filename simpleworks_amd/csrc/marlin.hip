@@ -33,6 +33,9 @@ struct swm_rng {
     ChaChaRng r;
 };
 struct swm_srs {
+    ~swm_srs() {
+        if (d_powers) (void)hipFree(d_powers);
+    }
     size_t max_degree = 0;
     G1Affine* d_powers = nullptr;  // [beta^i] g, i <= max_degree (device)
     std::vector<G1Affine> gamma_powers;  // [beta^i] gamma_g, i < 3 (host)
@@ -71,6 +74,10 @@ struct GammaTable {
 }  // namespace
 
 struct swm_pk {
+    ~swm_pk() {  // also runs when index_impl / pk_deserialize unwind with a half-built key
+        if (d_powers) (void)hipFree(d_powers);
+        if (d_powers28) (void)hipFree(d_powers28);
+    }
     IndexInfo info;
     uint64_t H = 0, K = 0, X = 0, B = 0;
     unsigned logH = 0, logK = 0, logX = 0, logB = 0;
@@ -1368,12 +1375,15 @@ void is_satisfied_impl(swm_ctx* ctx, const swm_r1cs* cs, int* ok, size_t* first_
         body;                                                 \
         return SWM_OK;                                        \
     } catch (const MarlinError& e) {                          \
-        if (ctx) set_err(ctx, e.code, "%s", e.what());        \
+        drain_streams(ctx);                                   \
+        set_err(ctx, e.code, "%s", e.what());                 \
         return e.code;                                        \
     } catch (const std::bad_alloc&) {                         \
+        drain_streams(ctx);                                   \
         return SWM_ERR_OOM;                                   \
     } catch (const std::exception& e) {                       \
-        if (ctx) set_err(ctx, SWM_ERR_INTERNAL, "%s", e.what()); \
+        drain_streams(ctx);                                   \
+        set_err(ctx, SWM_ERR_INTERNAL, "%s", e.what());       \
         return SWM_ERR_INTERNAL;                              \
     }
 
@@ -1391,6 +1401,14 @@ int swm_rng_from_seed(const uint8_t seed[32], swm_rng** out) {
     (*out)->r.seed(seed, 12);
     return SWM_OK;
 }
+int swm_rng_from_callback(swm_fill_bytes_fn fill_bytes, void* user, swm_rng** out) {
+    if (!out || !fill_bytes) return SWM_ERR_INVALID_ARG;
+    *out = new swm_rng();
+    (*out)->r = test_rng();  // unused state; every draw goes to the callback
+    (*out)->r.ext = fill_bytes;
+    (*out)->r.ext_user = user;
+    return SWM_OK;
+}
 void swm_rng_free(swm_rng* rng) { delete rng; }
 int swm_rng_next_u64(swm_rng* rng, uint64_t* out) {
     if (!rng || !out) return SWM_ERR_INVALID_ARG;
@@ -1406,17 +1424,19 @@ int swm_rng_rand_fr(swm_rng* rng, uint64_t out_mont[4]) {
 
 int swm_generate_universal_srs(swm_ctx* ctx, size_t nc, size_t nv, size_t nnz, swm_rng* rng, swm_srs** out) {
     if (!ctx || !rng || !out) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, *out = universal_setup(ctx, nc, nv, nnz, rng->r));
 }
 void swm_srs_destroy(swm_ctx* ctx, swm_srs* srs) {
     if (!srs) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    if (srs->d_powers) (void)hipFree(srs->d_powers);
+    swm::DeviceGuard g(ctx);
+    if (ctx) drain_streams(ctx);
     delete srs;
 }
 size_t swm_srs_max_degree(const swm_srs* srs) { return srs ? srs->max_degree : 0; }
 int swm_srs_power_of_g(swm_ctx* ctx, const swm_srs* srs, size_t i, uint64_t out_xy[12]) {
     if (!ctx || !srs || !out_xy || i > srs->max_degree) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, {
         G1Affine p = srs_power(ctx, srs->d_powers, i);
         memcpy(out_xy, &p, sizeof(p));
@@ -1426,13 +1446,13 @@ int swm_srs_power_of_g(swm_ctx* ctx, const swm_srs* srs, size_t i, uint64_t out_
 int swm_generate_proving_and_verifying_keys(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** pk,
                                             swm_vk** vk) {
     if (!ctx || !srs || !cs || !pk || !vk) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, index_impl(ctx, srs, cs, pk, vk));
 }
 void swm_pk_destroy(swm_ctx* ctx, swm_pk* pk) {
     if (!pk) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    if (pk->d_powers) (void)hipFree(pk->d_powers);
-    if (pk->d_powers28) (void)hipFree(pk->d_powers28);
+    swm::DeviceGuard g(ctx);
+    if (ctx) drain_streams(ctx);
     delete pk;
 }
 void swm_vk_destroy(swm_vk* vk) { delete vk; }
@@ -1440,6 +1460,7 @@ void swm_vk_destroy(swm_vk* vk) { delete vk; }
 int swm_generate_proof(swm_ctx* ctx, const swm_pk* pk, const swm_r1cs* cs, swm_rng* rng, uint8_t* proof_out, size_t cap,
                        size_t* len) {
     if (!ctx || !pk || !cs || !rng || !proof_out || !len) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, {
         std::vector<uint8_t> bytes = prove_impl(ctx, *pk, cs, rng->r);
         *len = bytes.size();
@@ -1489,6 +1510,7 @@ int swm_proof_validate(const uint8_t* bytes, size_t len) {
 
 int swm_pk_serialize(swm_ctx* ctx, const swm_pk* pk, uint8_t* out, size_t cap, size_t* len) {
     if (!ctx || !pk || !len) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, {
         std::vector<uint8_t> b = pk_serialize(ctx, *pk);
         *len = b.size();
@@ -1500,10 +1522,12 @@ int swm_pk_serialize(swm_ctx* ctx, const swm_pk* pk, uint8_t* out, size_t cap, s
 }
 int swm_pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len, swm_pk** out) {
     if (!ctx || !bytes || !out) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, *out = pk_deserialize(ctx, bytes, len));
 }
 int swm_r1cs_is_satisfied(swm_ctx* ctx, const swm_r1cs* cs, int* ok, size_t* first_bad) {
     if (!ctx || !cs || !ok) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, is_satisfied_impl(ctx, cs, ok, first_bad));
 }
 

@@ -23,17 +23,26 @@ struct MsmJob {
     size_t n = 0;
     WinLayout pl;
     unsigned red_blocks = 0, log_m = 0;
+    int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
+    const uint32_t* host_flags = nullptr;  // tail of the slot: [0] != 0 when a scalar was not a canonical field element
     hipEvent_t done = nullptr;
 };
 
 // d_bases28: the bases with both coordinates pre-multiplied by 2^8 (msm_scale_bases_run), consumed by the 28-bit-limb
 // inner loop of msm_accumulate; d_bases: the plain Montgomery (radix 2^384) points, used by the cold path.
-int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out);
+// d_inf_mask (optional, n bits, zeroed by the caller): bit i is set when point i is the point at infinity (x = y = 0).
+int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out, uint32_t* d_inf_mask = nullptr);
+// Which of a base set's points are the identity: the accumulation kernel adds whatever it is given, so their digits are
+// dropped in msm_digits.  mask == nullptr (the prover: SRS powers are never the identity) skips the test.
+struct MsmInfMask {
+    const uint32_t* mask = nullptr;  // bit (first + i) belongs to point i of this MSM
+    size_t first = 0;
+};
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job);
+                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask());
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
-            G1XYZZ* result);
+            G1XYZZ* result, MsmInfMask inf = MsmInfMask());
 
 }  // namespace swm

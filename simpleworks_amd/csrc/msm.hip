@@ -102,12 +102,30 @@ __device__ __forceinline__ void for_each_digit(const Fr& s, const WinLayout& L, 
 }
 
 // digits[w * n + i] = code of window w of scalar i (coalesced over i).            HBM: 32 B read + 4 W B written / point
+// A scalar that is not a canonical field element (>= r; arkworks' BigInteger256 scalars always are) raises *bad: the
+// recoding only covers 254 bits, so such an input cannot be given a meaning.  Points flagged in the infinity mask get
+// zero digits (they contribute nothing, as in VariableBaseMSM).
 __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
-                                                  uint32_t* __restrict__ digits) {
+                                                  uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
+                                                  size_t inf_first, uint32_t* __restrict__ bad) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr s = scalars[i];
+        bool ge = true;  // s >= r ?
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (s.v[k] != FrParams::P[k]) {
+                ge = s.v[k] > FrParams::P[k];
+                break;
+            }
+        }
+        if (ge) atomicOr(bad, 1u);
         if (mont) s = fp_to_std(s);
-        for_each_digit(s, L, [&](unsigned w, uint32_t code) { digits[(size_t)w * n + i] = code; });
+        bool skip = false;
+        if (inf_mask) {
+            size_t b = inf_first + i;
+            skip = (inf_mask[b >> 5] >> (b & 31)) & 1u;
+        }
+        for_each_digit(s, L, [&](unsigned w, uint32_t code) { digits[(size_t)w * n + i] = skip ? 0u : code; });
     }
 }
 
@@ -749,9 +767,15 @@ static int allow_big_lds(swm_ctx* ctx, int slot, const void* fn, size_t bytes) {
 }
 
 // bases28[i] = (2^8 x, 2^8 y): the same points with coordinates in Montgomery radix 2^392 (infinity stays (0, 0))
-__global__ void __launch_bounds__(256) msm_scale_bases(const G1Affine* __restrict__ in, size_t n, G1Affine* __restrict__ out) {
+__global__ void __launch_bounds__(256) msm_scale_bases(const G1Affine* __restrict__ in, size_t n, G1Affine* __restrict__ out,
+                                                       uint32_t* __restrict__ inf_mask) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (inf_mask) {
+        uint32_t z = 0;
+        for (int j = 0; j < 12; j++) z |= in[i].x.v[j] | in[i].y.v[j];
+        if (z == 0) atomicOr(&inf_mask[i >> 5], 1u << (i & 31));
+    }
     const uint32_t k[12] = SWM_FQ_SCALE256_MONT;
     Fq c;
 #pragma unroll
@@ -761,9 +785,10 @@ __global__ void __launch_bounds__(256) msm_scale_bases(const G1Affine* __restric
     p.y = fp_mul(p.y, c);
     out[i] = p;
 }
-int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out) {
+int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* d_out, uint32_t* d_inf_mask) {
     if (n == 0) return SWM_OK;
-    SWM_LAUNCH(ctx, "msm_scale_bases", msm_scale_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_in, n, d_out);
+    SWM_LAUNCH(ctx, "msm_scale_bases", msm_scale_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_in, n, d_out,
+               d_inf_mask);
     return SWM_OK;
 }
 
@@ -776,7 +801,7 @@ int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* 
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job) {
+                int mont, MsmJob* job, MsmInfMask inf) {
     job->active = false;
     job->n = n;
     if (n == 0) return SWM_OK;
@@ -805,12 +830,17 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_HIP(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
     }
     const size_t slot_bytes = (size_t)MAX_WIN * 16 * sizeof(G1XYZZ);
-    if ((size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > slot_bytes) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
+    const size_t flags_off = slot_bytes - 16;  // the last 16 bytes of a slot carry the status words of the job
+    if ((size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
     if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
     int slot = ctx->next_slot;
+    if (ctx->slot_busy[slot])  // its previous job has not been collected: the download would overwrite live results
+        return set_err(ctx, SWM_ERR_INTERNAL, "msm: more than %d jobs in flight", swm_ctx::MSM_SLOTS);
     ctx->next_slot = (ctx->next_slot + 1) % swm_ctx::MSM_SLOTS;
     if (!ctx->slot_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->slot_event[slot], hipEventDisableTiming));
+    job->slot = slot;
     job->host = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned + slot_bytes * slot);
+    job->host_flags = reinterpret_cast<const uint32_t*>((char*)job->host + flags_off);
     job->done = ctx->slot_event[slot];
     job->pl = pl;
     job->red_blocks = red_blocks;
@@ -901,7 +931,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
-    SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits);
+    SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
+               big_count + 1 /* zeroed with the histogram */);
     // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
     uint32_t SORT_TILE = SORT_TILE_MIN;
     if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
@@ -941,8 +972,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
     SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
                                 ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync((void*)job->host_flags, big_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
     job->active = true;
+    ctx->slot_busy[slot] = true;
     return SWM_OK;
 }
 
@@ -951,6 +984,9 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     if (!job->active) return SWM_OK;
     SWM_HIP(ctx, hipEventSynchronize(job->done));
     job->active = false;
+    ctx->slot_busy[job->slot] = false;
+    if (job->host_flags[0])
+        return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: a scalar is not a canonical field element (>= r)");
     // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per
     // workgroup; W_w by suffix sums over the <= 16 workgroups).  The windows are independent: they are folded on the
     // context's host workers.  Then Horner over the windows (high -> low, c_w doublings each), with the 2^shift of W_w
@@ -1003,9 +1039,9 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 
 // Synchronous form on the context's stream (K1 ABI).
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
-            G1XYZZ* result) {
+            G1XYZZ* result, MsmInfMask inf) {
     MsmJob job;
-    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job));
+    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job, inf));
     return msm_finish(ctx, &job, result);
 }
 

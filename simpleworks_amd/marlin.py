@@ -78,7 +78,7 @@ class Rng:
 
 def _check(rc, what, ctx=None):
     if rc != 0:
-        detail = ctx.lib.swm_last_error(ctx.h).decode(errors="replace") if ctx is not None else ""
+        detail = (ctx.lib.swm_last_error(ctx.h) if ctx is not None else load_library().swm_last_error(None)).decode(errors="replace")
         raise MarlinError(rc, what, detail)
 
 
@@ -94,6 +94,26 @@ def rng_from_seed(seed32):
     buf = (ctypes.c_uint8 * 32)(*bytes(seed32))
     _check(load_library().swm_rng_from_seed(buf, ctypes.byref(h)), "swm_rng_from_seed")
     return Rng(h)
+
+
+_FILL_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+
+
+def rng_from_fill_bytes(fill_bytes):
+    """swm_rng_from_callback: a generator owned by the CALLER behind the Rng handle.  fill_bytes(n) -> n bytes, the next
+    n bytes of the caller's stream (rand's RngCore::fill_bytes).  This is how a binding keeps the reference's
+    `&mut StdRng` parameters (src/marlin/mod.rs:49,73,83) and the draw stream at the same time."""
+    def _cb(_user, dest, n):
+        data = fill_bytes(n)
+        assert len(data) == n
+        ctypes.memmove(dest, data, n)
+    cb = _FILL_FN(_cb)
+    h = _vp()
+    _check(load_library().swm_rng_from_callback(ctypes.cast(cb, ctypes.c_void_p), None, ctypes.byref(h)),
+           "swm_rng_from_callback")
+    r = Rng(h)
+    r._cb = cb  # the trampoline lives as long as the handle
+    return r
 
 
 class ConstraintSystem:

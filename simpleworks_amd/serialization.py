@@ -12,9 +12,7 @@ def serialize_proof(proof):
 def deserialize_proof(bytes_proof):
     data = bytes(bytes_proof)
     buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
-    rc = load_library().swm_proof_validate(buf, len(data))
-    if rc != 0:
-        raise MarlinError(rc, "Error deserializing proof")
+    _check(load_library().swm_proof_validate(buf, len(data)), "Error deserializing proof")
     return MarlinProof(data)
 
 

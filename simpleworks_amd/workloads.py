@@ -104,3 +104,331 @@ def synthetic_r1cs(n, a, b):
 
     packed = PackedR1cs(instance, witness, mat(col_a, col_c), mat(col_b, col_b), mat(col_c, col_d))
     return packed, [c, d]
+
+
+# ===================================================================================================================
+# BASELINE config #5 stand-in: Pedersen-hash Merkle-membership circuit (examples/merkle-tree, SimpleMerkleTree)
+#
+# What the reference proves there (src/merkle_tree/merkle_tree_verification_u8.rs:25-58): a u8 leaf is a member of a
+# Pedersen Merkle tree — public inputs [root, 8 leaf bits LSB-first] (src/merkle_tree/simple_merkle_tree.rs:129-143,
+# src/gadgets/traits.rs:150-164), private authentication path; leaf hash = Pedersen CRH with 144 windows of 4 bits,
+# inner nodes = Pedersen CRH with 128 windows of 4 bits over left || right digests (src/merkle_tree/common.rs:11-52),
+# both on ed-on-BLS12-377 and compressed to the x coordinate (TECompressor); a tree over 2^18 leaves has height 19
+# (simple_merkle_tree.rs:155-163): one leaf hash + 18 two-to-one hashes in the circuit.
+#
+# The reference synthesises that R1CS with ark-r1cs-std / ark-crypto-primitives gadgets, which are not available here
+# (SURVEY.md §8d), so the constraint-by-constraint layout below is OURS: same statement, same I/O convention, same hash
+# (window sizes, bit order, curve), our own gadget for the conditional point addition.  The Pedersen generators are
+# derived from a seeded PRNG instead of ark_std::test_rng (they are circuit constants; [U] either way).  What matters
+# to the hot path is the SHAPE this gives the prover, which the one-term-per-row synthetic circuit lacks:
+#   * multi-term rows (1-3 terms; bit-packing rows with 257 terms), booleanity rows b (1 - b) = 0,
+#   * rows with empty A and B, `0 * 0 = a - b` — the shape simpleworks' own UInt gadgets emit
+#     (src/gadgets/uint8.rs:117-118, :165-167) — from the canonical-range rows of the digests and from the optional
+#     block of simpleworks-style UInt8 operations (shift / xor / and) on the path bytes,
+#   * a 0/1-heavy witness (bits, and products with a zero bit), |K| != |H|.
+# ===================================================================================================================
+ED_A = R_MODULUS - 1          # twisted Edwards a = -1
+ED_D = 3021                   # d
+ED_COFACTOR = 4
+ED_SUBGROUP_ORDER = 2111115437357092606062206234695386632838870926408408195193685246394721360383
+ED_GENERATOR = (4497879464030519973909970603271755437257548612157028181994697785683032656389,
+                4357141146396347889246900916607623952598927460421559113092863576544024487809)
+
+
+def ed_add(p, q):
+    """Unified twisted-Edwards addition on ed-on-BLS12-377 (a = -1, d = 3021) in affine coordinates."""
+    x1, y1 = p
+    x2, y2 = q
+    t = ED_D * x1 % R_MODULUS * x2 % R_MODULUS * y1 % R_MODULUS * y2 % R_MODULUS
+    x3 = (x1 * y2 + y1 * x2) * pow(1 + t, -1, R_MODULUS) % R_MODULUS
+    y3 = (y1 * y2 + x1 * x2) * pow(1 - t, -1, R_MODULUS) % R_MODULUS
+    return x3, y3
+
+
+def ed_mul(p, k):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = ed_add(acc, p)
+        p = ed_add(p, p)
+        k >>= 1
+    return acc
+
+
+def ed_on_curve(p):
+    x, y = p
+    return (ED_A * x * x + y * y - 1 - ED_D * x * x % R_MODULUS * y * y) % R_MODULUS == 0
+
+
+def _fr_sqrt(v):
+    """Tonelli-Shanks in Fr (two-adicity 47)."""
+    v %= R_MODULUS
+    if v == 0:
+        return 0
+    if pow(v, (R_MODULUS - 1) // 2, R_MODULUS) != 1:
+        return None
+    s, q = 47, (R_MODULUS - 1) >> 47
+    z = pow(22, q, R_MODULUS)  # 22 generates Fr*
+    m, c, t, r = s, z, pow(v, q, R_MODULUS), pow(v, (q + 1) // 2, R_MODULUS)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % R_MODULUS
+            i += 1
+        b = pow(c, 1 << (m - i - 1), R_MODULUS)
+        m, c = i, b * b % R_MODULUS
+        t, r = t * c % R_MODULUS, r * b % R_MODULUS
+    return r
+
+
+class _SplitMix:
+    def __init__(self, seed):
+        self.s = seed & ((1 << 64) - 1)
+
+    def next_u64(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+        return z ^ (z >> 31)
+
+    def fr(self):
+        while True:
+            v = 0
+            for k in range(4):
+                v |= self.next_u64() << (64 * k)
+            v &= (1 << 253) - 1
+            if v < R_MODULUS:
+                return v
+
+
+def pedersen_generators(num_windows, window_size, seed):
+    """ark-crypto-primitives pedersen::CRH::setup shape: one random subgroup element per window and its doublings,
+    generators[w][j] = 2^j * base_w.  Bases by try-and-increment on y from a seeded generator, cofactor cleared."""
+    g = _SplitMix(seed)
+    out = []
+    while len(out) < num_windows:
+        y = g.fr()
+        num = (1 - y * y) % R_MODULUS
+        den = (ED_A - ED_D * y * y) % R_MODULUS
+        x = _fr_sqrt(num * pow(den, -1, R_MODULUS))
+        if x is None or x == 0:
+            continue
+        p = ed_mul((x, y), ED_COFACTOR)
+        if p == (0, 1):
+            continue
+        row = [p]
+        for _ in range(window_size - 1):
+            row.append(ed_add(row[-1], row[-1]))
+        out.append(row)
+    return out
+
+
+def pedersen_hash_bits(bits, gens):
+    """Pedersen CRH + TECompressor: x coordinate of sum_k bits[k] * gens[k // ws][k % ws] (missing bits are zero)."""
+    ws = len(gens[0])
+    assert len(bits) <= ws * len(gens)
+    acc = (0, 1)
+    for k, b in enumerate(bits):
+        if b:
+            acc = ed_add(acc, gens[k // ws][k % ws])
+    return acc[0]
+
+
+def _bits_le(v, n):
+    return [(v >> i) & 1 for i in range(n)]
+
+
+class MerkleParams:
+    """Hash parameters of the membership circuit.  digest_bits = 256 with 144 / 128 windows of 4 is the reference's
+    configuration (src/merkle_tree/common.rs:16-30); smaller values give toy instances for the pure-Python prover
+    (only the low digest_bits bits of a child digest enter its parent's hash; the rest is carried in one witness)."""
+
+    def __init__(self, digest_bits=256, leaf_windows=144, inner_windows=128, window_size=4, seed=0x5157_4D41_524C_494E):
+        assert 2 * digest_bits <= inner_windows * window_size and 8 <= leaf_windows * window_size
+        self.digest_bits = digest_bits
+        self.leaf_gens = pedersen_generators(leaf_windows, window_size, seed)
+        self.inner_gens = pedersen_generators(inner_windows, window_size, seed ^ 0xA5A5_A5A5_5A5A_5A5A)
+
+    def leaf_hash(self, leaf_u8):
+        return pedersen_hash_bits(_bits_le(leaf_u8, 8), self.leaf_gens)
+
+    def inner_hash(self, left, right):
+        d = self.digest_bits
+        return pedersen_hash_bits(_bits_le(left, d) + _bits_le(right, d), self.inner_gens)
+
+    def root_from_path(self, leaf_u8, leaf_index, siblings):
+        cur = self.leaf_hash(leaf_u8)
+        for lvl, s in enumerate(siblings):
+            cur = self.inner_hash(s, cur) if (leaf_index >> lvl) & 1 else self.inner_hash(cur, s)
+        return cur
+
+    def build_tree(self, leaves_u8):
+        """All levels of the tree over len(leaves) = 2^h leaves, bottom up (native model of MerkleTree::new,
+        src/merkle_tree/simple_merkle_tree.rs:47-49); returns the list of levels, levels[-1][0] is the root."""
+        assert len(leaves_u8) & (len(leaves_u8) - 1) == 0
+        levels = [[self.leaf_hash(v) for v in leaves_u8]]
+        while len(levels[-1]) > 1:
+            prev = levels[-1]
+            levels.append([self.inner_hash(prev[2 * i], prev[2 * i + 1]) for i in range(len(prev) // 2)])
+        return levels
+
+    @staticmethod
+    def path_of(levels, index):
+        return [levels[lvl][(index >> lvl) ^ 1] for lvl in range(len(levels) - 1)]
+
+
+class _LC:
+    """A linear combination with its value: what a gadget coordinate is between constraints."""
+    __slots__ = ("terms", "value")
+
+    def __init__(self, terms, value):
+        self.terms, self.value = terms, value % R_MODULUS
+
+    def scaled(self, k):
+        k %= R_MODULUS
+        return _LC([(c * k % R_MODULUS, v) for c, v in self.terms], self.value * k)
+
+    def plus(self, o):
+        return _LC(self.terms + o.terms, self.value + o.value)
+
+    def minus(self, o):
+        return self.plus(o.scaled(R_MODULUS - 1))
+
+
+def _cond_add_const(cs, one, acc, point, bit):
+    """acc + bit * point for a CONSTANT point and a boolean variable `bit` (an _LC over one variable):
+        t = X Y;  bt = bit t;  m1 = bit ((cy - 1) X + cx Y);  m2 = bit ((cy - 1) Y + cx X)
+        X3 (1 + k bt) = X + m1;   Y3 (1 - k bt) = Y + m2,   k = d cx cy        (a = -1)
+    six rows, six new witnesses.  acc = None is the identity: the sum is linear in the bit and costs nothing."""
+    cx, cy = point
+    if acc is None:
+        return (bit.scaled(cx), _LC([(1, one)], 1).plus(bit.scaled(cy - 1)))
+    X, Y = acc
+
+    def witness(v):
+        return _LC([(1, cs.new_witness_variable(v % R_MODULUS))], v)
+
+    def product(a, b):
+        w = witness(a.value * b.value)
+        cs.enforce_constraint(a.terms, b.terms, w.terms)
+        return w
+    t = product(X, Y)
+    bt = product(bit, t)
+    m1 = product(bit, X.scaled(cy - 1).plus(Y.scaled(cx)))
+    m2 = product(bit, Y.scaled(cy - 1).plus(X.scaled(cx)))
+    k = ED_D * cx % R_MODULUS * cy % R_MODULUS
+    kbt = bt.scaled(k)
+    den_x = _LC([(1, one)], 1).plus(kbt)
+    den_y = _LC([(1, one)], 1).minus(kbt)
+    num_x, num_y = X.plus(m1), Y.plus(m2)
+    X3 = witness(num_x.value * pow(den_x.value, -1, R_MODULUS))
+    Y3 = witness(num_y.value * pow(den_y.value, -1, R_MODULUS))
+    cs.enforce_constraint(X3.terms, den_x.terms, num_x.terms)
+    cs.enforce_constraint(Y3.terms, den_y.terms, num_y.terms)
+    return (X3, Y3)
+
+
+def _boolean_witness(cs, one, v):
+    """Boolean::new_witness: b (1 - b) = 0."""
+    b = _LC([(1, cs.new_witness_variable(v))], v)
+    cs.enforce_constraint(b.terms, [(1, one), (R_MODULUS - 1, b.terms[0][1])], [])
+    return b
+
+
+def build_merkle_membership(cs, params, leaf_u8, leaf_index, siblings, gadget_byte_ops=0, root=None):
+    """Emits the membership circuit into `cs` (any builder with ark-relations' vocabulary: new_input_variable,
+    new_witness_variable, enforce_constraint(a, b, c), one()).  Public inputs, in order: root, then the 8 leaf bits
+    LSB-first — the vector SimpleMerkleTree::verify rebuilds (src/merkle_tree/simple_merkle_tree.rs:129-143).
+    `root` overrides the public root (a wrong one gives an unsatisfied system: the final row fails).
+    gadget_byte_ops > 0 appends that many simpleworks-style UInt8 operations (shl / xor / and, cycling) on the bytes of
+    the decomposed digests: 8 new boolean witnesses and 8-16 rows each, half of them with empty A and B
+    (src/gadgets/uint8.rs:117-118, :165-167).  Returns the public-input list [root, b0..b7]."""
+    one = cs.one()
+    d = params.digest_bits
+    true_root = params.root_from_path(leaf_u8, leaf_index, siblings)
+    pub_root = true_root if root is None else root % R_MODULUS
+    root_v = _LC([(1, cs.new_input_variable(pub_root))], pub_root)
+    leaf_bits = []
+    for i in range(8):  # UInt8::new_input: 8 booleans, least significant first
+        v = (leaf_u8 >> i) & 1
+        b = _LC([(1, cs.new_input_variable(v))], v)
+        cs.enforce_constraint(b.terms, [(1, one), (R_MODULUS - 1, b.terms[0][1])], [])
+        leaf_bits.append(b)
+    acc = None
+    ws = len(params.leaf_gens[0])
+    for k, b in enumerate(leaf_bits):
+        acc = _cond_add_const(cs, one, acc, params.leaf_gens[k // ws][k % ws], b)
+    cur = acc[0]
+    byte_pool = []
+    ws = len(params.inner_gens[0])
+    for lvl, sib in enumerate(siblings):
+        dirbit = _boolean_witness(cs, one, (leaf_index >> lvl) & 1)
+        s = _LC([(1, cs.new_witness_variable(sib % R_MODULUS))], sib)
+        # left = dir ? sibling : cur  (one row), right = cur + sibling - left (linear)
+        left_v = s.value if dirbit.value else cur.value
+        left = _LC([(1, cs.new_witness_variable(left_v))], left_v)
+        cs.enforce_constraint(dirbit.terms, s.minus(cur).terms, left.minus(cur).terms)
+        right = cur.plus(s).minus(left)
+        bits = []
+        for child in (left, right):
+            cb = [_boolean_witness(cs, one, (child.value >> i) & 1) for i in range(d)]
+            packed = _LC([], 0)
+            for i, b in enumerate(cb):
+                packed = packed.plus(b.scaled(1 << i))
+            if d < 256:  # toy digests: the bits above digest_bits travel in one unconstrained witness
+                hi = child.value >> d
+                packed = packed.plus(_LC([(1 << d, cs.new_witness_variable(hi))], hi << d))
+            cs.enforce_constraint(packed.minus(child).terms, [(1, one)], [])
+            for i in range(253, d):  # canonical range: r < 2^253, the top bits are zero — rows `0 * 0 = bit`
+                cs.enforce_constraint([], [], cb[i].terms)
+            bits += cb
+            for i in range(0, d - 7, 8):
+                byte_pool.append(cb[i:i + 8])
+        acc = None
+        for k, b in enumerate(bits):
+            acc = _cond_add_const(cs, one, acc, params.inner_gens[k // ws][k % ws], b)
+        cur = acc[0]
+    cs.enforce_constraint(cur.minus(root_v).terms, [(1, one)], [])  # is_member.enforce_equal(TRUE)
+    # optional block of simpleworks UInt8 gadget rows over the path bytes
+    for op in range(gadget_byte_ops):
+        a = byte_pool[(7 * op) % len(byte_pool)]
+        b = byte_pool[(11 * op + 3) % len(byte_pool)]
+        kind = op % 3
+        if kind == 0:  # shift_left by k (src/gadgets/uint8.rs:141-185): new UInt8 witness + rows 0 * 0 = lc
+            k = 1 + op % 7
+            c = [_boolean_witness(cs, one, a[i - k].value if i >= k else 0) for i in range(8)]
+            for i in range(8):
+                cs.enforce_constraint([], [], c[i].terms if i < k else a[i - k].minus(c[i]).terms)
+        elif kind == 1:  # xor (ark-r1cs-std Boolean::xor): (a + a) * b = a + b - c
+            c = []
+            for i in range(8):
+                v = a[i].value ^ b[i].value
+                ci = _LC([(1, cs.new_witness_variable(v))], v)
+                cs.enforce_constraint(a[i].scaled(2).terms, b[i].terms, a[i].plus(b[i]).minus(ci).terms)
+                c.append(ci)
+        else:  # and: a * b = c
+            c = []
+            for i in range(8):
+                v = a[i].value & b[i].value
+                ci = _LC([(1, cs.new_witness_variable(v))], v)
+                cs.enforce_constraint(a[i].terms, b[i].terms, ci.terms)
+                c.append(ci)
+        byte_pool.append(c)
+    return [pub_root] + [(leaf_u8 >> i) & 1 for i in range(8)]
+
+
+def merkle_membership_circuit(height=19, leaf_u8=0xA7, leaf_index=None, seed=7, gadget_byte_ops=2400, params=None,
+                              root=None):
+    """BASELINE config #5 stand-in as a ConstraintSystem.  height = merkle_tree_height(number of leaves)
+    (src/merkle_tree/simple_merkle_tree.rs:155-163): height - 1 two-to-one hashes; 19 for 2^18 leaves.  The siblings
+    are random digests (the other 2^18 - 1 leaves are not needed to prove one path).  Returns (cs, public_inputs, params)."""
+    params = params or MerkleParams()
+    g = _SplitMix(seed)
+    levels = height - 1
+    siblings = [g.fr() for _ in range(levels)]
+    if leaf_index is None:
+        leaf_index = g.next_u64() % (1 << levels)
+    cs = ConstraintSystem()
+    public = build_merkle_membership(cs, params, leaf_u8, leaf_index, siblings, gadget_byte_ops, root)
+    return cs, public, params

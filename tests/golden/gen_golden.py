@@ -235,7 +235,56 @@ def gen_marlin():
     dump("marlin.json", out)
 
 
+MERKLE_TINY = dict(digest_bits=8, leaf_windows=2, inner_windows=4, window_size=4, seed=11,
+                   leaves=[3, 200, 77, 9], leaf_index=2, gadget_byte_ops=6)
+
+
+def merkle_tiny_system(cs):
+    """The Pedersen-Merkle membership circuit of simpleworks_amd/workloads.py (BASELINE config #5 stand-in) at toy
+    hash parameters, emitted into `cs`.  The circuit DESCRIPTION is host logic shared with the product; the prover
+    that turns it into proof bytes below is the independent Python model."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from simpleworks_amd import workloads as W
+    kw = MERKLE_TINY
+    P = W.MerkleParams(kw["digest_bits"], kw["leaf_windows"], kw["inner_windows"], kw["window_size"], kw["seed"])
+    levels = P.build_tree(kw["leaves"])
+    path = P.path_of(levels, kw["leaf_index"])
+    public = W.build_merkle_membership(cs, P, kw["leaves"][kw["leaf_index"]], kw["leaf_index"], path, kw["gadget_byte_ops"])
+    assert public[0] == levels[-1][0]
+    return public
+
+
+def gen_marlin_merkle():
+    cs = M.ConstraintSystem()
+    public = merkle_tiny_system(cs)
+    assert cs.is_satisfied()
+    a_m, b_m, c_m = cs.to_matrices()
+    nnz = max(sum(len(r) for r in m) for m in (a_m, b_m, c_m))
+    nv = len(cs.instance) + len(cs.witness)
+    sizes = (cs.num_constraints, nv, nnz)
+    rng = M.generate_rand()
+    t = time.time()
+    srs = M.generate_universal_srs(*sizes, rng)
+    print(" merkle_tiny: srs %.0fs" % (time.time() - t), sizes, srs.max_degree)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    print(" merkle_tiny: index %.0fs" % (time.time() - t))
+    trace = {}
+    proof = M.prove(pk, cs, rng, trace)
+    pbytes = M.serialize_proof(proof)
+    assert M.verify_proof(vk, public, M.deserialize_proof(pbytes), rng)
+    wrong = list(public)
+    wrong[3] ^= 1
+    assert not M.verify_proof(vk, wrong, M.deserialize_proof(pbytes), M.generate_rand())
+    print(" merkle_tiny: prove+verify %.0fs" % (time.time() - t), len(pbytes))
+    dump("marlin_merkle.json", {"merkle_tiny": {
+        "circuit": MERKLE_TINY, "srs": list(sizes), "max_degree": srs.max_degree,
+        "public_input": [hx(x) for x in public], "num_constraints": vk["num_constraints"],
+        "num_variables": vk["num_variables"], "num_non_zero": vk["num_non_zero"],
+        "challenges": {k: hx(trace[k]) for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi")},
+        "proof": pbytes.hex(), "vk": M.serialize_verifying_key(vk).hex()}})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fields", "g1_msm", "ntt", "misc", "rng", "marlin"]
+    which = sys.argv[1:] or ["fields", "g1_msm", "ntt", "misc", "rng", "marlin", "marlin_merkle"]
     for w in which:
         globals()["gen_" + w]()

@@ -294,6 +294,93 @@ def test_ntt_roundtrip_2_24_and_linearity(ctx, orc):
     assert np.array_equal(s, outs[2])
 
 
+def test_msm_infinity_bases(ctx, orc):
+    """The point at infinity (x = y = 0) is a valid base (ark-ec VariableBaseMSM accepts zero bases): first, middle,
+    last and only position of a bucket, at a size where whole segments run through the 28-bit fast path."""
+    from pyref.prng import fr_array
+    g = golden("msm.json")
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    n = 4096
+    bases = orc.srs_bases(n, h2i(g["tau"]), G)
+    for holes in ([0], [n - 1], [0, 1, 2, 3], list(range(5, n, 97)), list(range(0, n, 2))):
+        b = bases.copy()
+        b[holes] = 0
+        bh = ctx.srs_upload(b)
+        # every scalar equal: one bucket per window holds every point, so the holes sit first / inside / last in a chain
+        for sc in (fr_array(n, 300), np.ascontiguousarray(np.tile(ints_to_limbs([0xABCDEF123], 4), (n, 1)))):
+            keep = np.ones(n, dtype=bool)
+            keep[holes] = False
+            ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[keep]), np.ascontiguousarray(sc[keep]), threads=4))
+            assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref, holes[:4]
+        # with an offset into the base set the mask is read at the shifted position
+        sc = fr_array(64, 301)
+        keep = np.array([(3 + i) not in set(holes) for i in range(64)])
+        ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[3:67][keep]), np.ascontiguousarray(sc[keep])))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc, offset=3)) == ref
+        bh.free()
+    only = np.zeros((1, 12), dtype=np.uint64)
+    bh = ctx.srs_upload(only)
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, ints_to_limbs([12345], 4))) is None
+    bh.free()
+
+
+def test_msm_rejects_non_canonical_scalars(ctx, orc):
+    """include/swmarlin.h: scalars must be canonical (< r); r itself, r + 1 and 2^256 - 1 fail with INVALID_ARG."""
+    import simpleworks_amd as swm
+    g = golden("msm.json")
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(64, h2i(g["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    ok = ints_to_limbs([R - 1] * 64, 4)
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, ok)) is not None
+    for bad in (R, R + 1, (1 << 256) - 1, 1 << 255):
+        sc = ok.copy()
+        sc[17] = ints_to_limbs([bad], 4)[0]
+        with pytest.raises(swm.SwmError) as e:
+            ctx.msm_g1(bh, sc)
+        assert e.value.code == -1 and "canonical" in str(e.value)
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, ok)) is not None  # the context stays usable
+    bh.free()
+
+
+def test_msm_vs_oracle_2_22(ctx, orc):
+    """BASELINE configs[3] size: 2^22 points, uniform scalars, bit-exact against the C oracle (all host threads)."""
+    from pyref.prng import fr_array
+    n = 1 << 22
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    sc = fr_array(n, 422)
+    ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=orc.lib.oracle_max_threads()))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref
+    bh.free()
+
+
+def test_entry_points_from_another_thread(ctx, orc):
+    """A context is bound to its GPU, not to the thread that created it: every entry point selects the context's device
+    (a fresh thread has device 0 current here, but no HIP state of its own; the call must still work and agree)."""
+    import threading
+    from pyref.prng import fr_array
+    x = orc.fr_to_mont(fr_array(1 << 12, 9))
+    want = orc.ntt(x, 12, 0, 0, 2)
+    out = {}
+
+    def run():
+        try:
+            out["ntt"] = ctx.ntt_fr(x, 12)
+            d = ctx.to_device(x)
+            ctx.ntt_fr_dev(d, 12)
+            out["dev"] = d.download(x.shape)
+            d.free()
+        except Exception as e:  # surfaced in the main thread
+            out["err"] = e
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    assert "err" not in out, out.get("err")
+    assert np.array_equal(out["ntt"], want) and np.array_equal(out["dev"], want)
+
+
 # ------------------------------------------------------------------------------------------------ K3 / K4
 def test_spmv_golden_and_random(ctx, orc):
     s = golden("misc.json")["spmv"]

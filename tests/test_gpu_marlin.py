@@ -313,3 +313,88 @@ def test_error_paths_return_status_codes(M, S, W):
                     np.zeros((3, 4), np.uint64))            # column index beyond z
     pk16.free()
     srs.free()
+
+
+def test_callback_rng_reproduces_golden_bytes(M, S, W):
+    """swm_rng_from_callback: a shim that keeps the reference's `&mut StdRng` parameters (src/marlin/mod.rs:49,73,83)
+    hands the library a fill_bytes trampoline over ITS generator.  Fed with ark_std::test_rng's stream, setup + index +
+    prove through the callback emit the golden bytes — including the bulk draw of the mask polynomial."""
+    for name in ("synthetic_32", "random_sparse"):
+        case = golden("marlin.json")[name]
+        src = M.generate_rand()  # stands for the caller's StdRng
+        served = [0]
+
+        def fill(n):
+            served[0] += n
+            out = bytearray()
+            while len(out) < n:
+                out += src.next_u64().to_bytes(8, "little")
+            assert len(out) == n  # the library only asks for whole u64 / whole candidates
+            return bytes(out)
+        rng = M.rng_from_fill_bytes(fill)
+        srs = M.generate_universal_srs(*case["srs"], rng)
+        if name.startswith("random_"):
+            cs = W.random_sparse_circuit(**case["circuit"])
+        else:
+            cs = W.synthetic_circuit(case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        proof = M.generate_proof(cs, pk, rng)
+        assert S.serialize_verifying_key(vk).hex() == case["vk"]
+        assert S.serialize_proof(proof).hex() == case["proof"]
+        assert M.verify_proof(vk, [h2i(x) for x in case["public_input"]], proof, rng)
+        assert served[0] > 3 * 32 * 32  # the mask coefficients came through the callback
+        pk.free()
+        srs.free()
+
+
+def test_prove_verify_2_18(M, W):
+    n = 1 << 18
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 0xabcdef, 0x13579b)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
+    proof = M.generate_proof(cs, pk, rng)
+    assert M.verify_proof(vk, public, proof, M.generate_rand())
+    pk.free()
+
+
+def test_two_contexts_two_threads_prove_concurrently(M, W):
+    """SURVEY.md §8b threading row: several host threads prove concurrently on different systems, one context each.
+    Both proofs must equal what the same (key, seed) gives when proved alone."""
+    import threading
+    import simpleworks_amd as swm
+    n = 1 << 16
+    seeds = [bytes([7] * 32), bytes([9] * 32)]
+    ctxs = [swm.Context(0), swm.Context(0)]
+    setups = []
+    for i, c in enumerate(ctxs):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(n, n, n, rng, ctx=c)
+        cs, public = W.synthetic_r1cs(n, 1000 + i, 77 + i)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        alone = M.generate_proof(cs, pk, M.rng_from_seed(seeds[i]))
+        setups.append((cs, public, pk, vk, alone))
+    out = [None, None]
+
+    def run(i):
+        cs, public, pk, vk, _ = setups[i]
+        try:
+            out[i] = [M.generate_proof(cs, pk, M.rng_from_seed(seeds[i])) for _ in range(3)]
+        except Exception as e:
+            out[i] = e
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        cs, public, pk, vk, alone = setups[i]
+        assert not isinstance(out[i], Exception), out[i]
+        for p in out[i]:
+            assert p.data == alone.data
+        assert M.verify_proof(vk, public, out[i][0], M.generate_rand())
+        pk.free()
+    for c in ctxs:
+        c.close()

@@ -116,3 +116,95 @@ def test_python_reference_agrees_with_fixture():
     proof = P.generate_proof(cs, pk, rng)
     assert P.serialize_proof(proof).hex() == case["proof"]
     assert P.serialize_verifying_key(vk).hex() == case["vk"]
+
+
+def _compressed_g1(x, y):
+    """ark-serialize 0.3 compressed G1: x little-endian, bit 7 of the last byte = y is the larger root."""
+    from oracle_lib import Q
+    b = bytearray(x.to_bytes(48, "little"))
+    if y > (Q - y) % Q:
+        b[47] |= 0x80
+    return bytes(b)
+
+
+def test_deserialisers_are_the_checked_form():
+    """CanonicalDeserialize::deserialize (what src/marlin/serialization.rs:14-17,26-31 call) validates points: on the
+    curve AND in the prime-order subgroup; flag byte 0xC0 is invalid; ark-marlin provers never send prover messages."""
+    from oracle_lib import Q
+    from pyref import bls12_377 as bls
+    case = golden("marlin.json")["synthetic_8"]
+    raw = bytes.fromhex(case["proof"])
+    assert S.deserialize_proof(raw)  # baseline: parses
+    # a point on the curve outside the r-torsion (BLS12-377 G1 has a ~2^125 cofactor: almost every curve point)
+    x = 5
+    while True:
+        y = bls.fq_sqrt((x * x * x + 1) % Q)
+        if y is not None and bls.g1_mul_fast((x, y), bls.R) is not None:
+            break
+        x += 1
+    assert (y * y - x * x * x - 1) % Q == 0
+    t = bytearray(raw)
+    t[16:16 + 48] = _compressed_g1(x, y)
+    with pytest.raises(M.MarlinError) as e:
+        S.deserialize_proof(bytes(t))
+    assert e.value.code == -7 and "subgroup" in str(e.value)
+    vk = S.deserialize_verifying_key(bytes.fromhex(case["vk"]))
+    with pytest.raises(M.MarlinError):  # the verifier parses the proof with the same checks
+        M.verify_proof(vk, _pub(case), M.MarlinProof(bytes(t)), M.generate_rand())
+    # the same point IS accepted once the cofactor is cleared (control: the rejection above was the subgroup test)
+    px, py = bls.g1_mul_fast((x, y), bls.G1_COFACTOR)
+    t[16:16 + 48] = _compressed_g1(px, py)
+    assert S.deserialize_proof(bytes(t))
+    # verifying key: first index commitment replaced by the torsion point
+    vkb = bytearray(bytes.fromhex(case["vk"]))
+    vkb[40:40 + 48] = _compressed_g1(x, y)
+    with pytest.raises(M.MarlinError):
+        S.deserialize_verifying_key(bytes(vkb))
+    # flags: infinity AND sign is not a valid combination
+    t = bytearray(raw)
+    t[16 + 47] |= 0xC0
+    with pytest.raises(M.MarlinError) as e:
+        S.deserialize_proof(bytes(t))
+    assert "flags" in str(e.value)
+    # x not on the curve
+    xb = 2
+    while bls.fq_sqrt((xb ** 3 + 1) % Q) is not None:
+        xb += 1
+    t = bytearray(raw)
+    t[16:16 + 48] = xb.to_bytes(48, "little")
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proof(bytes(t))
+    # a FieldElements prover message (Option::Some) in place of EmptyMessage: refused, not silently ignored
+    n_evals = int.from_bytes(raw[569:577], "little")
+    off = 569 + 8 + 32 * n_evals + 8
+    assert raw[off:off + 3] == b"\x00\x00\x00" and raw[off - 8:off] == (3).to_bytes(8, "little")
+    t = bytearray(raw)
+    t[off:off + 1] = b"\x01" + (1).to_bytes(8, "little") + (7).to_bytes(32, "little")
+    with pytest.raises(M.MarlinError) as e:
+        S.deserialize_proof(bytes(t))
+    assert "prover message" in str(e.value)
+
+
+def test_callback_rng_consumes_the_callers_stream():
+    """swm_rng_from_callback: draws through the caller's fill_bytes are the draws of the built-in generator when the
+    callback serves the same ChaCha12 stream (word for word: next_u64 = 8 bytes, Fr::rand = 32 bytes per candidate)."""
+    g = golden("rng.json")
+    src = M.generate_rand()
+    calls = []
+
+    def fill(n):
+        assert n % 4 == 0
+        calls.append(n)
+        out = b""
+        while len(out) < n:  # the reference stream, pulled 8 bytes at a time
+            out += src.next_u64().to_bytes(8, "little")
+        return out[:n]
+    rng = M.rng_from_fill_bytes(fill)
+    assert [hex(rng.next_u64()) for _ in range(6)] == g["test_rng_u64"][:6]
+    assert calls == [8] * 6
+    # Fr::rand through the callback equals Fr::rand of a fresh built-in generator advanced by the same six u64s
+    ref = M.generate_rand()
+    for _ in range(6):
+        ref.next_u64()
+    for _ in range(5):
+        assert np.array_equal(rng.rand_fr_mont(), ref.rand_fr_mont())
