@@ -33,19 +33,40 @@ METRIC = "Marlin prove() constraints/sec at 2^20 R1CS; G1 MSM points/sec"
 FR_R = int("12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001", 16)
 
 
-def _oracle_inputs():
-    from oracle_lib import Oracle, golden, h2i
-    orc = Oracle()
+def _oracle_inputs(native=False):
+    """The CPU checker.  native=True (cpu_baseline leg only): a copy compiled on THIS host with -O3 -march=native
+    (oracle/Makefile `native`) when gcc is present, so that the CPU column is not handicapped by portable code."""
+    from oracle_lib import Oracle, golden, h2i, ORACLE_DIR
+    path, flags = None, "-O3 (portable build shipped with the repo)"
+    if native:
+        import subprocess
+        try:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            path = os.path.join(ORACLE_DIR, "_build", "liboracle_native.so")
+            flags = "-O3 -march=native -fopenmp, gcc on the bench host"
+        except Exception:
+            path = None
+    orc = Oracle(path)
     tau = h2i(golden("msm.json")["tau"])
     G = orc.points_to_mont([tuple(h2i(v) for v in golden("g1.json")["generator"])])
-    return orc, tau, G
+    return orc, tau, G, flags
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline_msm(log_n_sample):
     """arkworks-algorithm CPU restatement (oracle/oracle.c: VariableBaseMSM, one thread per window) on a bounded
-    sample of the MSM workload, timed on this host."""
+    sample of the MSM workload, timed on this host: all window threads, and one thread."""
     from pyref.prng import fr_array
-    orc, tau, G = _oracle_inputs()
+    orc, tau, G, flags = _oracle_inputs(native=True)
     n = 1 << log_n_sample
     bases = orc.srs_bases(n, tau, G)
     sc = fr_array(n, 7)
@@ -55,38 +76,69 @@ def cpu_baseline_msm(log_n_sample):
     t0 = time.perf_counter()
     orc.msm(bases, sc, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": "one 2^%d-point G1 MSM, arkworks Pippenger (c=%d, %d windows, one thread per window), %.2f s"
-                      % (log_n_sample, c, nwin, dt)}
-
-
-def cpu_baseline_prove(log_n_sample):
-    """CPU port of one prove() at a bounded size: the oracle's arkworks-algorithm kernels (Pippenger MSM with arkworks'
-    window rule, radix-2 FFT, both with OpenMP where arkworks' `parallel` feature uses rayon) run over the SAME call
-    list one GPU prove() issues at N = 2^log_n_sample (17 MSMs, 19 NTTs; sizes below), with random
-    coefficients.  Reported as constraints/s = N / total time."""
-    from pyref.prng import fr_array
-    orc, tau, G = _oracle_inputs()
-    N = 1 << log_n_sample
-    threads = max(1, min(orc.lib.oracle_max_threads(), os.cpu_count() or 1, 32))
-    bases = orc.srs_bases(3 * N, tau, G)
-    msm_sizes = [N, N + 1, N + 1, 3 * N, N, N - 1, N - 1, 2 * N + 1, N - 1, N - 1, 3 * N - 3, 3 * N - 1, N - 2, 3 * N - 4, N - 2]
-    ntt_logs = [log_n_sample] * 9 + [log_n_sample + 2] * 10
-    sc = fr_array(3 * N, 8)
-    x = orc.fr_to_mont(fr_array(4 * N, 9))
+    n1 = n >> 2
     t0 = time.perf_counter()
-    for m in msm_sizes:
-        orc.msm(np.ascontiguousarray(bases[:m]), np.ascontiguousarray(sc[:m]), threads=threads)
-    t_msm = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    for lg in ntt_logs:
-        orc.ntt(np.ascontiguousarray(x[: 1 << lg]), lg, 0, 0, threads)
-    t_ntt = time.perf_counter() - t1
-    dt = t_msm + t_ntt
-    return {"value": N / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
-            "sample": "kernel calls of one prove() at N=2^%d replayed on the CPU oracle: %d MSMs (%.1f N points, %.2f s) + %d "
-                      "NTTs (%.2f s); mat-vec and pointwise work omitted (< 5 %%)"
-                      % (log_n_sample, len(msm_sizes), sum(msm_sizes) / N, t_msm, len(ntt_logs), t_ntt)}
+    orc.msm(np.ascontiguousarray(bases[:n1]), np.ascontiguousarray(sc[:n1]), threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "points/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+            "host_threads": os.cpu_count(), "build": flags,
+            "sample": "one 2^%d-point G1 MSM, arkworks Pippenger (c=%d, %d windows, one thread per window as ark-ec's "
+                      "`parallel` feature), %.2f s" % (log_n_sample, c, nwin, dt),
+            "one_thread": {"value": n1 / dt1, "unit": "points/s", "cores": 1,
+                           "sample": "one 2^%d-point MSM on one thread, %.2f s" % (log_n_sample - 2, dt1)}}
+
+
+def cpu_baseline_prove(calls, N, mats, z, log_shift_1t):
+    """CPU port of one prove(): the oracle's arkworks-algorithm kernels (Pippenger MSM with arkworks' window rule and
+    one thread per window, radix-2 FFT and row-parallel mat-vec with OpenMP where arkworks' `parallel` feature uses
+    rayon) replayed over the K1-K3 call list the library LOGGED for one GPU proof of this workload,
+    at full size on all host threads, and with every size divided by 2^log_shift_1t on one thread.  The pointwise work
+    between the kernels is not replayed (a few % of a CPU proof).  constraints/s = N / total time."""
+    from pyref.prng import fr_array
+    orc, tau, G, flags = _oracle_inputs(native=True)
+    all_threads = max(1, min(orc.lib.oracle_max_threads(), os.cpu_count() or 1))
+    msm_sizes = [v for k, v in calls if k == "m"]
+    ntt_logs = [v for k, v in calls if k == "n"]
+    spmv = [v for k, v in calls if k == "s"]
+    max_m = max(msm_sizes)
+    bases = orc.srs_bases(max_m, tau, G)
+    sc = fr_array(max_m, 8)
+    x = orc.fr_to_mont(fr_array(1 << max(ntt_logs), 9))
+
+    def replay(shift, threads):
+        t = {"msm": 0.0, "ntt": 0.0, "spmv": 0.0}
+        t0 = time.perf_counter()
+        for m in msm_sizes:
+            m = max(m >> shift, 1)
+            orc.msm(np.ascontiguousarray(bases[:m]), np.ascontiguousarray(sc[:m]), threads=threads)
+        t["msm"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for lg in ntt_logs:
+            lg = max(lg - shift, 1)
+            orc.ntt(np.ascontiguousarray(x[: 1 << lg]), lg, 0, 0, threads)
+        t["ntt"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(len(spmv)):
+            rowptr, col, val = mats[i % len(mats)]
+            rows = max((len(rowptr) - 1) >> shift, 1)
+            rp = np.ascontiguousarray(rowptr[: rows + 1])
+            orc.spmv(rp, col, val, z, threads=threads)
+        t["spmv"] = time.perf_counter() - t0
+        return t
+    ta = replay(0, all_threads)
+    t1 = replay(log_shift_1t, 1)
+    tot_a, tot_1 = sum(ta.values()), sum(t1.values())
+    desc = "%d MSMs (%.1f N points), %d NTTs (%.1f N elements), %d mat-vecs" % (
+        len(msm_sizes), sum(msm_sizes) / N, len(ntt_logs), sum(1 << l for l in ntt_logs) / N, len(spmv))
+    return {"value": N / tot_a, "unit": "constraints/s", "cores": all_threads, "kind": "port",
+            "cpu_model": _cpu_model(), "host_threads": os.cpu_count(), "build": flags,
+            "sample": "the K1-K3 call list of ONE proof at full size (N = %d: %s) replayed on the arkworks-algorithm CPU "
+                      "restatement with %d threads: MSM %.1f s (window-parallel: at most %d busy), NTT %.1f s, mat-vec %.2f s"
+                      % (N, desc, all_threads, ta["msm"], (253 + orc.lib.oracle_msm_window(max_m) - 1) // orc.lib.oracle_msm_window(max_m),
+                         ta["ntt"], ta["spmv"]),
+            "one_thread": {"value": (N >> log_shift_1t) / tot_1, "unit": "constraints/s", "cores": 1,
+                           "sample": "the same call list with every size divided by %d (N = %d) on ONE thread: MSM %.1f s, "
+                                     "NTT %.1f s, mat-vec %.2f s" % (1 << log_shift_1t, N >> log_shift_1t, t1["msm"], t1["ntt"], t1["spmv"])}}
 
 
 def main():
@@ -96,6 +148,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="prove", choices=["prove", "msm", "prove_sharded"])
     ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--circuit", default="synthetic", choices=["synthetic", "merkle"],
+                    help="prove workloads: `synthetic` = the 2^L-row a*b=c circuit of BASELINE configs[1-3] (default, the "
+                         "headline); `merkle` = the Pedersen-hash Merkle-membership circuit of BASELINE configs[4] "
+                         "(tree over 2^18 leaves, + the simpleworks UInt8 gadget block; --log-n is ignored)")
     ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true",
@@ -139,7 +195,7 @@ def main():
     if args.workload == "msm":
         from oracle_lib import ints_to_limbs
         from pyref.prng import fr_array
-        orc, tau, G = _oracle_inputs()  # oracle used for INPUT generation only ([tau^i]G bases)
+        orc, tau, G, _ = _oracle_inputs()  # oracle used for INPUT generation only ([tau^i]G bases)
         shift = pow(tau, rank * n, FR_R)
         G_r = orc.fixed_base_mul(G, ints_to_limbs([shift], 4), threads=1) if rank else G
         bases = orc.srs_bases(n, tau, np.ascontiguousarray(G_r.reshape(1, 12)))
@@ -170,8 +226,16 @@ def main():
             from simpleworks_amd.dist import enable_sharded_prover
             enable_sharded_prover(ctx)
         rng = M.generate_rand()
-        srs = M.generate_universal_srs(n, n, n, rng)
-        cs, public = W.synthetic_r1cs(n, 0x1234567 + (0 if sharded else rank), 0x7654321)
+        if args.circuit == "merkle":
+            mcs, public, _ = W.merkle_membership_circuit(leaf_u8=(0xA7 + (0 if sharded else rank)) & 0xFF)
+            cs = mcs.pack()
+            n = cs.num_constraints
+            nvars = cs.instance.shape[0] + cs.witness.shape[0]
+            nnz = max(int(m[0][-1]) for m in cs.mats)
+            srs = M.generate_universal_srs(n, nvars, nnz, rng)
+        else:
+            srs = M.generate_universal_srs(n, n, n, rng)
+            cs, public = W.synthetic_r1cs(n, 0x1234567 + (0 if sharded else rank), 0x7654321)
         pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
         srs.free()
         last = {}
@@ -180,8 +244,13 @@ def main():
             last["proof"] = M.generate_proof(cs, pk, rng)
         dominant, units, unit = "msm_accumulate", n, "constraints/s"
         alg_bytes = None
-        workload = ("marlin_prove: synthetic R1CS, 2^%d constraints = variables = non-zeros per matrix (|H| = |K| = 2^%d), "
-                    "SRS + proving key device resident" % (args.log_n, args.log_n))
+        if args.circuit == "merkle":
+            workload = ("marlin_prove: Pedersen-hash Merkle-membership circuit (BASELINE configs[4] stand-in: tree height 19 = "
+                        "2^18 leaves, 256-bit digests, + 2400 simpleworks UInt8 gadget ops): %d constraints, %d variables, "
+                        "max nnz %d (|H| = 2^17, |K| = 2^18), SRS + proving key device resident" % (n, nvars, nnz))
+        else:
+            workload = ("marlin_prove: synthetic R1CS, 2^%d constraints = variables = non-zeros per matrix (|H| = |K| = 2^%d), "
+                        "SRS + proving key device resident" % (args.log_n, args.log_n))
 
     def sync():
         ctx.synchronize()
@@ -193,7 +262,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.profile_reset()
-    ctx.profile_enable(1 if args.profile_all else 2)  # HIP events around msm_accumulate (roofline) or around everything
+    ctx.profile_enable(1 if args.profile_all else 2)  # HIP events around the roofline kernels (msm_accumulate, ntt_pass, spmv_*) or around everything
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -218,16 +287,40 @@ def main():
             # Algorithmic bytes per launch = 128 B x (points the library logged) / (MSM launches)  (SURVEY §8d).
             alg_bytes = 128.0 * work["msm_points"] / work["msm_calls"]
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected
-        # separately as MI355X_MICROARCH.md prescribes; summary committed under profiles/), scaled per point
-        traffic = None
+        # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need their own rocprofv3 invocation,
+        # MI355X_MICROARCH.md); taken from the newest committed PMC summary under profiles/ and scaled per point.
+        traffic, traffic_source = None, None
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_msm_accumulate.json"))
             if pmcs:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
                 traffic = pmc["hbm_bytes_per_point"] * (alg_bytes / 128.0)
+                traffic_source = "profiles/" + pmcs[-1] + " (separate rocprofv3 --pmc passes; bytes per point scaled to this launch size)"
         except Exception:
             traffic = None
+        # the other two kernels of the path against the same roof: NTT 64 B per element per transform
+        # (a transform is 2-3 ntt_pass launches), mat-vec 68 B per non-zero + 36 B per row
+        secondary = []
+        if "ntt_pass" in prof and work.get("ntt_elements"):
+            b = 64.0 * work["ntt_elements"]
+            a = b / (prof["ntt_pass"]["total_ms"] * 1e-3) / 1e9
+            secondary.append({"bound": "hbm", "kernel": "ntt_pass", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": a / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes": "64 B x %d elements over %d transforms (%d launches)"
+                                                   % (work["ntt_elements"] / args.steps, work["ntt_calls"] / args.steps,
+                                                      prof["ntt_pass"]["calls"] / args.steps),
+                              "ms_per_step": prof["ntt_pass"]["total_ms"] / args.steps})
+        sp = [k for k in prof if k.startswith("spmv_")]
+        if sp and work.get("spmv_nnz"):
+            b = 68.0 * work["spmv_nnz"] + 36.0 * work["spmv_rows"]
+            ms = sum(prof[k]["total_ms"] for k in sp)
+            a = b / (ms * 1e-3) / 1e9
+            secondary.append({"bound": "hbm", "kernel": "+".join(sorted(sp)), "achieved": a, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes": "68 B x %d non-zeros + 36 B x %d rows over %d mat-vecs"
+                                                   % (work["spmv_nnz"] / args.steps, work["spmv_rows"] / args.steps,
+                                                      work["spmv_calls"] / args.steps),
+                              "ms_per_step": ms / args.steps})
         out = {
             "metric": METRIC, "value": units * (1 if args.workload == "prove_sharded" else world) * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -239,15 +332,17 @@ def main():
                                                       "192-B partials all-gathered, transforms replicated",
                                      "msm": "point-range shards, all-gather of 144-B partials"}[args.workload]},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # explanatory figure: the kernel is bound by integer issue, not by HBM —
                          # mixed additions per second against the ceiling its instruction mix allows
                          # (3423 v_mad_u64_u32 + 677 64-bit shift/adds at 4.2 cycles, ~870 32-bit ops at 2.3, per
                          # wave-addition; 1024 SIMDs at 2.4 GHz)
-                         "mixed_adds_per_s": work["msm_digits"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
+                         # msm_adds = NON-ZERO digits (bucket entries), counted by the sort on the device
+                         "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
                          "issue_ceiling_mixed_adds_per_s": 8.2e9},
+            "roofline_secondary": secondary,
             "work_per_step": {k: v / args.steps for k, v in work.items()},
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }
@@ -255,7 +350,16 @@ def main():
             if args.workload == "msm":
                 out["cpu_baseline"] = cpu_baseline_msm(args.cpu_log_n or 18)
             else:
-                out["cpu_baseline"] = cpu_baseline_prove(args.cpu_log_n or 14)
+                per_proof = ctx.last_calls[: len(ctx.last_calls) // args.steps]  # the log of ONE proof
+                lg = max(n - 1, 1).bit_length()
+                shift_all = max(0, lg - args.cpu_log_n) if args.cpu_log_n else 0
+                if shift_all:  # --cpu-log-n: bound the all-thread replay too (slow hosts)
+                    per_proof = [[k, (v - shift_all if k == "n" else max(v >> shift_all, 1))] for k, v in per_proof]
+                z = np.ascontiguousarray(np.concatenate([cs.instance, cs.witness]))
+                base = cpu_baseline_prove(per_proof, n >> shift_all, cs.mats, z, max(0, lg - shift_all - 16))
+                if shift_all:
+                    base["sample"] += " [sizes divided by %d: --cpu-log-n]" % (1 << shift_all)
+                out["cpu_baseline"] = base
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:

@@ -155,6 +155,18 @@ int swm_generate_universal_srs(swm_ctx *ctx, size_t num_constraints, size_t num_
                                swm_rng *rng, swm_srs **out);
 void swm_srs_destroy(swm_ctx *ctx, swm_srs *srs);
 size_t swm_srs_max_degree(const swm_srs *srs);
+/* UniversalSRS <-> arkworks' in-memory kzg10::UniversalParams (what a binding that keeps the reference's
+ * `Box<UniversalSRS>` return type / `&UniversalSRS` parameter needs, src/marlin/mod.rs:50,89).
+ * export: powers_of_g[first .. first + count) as affine Montgomery x,y (count x 12 limbs); the three gamma-powers
+ *         KZG hiding with bound 1 uses (36 limbs; arkworks' map holds max_degree + 2 of them, MarlinKZG10::trim reads
+ *         indices 0..=2 only); h and beta_h in G2 as x.c0, x.c1, y.c0, y.c1 (4 x 6 Montgomery limbs, all-zero =
+ *         infinity).  Any of the three small outputs may be NULL.
+ * import: the same values in; the result behaves like a setup produced here.  Points are taken as given (an in-memory
+ *         struct is not validated by arkworks either). */
+int swm_srs_export(swm_ctx *ctx, const swm_srs *srs, size_t first, size_t count, uint64_t *powers_xy,
+                   uint64_t gamma_xy[36], uint64_t h[24], uint64_t beta_h[24]);
+int swm_srs_import(swm_ctx *ctx, const uint64_t *powers_xy, size_t n_powers, const uint64_t gamma_xy[36],
+                   const uint64_t h[24], const uint64_t beta_h[24], swm_srs **out);
 /* i-th power of g (affine Montgomery x,y) — test hook */
 int swm_srs_power_of_g(swm_ctx *ctx, const swm_srs *srs, size_t i, uint64_t out_xy[12]);
 
@@ -179,7 +191,15 @@ int swm_verify_proof(const swm_vk *vk, const uint64_t *public_inputs, size_t n, 
 int swm_vk_serialize(const swm_vk *vk, uint8_t *out, size_t cap, size_t *len);
 int swm_vk_deserialize(const uint8_t *bytes, size_t len, swm_vk **out);
 int swm_proof_validate(const uint8_t *bytes, size_t len);
-/* serialize_proving_key / deserialize_proving_key: round-trip of the key material through host bytes */
+/* serialize_proving_key / deserialize_proving_key (src/marlin/serialization.rs:33-45): the CanonicalSerialize bytes of
+ * ark_marlin::IndexProverKey — index_vk, index_comm_rands, index (info, matrices, the three matrix arithmetisations with
+ * their polynomials and evaluation tables), committer_key (trimmed powers, shifted powers, gamma powers, degree bounds,
+ * max_degree), points compressed — so that ProvingKey::deserialize(bytes) / proving_key.serialize() on the Rust side
+ * move a key across the boundary.  Field order as recalled from ark-marlin / ark-poly-commit 0.3.0 (not vendored in the
+ * reference: unpinned, like the proof layout).  ~2.5 GB at |K| = 2^20.  Deserialisation performs arkworks' checks
+ * (canonical field elements, points on the curve and in the prime-order subgroup — on the GPU for the committer key)
+ * and recomputes everything that is derived from the matrices instead of trusting it.
+ * swm_pk_serialize with out == NULL only reports the length. */
 int swm_pk_serialize(swm_ctx *ctx, const swm_pk *pk, uint8_t *out, size_t cap, size_t *len);
 int swm_pk_deserialize(swm_ctx *ctx, const uint8_t *bytes, size_t len, swm_pk **out);
 
@@ -207,10 +227,11 @@ int swm_set_msm_sharding(swm_ctx *ctx, unsigned rank, unsigned world, swm_allgat
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
  * kernel launch is bracketed by hipEventRecord on the stream it is launched on (on = 1), or only the launches of the
- * dominant kernel msm_accumulate (on = 2: what bench.py times its roofline from; bracketing all ~700 launches of a
- * 2^20 proof costs ~2 % of the proof).  swm_profile_json writes
+ * kernels bench.py prices against a roofline — msm_accumulate, ntt_pass, spmv_* — (on = 2; bracketing all ~700 launches
+ * of a 2^20 proof costs ~2 % of the proof).  swm_profile_json writes
  * {"kernels":[{"name":..,"calls":..,"total_ms":..,"avg_ms":..}, ...],
- *  "work":{"msm_calls":..,"msm_points":..,"ntt_calls":..,"ntt_elements":..,"spmv_calls":..,"spmv_rows":..}} into buf. */
+ *  "work":{"msm_calls","msm_points","msm_digits" (points x windows),"msm_adds" (non-zero digits = mixed additions),
+ *          "ntt_calls","ntt_elements","spmv_calls","spmv_rows","spmv_nnz"}} into buf. */
 int swm_profile_enable(swm_ctx *ctx, int on);
 int swm_profile_reset(swm_ctx *ctx);
 int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);

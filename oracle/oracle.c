@@ -520,6 +520,35 @@ static inline size_t bitrev(size_t x, unsigned bits) {
     return r;
 }
 
+/* out[i] = scale * base^i for i in [0, n): every thread starts its chunk from base^start (square-and-multiply) and
+ * continues with one multiplication per element, like ark-poly's compute_powers under the `parallel` feature. */
+static void fr_pow_u64(uint64_t *o, const uint64_t *b, uint64_t e) {
+    uint64_t acc[4], x[4];
+    memcpy(acc, FR_R1, 32);
+    memcpy(x, b, 32);
+    while (e) {
+        if (e & 1) fr_mul(acc, acc, x);
+        fr_sqr(x, x);
+        e >>= 1;
+    }
+    memcpy(o, acc, 32);
+}
+static void fr_scale_by_powers(uint64_t *a, size_t n, const uint64_t *scale, const uint64_t *base, int nt) {
+    size_t chunk = (n + (size_t)nt - 1) / (size_t)nt;
+    if (chunk < 1024) chunk = 1024;
+#pragma omp parallel for schedule(static) num_threads(nt) if (n >= 4096)
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        size_t hi = lo + chunk < n ? lo + chunk : n;
+        uint64_t p[4];
+        fr_pow_u64(p, base, lo);
+        fr_mul(p, p, scale);
+        for (size_t i = lo; i < hi; i++) {
+            fr_mul(a + 4 * i, a + 4 * i, p);
+            fr_mul(p, p, base);
+        }
+    }
+}
+
 void oracle_ntt_fr(uint64_t *a, unsigned log_n, int inverse, int coset, int threads) {
     size_t n = (size_t)1 << log_n;
     uint64_t w[4];
@@ -528,19 +557,12 @@ void oracle_ntt_fr(uint64_t *a, unsigned log_n, int inverse, int coset, int thre
     fr_mul(gen_m, gen, FR_R2);
     fr_inverse(gen_inv, gen_m);
     if (inverse) fr_inverse(w, w);
-    (void)threads;
     int nt = threads > 0 ? threads : 1;
     /* coset_fft: multiply coefficient i by g^i first */
-    if (coset && !inverse) {
-        uint64_t p[4];
-        memcpy(p, FR_R1, 32);
-        for (size_t i = 0; i < n; i++) {
-            fr_mul(a + 4 * i, a + 4 * i, p);
-            fr_mul(p, p, gen_m);
-        }
-    }
+    if (coset && !inverse) fr_scale_by_powers(a, n, FR_R1, gen_m, nt);
     /* derange (bit reversal) then Cooley-Tukey DIT, natural order out.  ark-poly's fft does
      * Gentleman-Sande then derange; the outputs are the same vector. */
+#pragma omp parallel for schedule(static) num_threads(nt) if (n >= 4096)
     for (size_t i = 0; i < n; i++) {
         size_t j = bitrev(i, log_n);
         if (i < j) {
@@ -550,25 +572,23 @@ void oracle_ntt_fr(uint64_t *a, unsigned log_n, int inverse, int coset, int thre
             memcpy(a + 4 * j, t, 32);
         }
     }
-    /* per-stage twiddle table */
-    uint64_t *tw = malloc(32 * (n / 2 ? n / 2 : 1));
+    /* one table of the n/2 powers of the root (ark-poly: roots_of_unity), indexed with the stage's stride */
+    size_t half_n = n / 2 ? n / 2 : 1;
+    uint64_t *tw = malloc(32 * half_n);
+    for (size_t k = 0; k < half_n; k++) memcpy(tw + 4 * k, FR_R1, 32);
+    fr_scale_by_powers(tw, half_n, FR_R1, w, nt);
     for (unsigned s = 1; s <= log_n; s++) {
-        size_t len = (size_t)1 << s, half = len >> 1;
-        uint64_t wl[4];
-        memcpy(wl, w, 32);
-        for (unsigned k = s; k < log_n; k++) fr_sqr(wl, wl);
-        memcpy(tw, FR_R1, 32);
-        for (size_t k = 1; k < half; k++) fr_mul(tw + 4 * k, tw + 4 * (k - 1), wl);
+        size_t len = (size_t)1 << s, half = len >> 1, stride = n / len;
+        size_t total = n / 2; /* butterflies of this stage, flattened so that early stages parallelise too */
 #pragma omp parallel for schedule(static) num_threads(nt) if (n >= 4096)
-        for (size_t blk = 0; blk < n / len; blk++) {
+        for (size_t t = 0; t < total; t++) {
+            size_t blk = t / half, k = t % half;
             uint64_t *base = a + 4 * blk * len;
-            for (size_t k = 0; k < half; k++) {
-                uint64_t u[4], v[4];
-                memcpy(u, base + 4 * k, 32);
-                fr_mul(v, base + 4 * (k + half), tw + 4 * k);
-                fr_add(base + 4 * k, u, v);
-                fr_sub(base + 4 * (k + half), u, v);
-            }
+            uint64_t u[4], v[4];
+            memcpy(u, base + 4 * k, 32);
+            fr_mul(v, base + 4 * (k + half), tw + 4 * (k * stride));
+            fr_add(base + 4 * k, u, v);
+            fr_sub(base + 4 * (k + half), u, v);
         }
     }
     free(tw);
@@ -577,18 +597,20 @@ void oracle_ntt_fr(uint64_t *a, unsigned log_n, int inverse, int coset, int thre
         uint64_t ninv[4] = {n, 0, 0, 0};
         fr_mul(ninv, ninv, FR_R2);
         fr_inverse(ninv, ninv);
-        uint64_t p[4];
-        memcpy(p, ninv, 32);
-        for (size_t i = 0; i < n; i++) {
-            fr_mul(a + 4 * i, a + 4 * i, p);
-            if (coset) fr_mul(p, p, gen_inv);
-        }
+        fr_scale_by_powers(a, n, ninv, coset ? gen_inv : FR_R1, nt);
     }
 }
 
 /* ------------------------------------------------------------------ K3: sparse M*z (ark-marlin prover_init inner_prod_fn) */
 void oracle_spmv_fr(const uint32_t *rowptr, const uint32_t *col, const uint64_t *val4, const uint64_t *z4,
                     uint64_t *out4, size_t rows) {
+    oracle_spmv_fr_mt(rowptr, col, val4, z4, out4, rows, 1);
+}
+/* rows in parallel, as ark-marlin's cfg_iter!(matrix) under the `parallel` feature */
+void oracle_spmv_fr_mt(const uint32_t *rowptr, const uint32_t *col, const uint64_t *val4, const uint64_t *z4,
+                       uint64_t *out4, size_t rows, int threads) {
+    int nt = threads > 0 ? threads : 1;
+#pragma omp parallel for schedule(static, 1024) num_threads(nt) if (rows >= 4096)
     for (size_t r = 0; r < rows; r++) {
         uint64_t acc[4] = {0, 0, 0, 0};
         for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; k++) {

@@ -67,6 +67,9 @@ void oracle_ntt_fr(uint64_t *data4, unsigned log_n, int inverse, int coset, int 
 /* ---- K3: row-sparse M*z as in ark-marlin prover_init; CSR, Montgomery values. */
 void oracle_spmv_fr(const uint32_t *rowptr, const uint32_t *col, const uint64_t *val4, const uint64_t *z4,
                     uint64_t *out4, size_t rows);
+/* the same with the rows spread over `threads` OpenMP threads (ark-marlin's cfg_iter! under `parallel`) */
+void oracle_spmv_fr_mt(const uint32_t *rowptr, const uint32_t *col, const uint64_t *val4, const uint64_t *z4,
+                       uint64_t *out4, size_t rows, int threads);
 
 /* number of OpenMP threads the library can use on this host */
 int oracle_max_threads(void);

@@ -835,6 +835,78 @@ def serialize_verifying_key(vk):
     return out
 
 
+def ser_usize_opt(v):
+    return b"\x00" if v is None else b"\x01" + ser_u64(v)
+
+
+def ser_domain(d):
+    """CanonicalSerialize of GeneralEvaluationDomain::Radix2 (ark-poly 0.3.0 [U]): a u8 variant tag, then the derived
+    serialisation of Radix2EvaluationDomain { size: u64, log_size_of_group: u32, size_as_field_element, size_inv,
+    group_gen, group_gen_inv, generator_inv }."""
+    out = b"\x00" + ser_u64(d.size) + d.log.to_bytes(4, "little")
+    out += ser_fr(d.size % R) + ser_fr(d.size_inv) + ser_fr(d.gen) + ser_fr(d.gen_inv) + ser_fr(pow(22, -1, R))
+    return out
+
+
+def ser_fr_vec(v):
+    return ser_u64(len(v)) + b"".join(ser_fr(x) for x in v)
+
+
+def ser_labeled_poly(label, coeffs, degree_bound=None, hiding_bound=None):
+    """LabeledPolynomial { label: String, polynomial: Rc<DensePolynomial>, degree_bound, hiding_bound } [U]."""
+    lb = label.encode()
+    return ser_u64(len(lb)) + lb + ser_fr_vec(poly_trim(coeffs)) + ser_usize_opt(degree_bound) + ser_usize_opt(hiding_bound)
+
+
+def ser_evals(vals, domain):
+    """Evaluations { evals: Vec<F>, domain: GeneralEvaluationDomain } [U]."""
+    return ser_fr_vec(vals) + ser_domain(domain)
+
+
+def ser_matrix(m):
+    """Matrix<F> = Vec<Vec<(F, usize)>>."""
+    out = ser_u64(len(m))
+    for row in m:
+        out += ser_u64(len(row))
+        for val, col in row:
+            out += ser_fr(val) + ser_u64(col)
+    return out
+
+
+def serialize_proving_key(pk):
+    """CanonicalSerialize of IndexProverKey (src/marlin/serialization.rs:33-39) — field order of ark-marlin 0.3.0's
+    derives as recalled [U]:
+        IndexProverKey { index_vk, index_comm_rands: Vec<marlin_pc::Randomness>, index: Index, committer_key }
+        Index { index_info, a, b, c, a_star_arith, b_star_arith, c_star_arith }
+        MatrixArithmetization { row, col, val, row_col: LabeledPolynomial, evals_on_K: MatrixEvals { row, col, val },
+                                evals_on_B: MatrixEvals, row_col_evals_on_B: Evaluations }
+        marlin_pc::CommitterKey { powers, shifted_powers: Option<Vec>, powers_of_gamma_g, enforced_degree_bounds: Option<Vec<usize>>, max_degree }
+    """
+    vk, idx, ck = pk["vk"], pk["index"], pk["ck"]
+    out = serialize_verifying_key(vk)
+    out += ser_u64(len(pk["index_comm_rands"]))
+    for _ in pk["index_comm_rands"]:  # index polynomials are committed without hiding: empty blinding polynomial, no shifted rand
+        out += ser_fr_vec([]) + b"\x00"
+    out += ser_u64(idx.num_variables) + ser_u64(idx.num_constraints) + ser_u64(idx.num_non_zero) + ser_u64(idx.num_instance_variables)
+    out += ser_matrix(idx.a) + ser_matrix(idx.b) + ser_matrix(idx.c)
+    dk = Domain(idx.num_non_zero)
+    db = Domain(3 * dk.size - 3)
+    for m in "abc":
+        ar = idx.arith[m]
+        for n in ("row", "col", "val", "row_col"):
+            out += ser_labeled_poly(m + "_" + n, ar[n])
+        for dom, suf in ((dk, "_K"), (db, "_B")):
+            for n in ("row", "col", "val"):
+                out += ser_evals(ar[n + suf], dom)
+        out += ser_evals(ar["row_col_B"], db)
+    out += ser_u64(len(ck.powers)) + b"".join(ser_g1(p) for p in ck.powers)
+    out += b"\x01" + ser_u64(len(ck.shifted_powers)) + b"".join(ser_g1(p) for p in ck.shifted_powers)
+    out += ser_u64(len(ck.powers_of_gamma_g)) + b"".join(ser_g1(p) for p in ck.powers_of_gamma_g)
+    out += b"\x01" + ser_u64(len(ck.enforced_degree_bounds)) + b"".join(ser_u64(d) for d in ck.enforced_degree_bounds)
+    out += ser_u64(ck.max_degree)
+    return out
+
+
 # ----------------------------------------------------------------------------- verifier
 def verify(vk, public_input, proof, rng):
     """Marlin::verify (src/marlin/mod.rs:79-86) + MarlinKZG10::check_combinations + KZG10::batch_check."""

@@ -54,6 +54,8 @@ ABI = {
     "swm_srs_destroy": (None, [_vp, _vp]),
     "swm_srs_max_degree": (_sz, [_vp]),
     "swm_srs_power_of_g": (_int, [_vp, _vp, _sz, _u64p]),
+    "swm_srs_export": (_int, [_vp, _vp, _sz, _sz, _u64p, _u64p, _u64p, _u64p]),
+    "swm_srs_import": (_int, [_vp, _u64p, _sz, _u64p, _u64p, _u64p, ctypes.POINTER(_vp)]),
     "swm_generate_proving_and_verifying_keys": (_int, [_vp, _vp, ctypes.c_void_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "swm_pk_destroy": (None, [_vp, _vp]),
     "swm_vk_destroy": (None, [_vp]),
@@ -309,10 +311,11 @@ class Context:
         self._check(self.lib.swm_profile_reset(self.h), "swm_profile_reset")
 
     def profile(self):
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 20)
         self._check(self.lib.swm_profile_json(self.h, buf, len(buf)), "swm_profile_json")
         doc = json.loads(buf.value.decode())
         self.last_work = doc.get("work", {})
+        self.last_calls = doc.get("calls", [])
         return {k["name"]: k for k in doc["kernels"]}
 
     # ---- self tests

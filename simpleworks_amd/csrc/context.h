@@ -56,7 +56,16 @@ struct swm_ctx {
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
-    uint64_t stat_msm_digits = 0;  // points x windows: the mixed additions the accumulation performs (zero digits included)
+    uint64_t stat_msm_digits = 0;  // points x windows (zero digits included)
+    uint64_t stat_msm_adds = 0;    // NON-ZERO digits = bucket entries = the mixed additions msm_accumulate performs (counted by
+                                   // the sort on the device; collected in msm_finish)
+    uint64_t stat_spmv_nnz = 0;
+    // the K1-K3 calls themselves while profiling is on ("the log is mandatory"): ('m', points),
+    // ('n', log2 size), ('s', rows) + ('z', non-zeros); bench.py replays this list on the CPU oracle
+    std::vector<std::pair<char, uint64_t>> call_log;
+    void log_call(char kind, uint64_t v) {
+        if (profiling && call_log.size() < 8192) call_log.push_back({kind, v});
+    }
     uint64_t stat_msm_calls = 0, stat_msm_points = 0, stat_ntt_calls = 0, stat_ntt_elems = 0, stat_spmv_calls = 0,
              stat_spmv_rows = 0;
     int profiling = 0;  // 0 off, 1 every launch, 2 the dominant kernel (msm_accumulate) only

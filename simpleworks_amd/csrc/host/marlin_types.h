@@ -281,8 +281,7 @@ inline std::vector<uint8_t> serialize_verifying_key(const VerifyingKey& vk) {
     return w.b;
 }
 
-inline VerifyingKey deserialize_verifying_key(const uint8_t* data, size_t len) {
-    ByteReader r(data, len);
+inline VerifyingKey read_verifying_key(ByteReader& r) {
     VerifyingKey vk;
     vk.info.num_variables = r.u64();
     vk.info.num_constraints = r.u64();
@@ -306,6 +305,11 @@ inline VerifyingKey deserialize_verifying_key(const uint8_t* data, size_t len) {
     }
     vk.vk.max_degree = r.u64();
     vk.vk.supported_degree = r.u64();
+    return vk;
+}
+inline VerifyingKey deserialize_verifying_key(const uint8_t* data, size_t len) {
+    ByteReader r(data, len);
+    VerifyingKey vk = read_verifying_key(r);
     if (r.pos != len) throw MarlinError(SWM_ERR_SERIALIZATION, "trailing bytes");
     return vk;
 }

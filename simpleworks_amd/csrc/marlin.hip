@@ -77,6 +77,8 @@ struct swm_pk {
     ~swm_pk() {  // also runs when index_impl / pk_deserialize unwind with a half-built key
         if (d_powers) (void)hipFree(d_powers);
         if (d_powers28) (void)hipFree(d_powers28);
+        if (d_shifted) (void)hipFree(d_shifted);
+        if (d_shifted28) (void)hipFree(d_shifted28);
     }
     IndexInfo info;
     uint64_t H = 0, K = 0, X = 0, B = 0;
@@ -84,9 +86,27 @@ struct swm_pk {
     HostCsr ha, hb, hc;  // padded, balanced matrices (kept for key serialisation)
     DevCsr a, b, c, at, bt, ct;
     MatrixArith ar[3];
-    G1Affine* d_powers = nullptr;    // full SRS powers [0, srs_max_degree]
-    G1Affine* d_powers28 = nullptr;  // the same powers scaled for the MSM inner loop (msm_scale_bases_run)
+    // committer key as MarlinKZG10::trim lays it out: powers [0, supported_degree] and, for the degree-bound shifts,
+    // the top of the SRS [shift_base, srs_max_degree] with shift_base = srs_max_degree - largest enforced bound.
+    // d_*28: the same points scaled for the MSM inner loop (msm_scale_bases_run).
+    G1Affine* d_powers = nullptr;
+    G1Affine* d_powers28 = nullptr;
+    G1Affine* d_shifted = nullptr;
+    G1Affine* d_shifted28 = nullptr;
+    size_t n_powers = 0, n_shifted = 0, shift_base = 0;
     size_t srs_max_degree = 0;
+    // bases for an MSM of n points starting at SRS power `offset`
+    void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28) const {
+        if (offset + n <= n_powers) {
+            *b = d_powers + offset;
+            *b28 = d_powers28 + offset;
+        } else if (offset >= shift_base && offset + n <= shift_base + n_shifted) {
+            *b = d_shifted + (offset - shift_base);
+            *b28 = d_shifted28 + (offset - shift_base);
+        } else {
+            throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+        }
+    }
     std::vector<G1Affine> gamma_powers;
     GammaTable gtab;
     VerifyingKey vk;
@@ -341,9 +361,10 @@ uint64_t ahp_max_degree(uint64_t num_constraints, uint64_t num_variables, uint64
 // MSM of a device coefficient vector against SRS powers starting at `offset` -> host XYZZ (synchronous form)
 G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n) {
     if (n == 0) return g1_xyzz_identity();
-    if (offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+    const G1Affine *b, *b28;
+    pk.bases_at(offset, n, &b, &b28);
     G1XYZZ r;
-    rc_check(ctx, msm_run(ctx, pk.d_powers + offset, pk.d_powers28 + offset, coeffs, n, 1, &r));
+    rc_check(ctx, msm_run(ctx, b, b28, coeffs, n, 1, &r));
     return r;
 }
 // asynchronous form: alternates between the two MSM lanes of the context
@@ -354,7 +375,8 @@ struct AsyncMsm {
     bool sharded = false;
 };
 void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
-    if (n && offset + n > pk.srs_max_degree + 1) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
+    const G1Affine *b = nullptr, *b28 = nullptr;
+    if (n) pk.bases_at(offset, n, &b, &b28);
     static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
     size_t lo = 0, hi = n;
     out->sharded = ctx->shard_world > 1;
@@ -362,8 +384,7 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
         lo = (size_t)(((unsigned __int128)n * ctx->shard_rank) / ctx->shard_world);
         hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
     }
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, pk.d_powers + offset + lo, pk.d_powers28 + offset + lo, coeffs + lo,
-                              hi - lo, 1, &out->job));
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job));
 }
 G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
     G1XYZZ r;
@@ -644,6 +665,24 @@ void arithmetize(swm_ctx* ctx, swm_pk& pk, const HostCsr& m, MatrixArith& ar) {
     ar.row_col_B = on_b(ar.row_col);
 }
 
+// Copies the two power ranges of a trimmed committer key into the key (device or host source) and derives the scaled twins.
+void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, size_t n_powers, const G1Affine* shifted,
+                           size_t n_shifted, bool device_src) {
+    const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    pk.n_powers = n_powers;
+    pk.n_shifted = n_shifted;
+    pk.shift_base = pk.srs_max_degree + 1 - n_shifted;
+    hip_check(ctx, hipMalloc((void**)&pk.d_powers, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers)");
+    hip_check(ctx, hipMalloc((void**)&pk.d_powers28, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers28)");
+    hip_check(ctx, hipMalloc((void**)&pk.d_shifted, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted)");
+    hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted28)");
+    hip_check(ctx, hipMemcpyAsync(pk.d_powers, powers, n_powers * sizeof(G1Affine), kind, ctx->stream), "copy powers");
+    if (n_shifted) hip_check(ctx, hipMemcpyAsync(pk.d_shifted, shifted, n_shifted * sizeof(G1Affine), kind, ctx->stream), "copy shifted");
+    rc_check(ctx, msm_scale_bases_run(ctx, pk.d_powers, n_powers, pk.d_powers28));
+    rc_check(ctx, msm_scale_bases_run(ctx, pk.d_shifted, n_shifted, pk.d_shifted28));
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+}
+
 void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** out_pk, swm_vk** out_vk) {
     PaddedR1cs p = pad_and_square(cs);
     std::unique_ptr<swm_pk> pk(new swm_pk());
@@ -663,13 +702,10 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     if (pk->X >= pk->H) throw MarlinError(SWM_ERR_INVALID_ARG, "index: the circuit needs at least one witness variable");
     uint64_t max_deg = ahp_max_degree(p.ncons, pk->info.num_variables, nnz);
     if (srs->max_degree < max_deg) throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "IndexTooLarge");
-    // committer key: the SRS powers stay resident with the key (MarlinKZG10::trim copies them, too)
+    // committer key = MarlinKZG10::trim(srs, supported_degree = max_deg, hiding bound 1, bounds {|H| - 2, |K| - 2})
     pk->srs_max_degree = srs->max_degree;
-    hip_check(ctx, hipMalloc((void**)&pk->d_powers, (srs->max_degree + 1) * sizeof(G1Affine)), "hipMalloc(pk powers)");
-    hip_check(ctx, hipMemcpyAsync(pk->d_powers, srs->d_powers, (srs->max_degree + 1) * sizeof(G1Affine),
-                                  hipMemcpyDeviceToDevice, ctx->stream), "d2d");
-    hip_check(ctx, hipMalloc((void**)&pk->d_powers28, (srs->max_degree + 1) * sizeof(G1Affine)), "hipMalloc(pk powers28)");
-    rc_check(ctx, msm_scale_bases_run(ctx, pk->d_powers, srs->max_degree + 1, pk->d_powers28));
+    install_committer_key(ctx, *pk, srs->d_powers, max_deg + 1, srs->d_powers + (srs->max_degree - (std::max(pk->H, pk->K) - 2)),
+                          std::max(pk->H, pk->K) - 2 + 1, /*device_src=*/true);
     pk->gamma_powers = srs->gamma_powers;
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->ha = p.a; pk->hb = p.b; pk->hc = p.c;
@@ -685,14 +721,14 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     // verifier key
     VerifyingKey& vk = pk->vk;
     vk.info = pk->info;
-    vk.vk.g = srs_power(ctx, pk->d_powers, 0);
+    vk.vk.g = srs_power(ctx, srs->d_powers, 0);
     vk.vk.gamma_g = pk->gamma_powers[0];
     vk.vk.h = srs->h;
     vk.vk.beta_h = srs->beta_h;
     std::vector<uint64_t> bounds = {pk->H - 2, pk->K - 2};
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
-    for (auto d : bounds) vk.vk.degree_bounds_and_shift_powers.push_back({d, srs_power(ctx, pk->d_powers, srs->max_degree - d)});
+    for (auto d : bounds) vk.vk.degree_bounds_and_shift_powers.push_back({d, srs_power(ctx, srs->d_powers, srs->max_degree - d)});
     vk.vk.max_degree = srs->max_degree;
     vk.vk.supported_degree = max_deg;
     // commit the 12 index polynomials (no hiding, no degree bounds)
@@ -1242,90 +1278,332 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
 
 
 // ================================================================================================ key (de)serialisation
-// serialize_proving_key / deserialize_proving_key (src/marlin/serialization.rs:33-45).  The key is this library's
-// own object (device-resident matrices, index polynomials and SRS powers), so the byte format is ours:
-// the padded matrices, the SRS powers (uncompressed Montgomery limbs) and the verifying key; everything derived
-// (transposes, arithmetisation, evaluation tables) is recomputed on the GPU when the key is loaded.
-void put_csr(ByteWriter& w, const HostCsr& m) {
-    w.u64(m.rows());
-    w.u64(m.nnz());
-    w.raw(m.rowptr.data(), m.rowptr.size() * 4);
-    w.raw(m.col.data(), m.col.size() * 4);
-    w.raw(m.val.data(), m.val.size() * sizeof(Fr));
+// serialize_proving_key / deserialize_proving_key (src/marlin/serialization.rs:33-45): the CanonicalSerialize bytes of
+// ark_marlin::IndexProverKey<Fr, MarlinKZG10<..>>, field order of ark-marlin / ark-poly-commit / ark-poly 0.3.0's derives
+// as recalled [U] (the same layout oracle/pyref/marlin.py::serialize_proving_key emits; parity test on small keys):
+//   IndexProverKey { index_vk, index_comm_rands: Vec<marlin_pc::Randomness>, index: Index, committer_key }
+//   Index { index_info, a, b, c: Matrix = Vec<Vec<(F, usize)>>, a_star_arith, b_star_arith, c_star_arith }
+//   MatrixArithmetization { row, col, val, row_col: LabeledPolynomial { label, coeffs, degree_bound, hiding_bound },
+//                           evals_on_K { row, col, val }, evals_on_B { row, col, val }, row_col_evals_on_B : Evaluations { evals, domain } }
+//   marlin_pc::CommitterKey { powers, shifted_powers: Option<Vec>, powers_of_gamma_g, enforced_degree_bounds: Option<Vec<usize>>, max_degree }
+// Bulk data is converted on the GPU (Montgomery -> canonical bytes, affine -> compressed points and back, including the
+// curve and subgroup checks CanonicalDeserialize performs).  When a key is loaded, only what defines it is used — the
+// matrices, the committer key, the verifying key; everything derived from the matrices (arithmetisation polynomials and
+// their evaluation tables) is parsed for shape and then recomputed on the device rather than trusted.
+struct FqSqrtConsts {
+    static constexpr uint32_t HALF[12] = SWM_FQ_PM1_HALF;
+    static constexpr uint32_t T[12] = SWM_FQ_TS_T;
+    static constexpr uint32_t TP1H[12] = SWM_FQ_TS_T_PLUS1_HALF;
+    static constexpr uint32_t C[12] = SWM_FQ_TS_C_MONT;
+};
+// Tonelli-Shanks as in host/hostmath.h, device side
+__device__ bool fq_sqrt_dev(const Fq& a, Fq* out) {
+    if (fp_is_zero(a)) {
+        *out = a;
+        return true;
+    }
+    if (!fp_is_one(fp_pow(a, FqSqrtConsts::HALF, 12))) return false;
+    Fq c;
+    for (int k = 0; k < 12; k++) c.v[k] = FqSqrtConsts::C[k];
+    Fq x = fp_pow(a, FqSqrtConsts::TP1H, 12);
+    Fq b = fp_pow(a, FqSqrtConsts::T, 12);
+    int m = SWM_FQ_TWO_ADICITY;
+    while (!fp_is_one(b)) {
+        int i = 0;
+        Fq bb = b;
+        while (!fp_is_one(bb)) {
+            bb = fp_sqr(bb);
+            i++;
+        }
+        Fq g = c;
+        for (int k = 0; k < m - i - 1; k++) g = fp_sqr(g);
+        x = fp_mul(x, g);
+        c = fp_sqr(g);
+        b = fp_mul(b, c);
+        m = i;
+    }
+    *out = x;
+    return true;
 }
-HostCsr get_csr(ByteReader& r) {
+// affine -> ark-serialize compressed form (48 bytes: x little-endian, bit 7 of the last byte = y is the larger root,
+// bit 6 = infinity)
+__global__ void __launch_bounds__(256) g1_compress_kernel(const G1Affine* __restrict__ in, size_t n, uint32_t* __restrict__ out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = in[i];
+    uint32_t w[12];
+    if (g1_is_inf(p)) {
+        for (int k = 0; k < 12; k++) w[k] = 0;
+        w[11] = 0x40000000u;
+    } else {
+        Fq xs = fp_to_std(p.x), ys = fp_to_std(p.y), ny = fp_to_std(fp_neg(p.y));
+        for (int k = 0; k < 12; k++) w[k] = xs.v[k];
+        if (fp_cmp_std(ys, ny) > 0) w[11] |= 0x80000000u;
+    }
+    for (int k = 0; k < 12; k++) out[12 * i + k] = w[k];
+}
+// compressed -> affine with the checks of CanonicalDeserialize: flags, x < q, on the curve, [r]P = O.  *bad != 0 on failure.
+__global__ void __launch_bounds__(256) g1_decompress_kernel(const uint32_t* __restrict__ in, size_t n, G1Affine* __restrict__ out,
+                                                            uint32_t* __restrict__ bad) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq xs;
+    for (int k = 0; k < 12; k++) xs.v[k] = in[12 * i + k];
+    const uint32_t flags = xs.v[11] >> 30;
+    xs.v[11] &= 0x3fffffffu;
+    bool lt = false;
+    for (int k = 11; k >= 0; k--) {
+        if (xs.v[k] < FqParams::P[k]) { lt = true; break; }
+        if (xs.v[k] > FqParams::P[k]) break;
+    }
+    G1Affine r = g1_affine_identity();
+    if (flags == 3 || !lt) {
+        atomicOr(bad, 1u);
+    } else if (!(flags & 1)) {
+        r.x = fp_from_std(xs);
+        Fq y;
+        if (!fq_sqrt_dev(fp_add(fp_mul(fp_sqr(r.x), r.x), fp_one<Fq>()), &y)) {
+            atomicOr(bad, 2u);
+        } else {
+            Fq ny = fp_neg(y);
+            bool y_is_larger = fp_cmp_std(fp_to_std(y), fp_to_std(ny)) > 0;
+            r.y = (y_is_larger == ((flags & 2) != 0)) ? y : ny;
+            // subgroup: [r]P == O, double-and-add over the 253 bits of r
+            G1XYZZ acc = g1_xyzz_identity();
+            bool started = false;
+            for (int b = 252; b >= 0; b--) {
+                if (started) acc = g1_dbl(acc);
+                if ((FrParams::P[b >> 5] >> (b & 31)) & 1) {
+                    g1_add_mixed(acc, r);
+                    started = true;
+                }
+            }
+            if (!g1_is_inf(acc)) atomicOr(bad, 4u);
+        }
+    }
+    out[i] = r;
+}
+
+void put_fr_vec_dev(swm_ctx* ctx, ByteWriter& w, const Fr* d, size_t n) {  // Vec<Fr>: u64 length + canonical bytes
+    w.u64(n);
+    if (!n) return;
+    DVec tmp(ctx, n);
+    Fr* t = tmp.p;
+    ew(ctx, "ser_to_std", n, [=] __device__(size_t i) { t[i] = fp_to_std(d[i]); });
+    size_t at = w.b.size();
+    w.b.resize(at + n * sizeof(Fr));
+    hip_check(ctx, hipMemcpyAsync(w.b.data() + at, t, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+}
+void put_domain(ByteWriter& w, const HDomain& d) {  // GeneralEvaluationDomain::Radix2: u8 tag + Radix2EvaluationDomain
+    w.u8(0);
+    w.u64(d.size);
+    uint32_t lg = d.log;
+    w.raw(&lg, 4);
+    w.fr(d.size_fr);
+    w.fr(d.size_inv);
+    w.fr(d.gen);
+    w.fr(d.gen_inv);
+    w.fr(fp_inv(fp_from_u64<Fr>(22)));  // generator_inv = multiplicative_generator^-1
+}
+void put_g1_vec_dev(swm_ctx* ctx, ByteWriter& w, const G1Affine* d, size_t n) {  // Vec<G1Affine>, compressed
+    w.u64(n);
+    if (!n) return;
+    DBuf<uint32_t> tmp(ctx, n * 12);
+    LAUNCHX(ctx, "g1_compress", g1_compress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, n, tmp.p);
+    size_t at = w.b.size();
+    w.b.resize(at + n * 48);
+    hip_check(ctx, hipMemcpyAsync(w.b.data() + at, tmp.p, n * 48, hipMemcpyDeviceToHost, ctx->stream), "d2h");
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+}
+void put_matrix(ByteWriter& w, const HostCsr& m) {
+    w.u64(m.rows());
+    for (size_t r = 0; r < m.rows(); r++) {
+        w.u64(m.rowptr[r + 1] - m.rowptr[r]);
+        for (uint32_t k = m.rowptr[r]; k < m.rowptr[r + 1]; k++) {
+            w.fr(m.val[k]);
+            w.u64(m.col[k]);
+        }
+    }
+}
+HostCsr get_matrix(ByteReader& r, uint64_t ncols) {
     HostCsr m;
-    uint64_t rows = r.u64(), nnz = r.u64();
-    if (rows > (1ull << 31) || nnz > (1ull << 32)) throw MarlinError(SWM_ERR_SERIALIZATION, "bad matrix header");
-    m.rowptr.resize(rows + 1);
-    memcpy(m.rowptr.data(), r.take((rows + 1) * 4), (rows + 1) * 4);
-    m.col.resize(nnz);
-    if (nnz) memcpy(m.col.data(), r.take(nnz * 4), nnz * 4);
-    m.val.resize(nnz);
-    if (nnz) memcpy(m.val.data(), r.take(nnz * sizeof(Fr)), nnz * sizeof(Fr));
-    if (m.rowptr[rows] != nnz) throw MarlinError(SWM_ERR_SERIALIZATION, "inconsistent matrix");
+    uint64_t rows = r.u64();
+    if (rows > (1ull << 31)) throw MarlinError(SWM_ERR_SERIALIZATION, "bad matrix header");
+    m.rowptr.assign(1, 0);
+    for (uint64_t i = 0; i < rows; i++) {
+        uint64_t len = r.u64();
+        if (len > r.n - r.pos) throw MarlinError(SWM_ERR_SERIALIZATION, "bad matrix row");
+        for (uint64_t k = 0; k < len; k++) {
+            m.val.push_back(r.fr());
+            uint64_t c = r.u64();
+            if (c >= ncols) throw MarlinError(SWM_ERR_SERIALIZATION, "matrix column out of range");
+            m.col.push_back((uint32_t)c);
+        }
+        m.rowptr.push_back((uint32_t)m.col.size());
+    }
     return m;
+}
+// trailing zero coefficients are not part of a DensePolynomial
+size_t trimmed_len(swm_ctx* ctx, const Fr* d, size_t n) {
+    std::vector<Fr> h(n);
+    hip_check(ctx, hipMemcpyAsync(h.data(), d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    while (n && fp_is_zero(h[n - 1])) n--;
+    return n;
 }
 
 std::vector<uint8_t> pk_serialize(swm_ctx* ctx, const swm_pk& pk) {
     ByteWriter w;
-    w.raw("SWMPK001", 8);
+    std::vector<uint8_t> vkb = serialize_verifying_key(pk.vk);
+    w.raw(vkb.data(), vkb.size());
+    w.u64(pk.vk.index_comms.size());  // index_comm_rands: no hiding -> empty blinding polynomial, no shifted rand
+    for (size_t i = 0; i < pk.vk.index_comms.size(); i++) {
+        w.u64(0);
+        w.u8(0);
+    }
     w.u64(pk.info.num_variables);
     w.u64(pk.info.num_constraints);
     w.u64(pk.info.num_non_zero);
     w.u64(pk.info.num_instance_variables);
-    put_csr(w, pk.ha);
-    put_csr(w, pk.hb);
-    put_csr(w, pk.hc);
-    w.u64(pk.srs_max_degree);
-    size_t np = pk.srs_max_degree + 1;
-    std::vector<G1Affine> powers(np);
-    hip_check(ctx, hipMemcpyAsync(powers.data(), pk.d_powers, np * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream), "d2h");
-    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
-    w.raw(powers.data(), np * sizeof(G1Affine));
+    put_matrix(w, pk.ha);
+    put_matrix(w, pk.hb);
+    put_matrix(w, pk.hc);
+    HDomain dk(pk.K), db(pk.B);
+    for (int m = 0; m < 3; m++) {
+        const MatrixArith& ar = pk.ar[m];
+        const DVec* polys[4] = {&ar.row, &ar.col, &ar.val, &ar.row_col};
+        for (int j = 0; j < 4; j++) {
+            const char* label = kIndexerPolys[4 * m + j];
+            w.u64(strlen(label));
+            w.raw(label, strlen(label));
+            put_fr_vec_dev(ctx, w, polys[j]->p, trimmed_len(ctx, polys[j]->p, pk.K));
+            w.u8(0);  // degree_bound: None
+            w.u8(0);  // hiding_bound: None
+        }
+        for (const DVec* e : {&ar.row_K, &ar.col_K, &ar.val_K}) {
+            put_fr_vec_dev(ctx, w, e->p, pk.K);
+            put_domain(w, dk);
+        }
+        for (const DVec* e : {&ar.row_B, &ar.col_B, &ar.val_B, &ar.row_col_B}) {
+            put_fr_vec_dev(ctx, w, e->p, pk.B);
+            put_domain(w, db);
+        }
+    }
+    put_g1_vec_dev(ctx, w, pk.d_powers, pk.n_powers);
+    w.u8(1);
+    put_g1_vec_dev(ctx, w, pk.d_shifted, pk.n_shifted);
     w.u64(pk.gamma_powers.size());
-    w.raw(pk.gamma_powers.data(), pk.gamma_powers.size() * sizeof(G1Affine));
-    std::vector<uint8_t> vkb = serialize_verifying_key(pk.vk);
-    w.u64(vkb.size());
-    w.raw(vkb.data(), vkb.size());
+    for (auto& g : pk.gamma_powers) w.ser_g1(g);
+    w.u8(1);
+    w.u64(pk.vk.vk.degree_bounds_and_shift_powers.size());
+    for (auto& ds : pk.vk.vk.degree_bounds_and_shift_powers) w.u64(ds.first);
+    w.u64(pk.srs_max_degree);
     return w.b;
+}
+
+void skip_fr_vec(ByteReader& r, uint64_t expect_max) {
+    uint64_t n = r.u64();
+    if (n > expect_max) throw MarlinError(SWM_ERR_SERIALIZATION, "vector longer than its domain");
+    r.take(n * 32);
+}
+void skip_domain(ByteReader& r, uint64_t size) {
+    if (*r.take(1) != 0) throw MarlinError(SWM_ERR_SERIALIZATION, "not a radix-2 domain");
+    if (r.u64() != size) throw MarlinError(SWM_ERR_SERIALIZATION, "domain size does not match the index");
+    r.take(4 + 5 * 32);
+}
+// Vec<G1Affine> (compressed) -> host affine points, decompressed and checked on the device
+std::vector<G1Affine> get_g1_vec_dev(swm_ctx* ctx, ByteReader& r, uint64_t max_n) {
+    uint64_t n = r.u64();
+    if (n > max_n) throw MarlinError(SWM_ERR_SERIALIZATION, "bad point count");
+    std::vector<G1Affine> out(n);
+    if (!n) return out;
+    const uint8_t* src = r.take(n * 48);
+    DBuf<uint32_t> in(ctx, n * 12), bad(ctx, 1);
+    DBuf<G1Affine> pts(ctx, n);
+    bad.zero();
+    hip_check(ctx, hipMemcpyAsync(in.p, src, n * 48, hipMemcpyHostToDevice, ctx->stream), "h2d");
+    LAUNCHX(ctx, "g1_decompress", g1_decompress_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, in.p, n, pts.p, bad.p);
+    uint32_t b = bad.download(0, 1)[0];
+    if (b) throw MarlinError(SWM_ERR_SERIALIZATION, b & 4 ? "committer key: point not in the prime-order subgroup"
+                                                        : (b & 2 ? "committer key: x not on the curve" : "committer key: invalid point encoding"));
+    hip_check(ctx, hipMemcpyAsync(out.data(), pts.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+    return out;
 }
 
 swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
     ByteReader r(bytes, len);
-    if (memcmp(r.take(8), "SWMPK001", 8) != 0) throw MarlinError(SWM_ERR_SERIALIZATION, "not a proving key");
     std::unique_ptr<swm_pk> pk(new swm_pk());
+    pk->vk = read_verifying_key(r);
+    uint64_t nr = r.u64();
+    if (nr != pk->vk.index_comms.size()) throw MarlinError(SWM_ERR_SERIALIZATION, "index_comm_rands does not match index_comms");
+    for (uint64_t i = 0; i < nr; i++) {
+        skip_fr_vec(r, 4);
+        if (r.boolean()) skip_fr_vec(r, 4);
+    }
     pk->info.num_variables = r.u64();
     pk->info.num_constraints = r.u64();
     pk->info.num_non_zero = r.u64();
     pk->info.num_instance_variables = r.u64();
-    pk->ha = get_csr(r);
-    pk->hb = get_csr(r);
-    pk->hc = get_csr(r);
-    pk->srs_max_degree = r.u64();
-    size_t np = pk->srs_max_degree + 1;
-    const uint8_t* pw = r.take(np * sizeof(G1Affine));
-    uint64_t ng = r.u64();
-    if (ng > 16) throw MarlinError(SWM_ERR_SERIALIZATION, "bad gamma count");
-    pk->gamma_powers.resize(ng);
-    memcpy(pk->gamma_powers.data(), r.take(ng * sizeof(G1Affine)), ng * sizeof(G1Affine));
-    uint64_t vl = r.u64();
-    pk->vk = deserialize_verifying_key(r.take(vl), vl);
-    if (r.pos != len) throw MarlinError(SWM_ERR_SERIALIZATION, "trailing bytes");
+    if (pk->info.num_variables != pk->vk.info.num_variables || pk->info.num_constraints != pk->vk.info.num_constraints ||
+        pk->info.num_non_zero != pk->vk.info.num_non_zero || pk->info.num_instance_variables != pk->vk.info.num_instance_variables ||
+        pk->info.num_constraints != pk->info.num_variables || pk->info.num_variables > (1ull << 30) ||
+        pk->info.num_non_zero > (1ull << 31) || pk->info.num_non_zero == 0)
+        throw MarlinError(SWM_ERR_SERIALIZATION, "index info is inconsistent");
+    pk->ha = get_matrix(r, pk->info.num_variables);
+    pk->hb = get_matrix(r, pk->info.num_variables);
+    pk->hc = get_matrix(r, pk->info.num_variables);
     if (pk->ha.rows() != pk->info.num_constraints || pk->hb.rows() != pk->info.num_constraints ||
         pk->hc.rows() != pk->info.num_constraints)
         throw MarlinError(SWM_ERR_SERIALIZATION, "matrix shape does not match index info");
+    if (std::max(pk->ha.nnz(), std::max(pk->hb.nnz(), pk->hc.nnz())) > pk->info.num_non_zero)
+        throw MarlinError(SWM_ERR_SERIALIZATION, "matrix density exceeds index info");
     HDomain dh(pk->info.num_constraints), dk(pk->info.num_non_zero), dx(pk->info.num_instance_variables);
     HDomain db(3 * dk.size - 3);
     pk->H = dh.size; pk->logH = dh.log;
     pk->K = dk.size; pk->logK = dk.log;
     pk->X = dx.size; pk->logX = dx.log;
     pk->B = db.size; pk->logB = db.log;
-    hip_check(ctx, hipMalloc((void**)&pk->d_powers, np * sizeof(G1Affine)), "hipMalloc(pk powers)");
-    hip_check(ctx, hipMemcpyAsync(pk->d_powers, pw, np * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream), "h2d");
-    hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
-    hip_check(ctx, hipMalloc((void**)&pk->d_powers28, np * sizeof(G1Affine)), "hipMalloc(pk powers28)");
-    rc_check(ctx, msm_scale_bases_run(ctx, pk->d_powers, np, pk->d_powers28));
+    if (pk->X >= pk->H) throw MarlinError(SWM_ERR_SERIALIZATION, "index without witness variables");
+    for (int m = 0; m < 3; m++) {  // derived data: shape-checked, then recomputed below
+        for (int j = 0; j < 4; j++) {
+            uint64_t ll = r.u64();
+            if (ll > 64) throw MarlinError(SWM_ERR_SERIALIZATION, "bad polynomial label");
+            r.take(ll);
+            skip_fr_vec(r, pk->K);
+            if (r.boolean()) r.u64();
+            if (r.boolean()) r.u64();
+        }
+        for (int j = 0; j < 3; j++) {
+            skip_fr_vec(r, pk->K);
+            skip_domain(r, pk->K);
+        }
+        for (int j = 0; j < 4; j++) {
+            skip_fr_vec(r, pk->B);
+            skip_domain(r, pk->B);
+        }
+    }
+    std::vector<G1Affine> powers = get_g1_vec_dev(ctx, r, 1ull << 31);
+    std::vector<G1Affine> shifted;
+    if (r.boolean()) shifted = get_g1_vec_dev(ctx, r, 1ull << 31);
+    uint64_t ng = r.u64();
+    if (ng > 16) throw MarlinError(SWM_ERR_SERIALIZATION, "bad gamma count");
+    for (uint64_t i = 0; i < ng; i++) pk->gamma_powers.push_back(r.g1());
+    std::vector<uint64_t> bounds;
+    if (r.boolean()) {
+        uint64_t nb = r.u64();
+        if (nb > 64) throw MarlinError(SWM_ERR_SERIALIZATION, "bad degree-bound count");
+        for (uint64_t i = 0; i < nb; i++) bounds.push_back(r.u64());
+    }
+    pk->srs_max_degree = r.u64();
+    if (r.pos != len) throw MarlinError(SWM_ERR_SERIALIZATION, "trailing bytes");
+    const uint64_t max_bound = std::max(pk->H, pk->K) - 2;
+    if (powers.size() < ahp_max_degree(pk->info.num_constraints, pk->info.num_variables, pk->info.num_non_zero) + 1 ||
+        powers.size() > pk->srs_max_degree + 1 || shifted.size() != max_bound + 1 || pk->gamma_powers.size() < 3 ||
+        pk->srs_max_degree != pk->vk.vk.max_degree)
+        throw MarlinError(SWM_ERR_SERIALIZATION, "committer key does not fit the index");
+    install_committer_key(ctx, *pk, powers.data(), powers.size(), shifted.data(), shifted.size(), /*device_src=*/false);
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->a = upload_csr(ctx, pk->ha);
     pk->b = upload_csr(ctx, pk->hb);
@@ -1440,6 +1718,65 @@ int swm_srs_power_of_g(swm_ctx* ctx, const swm_srs* srs, size_t i, uint64_t out_
     SWM_GUARD(ctx, {
         G1Affine p = srs_power(ctx, srs->d_powers, i);
         memcpy(out_xy, &p, sizeof(p));
+    });
+}
+
+static void g2_to_limbs(const G2Affine& p, uint64_t out[24]) {
+    if (p.inf) {
+        memset(out, 0, 24 * 8);
+        return;
+    }
+    memcpy(out, &p.x.c0, 48);
+    memcpy(out + 6, &p.x.c1, 48);
+    memcpy(out + 12, &p.y.c0, 48);
+    memcpy(out + 18, &p.y.c1, 48);
+}
+static G2Affine g2_from_limbs(const uint64_t in[24]) {
+    G2Affine p;
+    bool zero = true;
+    for (int i = 0; i < 24; i++) zero &= in[i] == 0;
+    if (zero) return g2_identity();
+    p.inf = false;
+    memcpy(&p.x.c0, in, 48);
+    memcpy(&p.x.c1, in + 6, 48);
+    memcpy(&p.y.c0, in + 12, 48);
+    memcpy(&p.y.c1, in + 18, 48);
+    return p;
+}
+int swm_srs_export(swm_ctx* ctx, const swm_srs* srs, size_t first, size_t count, uint64_t* powers_xy, uint64_t gamma_xy[36],
+                   uint64_t h[24], uint64_t beta_h[24]) {
+    if (!ctx || !srs || first > srs->max_degree + 1 || count > srs->max_degree + 1 - first || (count && !powers_xy))
+        return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
+    SWM_GUARD(ctx, {
+        if (count) {
+            hip_check(ctx, hipMemcpyAsync(powers_xy, srs->d_powers + first, count * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream), "d2h");
+            hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        }
+        if (gamma_xy)
+            for (size_t i = 0; i < 3; i++) memcpy(gamma_xy + 12 * i, &srs->gamma_powers[i], sizeof(G1Affine));
+        if (h) g2_to_limbs(srs->h, h);
+        if (beta_h) g2_to_limbs(srs->beta_h, beta_h);
+    });
+}
+int swm_srs_import(swm_ctx* ctx, const uint64_t* powers_xy, size_t n_powers, const uint64_t gamma_xy[36], const uint64_t h[24],
+                   const uint64_t beta_h[24], swm_srs** out) {
+    if (!ctx || !powers_xy || n_powers < 2 || !gamma_xy || !h || !beta_h || !out) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
+    SWM_GUARD(ctx, {
+        std::unique_ptr<swm_srs> srs(new swm_srs());
+        srs->max_degree = n_powers - 1;
+        for (size_t i = 0; i < 3; i++) {
+            G1Affine g;
+            memcpy(&g, gamma_xy + 12 * i, sizeof(G1Affine));
+            srs->gamma_powers.push_back(g);
+        }
+        srs->h = g2_from_limbs(h);
+        srs->beta_h = g2_from_limbs(beta_h);
+        hip_check(ctx, hipMalloc((void**)&srs->d_powers, n_powers * sizeof(G1Affine)), "hipMalloc(srs)");
+        hip_check(ctx, hipMemcpyAsync(srs->d_powers, powers_xy, n_powers * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream), "h2d");
+        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        *out = srs.release();
     });
 }
 

@@ -808,6 +808,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
     ctx->stat_msm_calls++;
     ctx->stat_msm_points += n;
+    ctx->log_call('m', n);
     WinLayout pl = msm_plan(n);
     const size_t total = n * (size_t)pl.nwin;
     ctx->stat_msm_digits += total;
@@ -973,6 +974,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
                                 ctx->stream));
     SWM_HIP(ctx, hipMemcpyAsync((void*)job->host_flags, big_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipMemcpyAsync((void*)(job->host_flags + 1), bucket_off + pl.NB, 4, hipMemcpyDeviceToHost, ctx->stream));
     SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
     job->active = true;
     ctx->slot_busy[slot] = true;
@@ -985,6 +987,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     SWM_HIP(ctx, hipEventSynchronize(job->done));
     job->active = false;
     ctx->slot_busy[job->slot] = false;
+    ctx->stat_msm_adds += job->host_flags[1];  // entries the sort placed = non-zero digits
     if (job->host_flags[0])
         return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: a scalar is not a canonical field element (>= r)");
     // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per

@@ -202,6 +202,7 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
     if (log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: log_n > 30 unsupported");
     const uint64_t n = 1ull << log_n;
     ctx->stat_ntt_calls++;
+    ctx->log_call('n', log_n);
     ctx->stat_ntt_elems += n;
     Fr* data = reinterpret_cast<Fr*>(d_data);
     NttTables *rt = nullptr, *ct = nullptr;

@@ -112,6 +112,9 @@ int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* 
         if (plan) {
             nnz = (uint32_t)plan->nnz;
             max_row = (uint32_t)plan->max_row;
+            ctx->stat_spmv_nnz += nnz;
+            ctx->log_call('s', rows);
+            ctx->log_call('z', nnz);
         } else {
             DBuf<uint32_t> stats(ctx, 2);
             stats.zero();
@@ -120,6 +123,9 @@ int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* 
             std::vector<uint32_t> h = stats.download(0, 2);
             nnz = h[0];
             max_row = h[1];
+            ctx->stat_spmv_nnz += nnz;
+            ctx->log_call('s', rows);
+            ctx->log_call('z', nnz);
         }
         if (plan && max_row > SPMV_DIRECT_MAX) {
             // short rows directly (long ones are skipped), long rows by chunks

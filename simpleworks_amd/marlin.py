@@ -237,6 +237,30 @@ class UniversalSRS:
         _check(self.ctx.lib.swm_srs_power_of_g(self.ctx.h, self.h, i, _p64(out)), "swm_srs_power_of_g", self.ctx)
         return out
 
+    def export(self):
+        """swm_srs_export: (powers (n, 12), gamma powers (3, 12), h (24,), beta_h (24,)) — the fields of arkworks'
+        kzg10::UniversalParams as Montgomery limbs."""
+        n = self.max_degree + 1
+        powers = np.zeros((n, 12), dtype=np.uint64)
+        gamma = np.zeros((3, 12), dtype=np.uint64)
+        h, bh = np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64)
+        _check(self.ctx.lib.swm_srs_export(self.ctx.h, self.h, 0, n, _p64(powers), _p64(gamma), _p64(h), _p64(bh)),
+               "swm_srs_export", self.ctx)
+        return powers, gamma, h, bh
+
+    @staticmethod
+    def from_parts(powers, gamma, h, beta_h, ctx=None):
+        """swm_srs_import: a UniversalSRS built elsewhere (arkworks' UniversalParams flattened by the binding)."""
+        ctx = ctx or default_context()
+        powers = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 12)
+        gamma = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(3, 12)
+        hd = _vp()
+        _check(ctx.lib.swm_srs_import(ctx.h, _p64(powers), powers.shape[0], _p64(gamma),
+                                      _p64(np.ascontiguousarray(h, dtype=np.uint64)),
+                                      _p64(np.ascontiguousarray(beta_h, dtype=np.uint64)), ctypes.byref(hd)),
+               "swm_srs_import", ctx)
+        return UniversalSRS(ctx, hd)
+
     def free(self):
         if self.h:
             self.ctx.lib.swm_srs_destroy(self.ctx.h, self.h)

@@ -284,6 +284,28 @@ def gen_marlin_merkle():
         "proof": pbytes.hex(), "vk": M.serialize_verifying_key(vk).hex()}})
 
 
+def gen_pk_bytes():
+    """sha256 + length of serialize_proving_key (src/marlin/serialization.rs:33-39: IndexProverKey CanonicalSerialize,
+    layout [U]) for three small keys: tight SRS, |K| != |H|, and an SRS much larger than the index (trimmed powers and
+    shifted powers do not overlap)."""
+    import hashlib
+    out = {}
+    for name, cs, sizes in (("manual_constraints", M.manual_constraints_circuit(1, 1), (100, 25, 300)),
+                            ("synthetic_8", M.synthetic_circuit(8, 3, 5), (8, 8, 8)),
+                            ("random_sparse", M.random_sparse_circuit(seed=20261002), None)):
+        if sizes is None:
+            a_m, b_m, c_m = cs.to_matrices()
+            sizes = (cs.num_constraints, len(cs.instance) + len(cs.witness), max(sum(len(r) for r in m) for m in (a_m, b_m, c_m)))
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*sizes, rng)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        b = M.serialize_proving_key(pk)
+        out[name] = {"srs": list(sizes), "len": len(b), "sha256": hashlib.sha256(b).hexdigest(), "head": b[:64].hex(),
+                     "n_powers": len(pk["ck"].powers), "n_shifted": len(pk["ck"].shifted_powers)}
+        print(" pk bytes", name, len(b))
+    dump("pk_bytes.json", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fields", "g1_msm", "ntt", "misc", "rng", "marlin", "marlin_merkle"]
     for w in which:

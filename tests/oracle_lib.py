@@ -24,10 +24,12 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-def load():
-    if not os.path.exists(LIB_PATH):
-        build()
-    lib = ctypes.CDLL(LIB_PATH)
+def load(path=None):
+    if path is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        path = LIB_PATH
+    lib = ctypes.CDLL(path)
     sz = ctypes.c_size_t
     for name, args in {
         "oracle_fr_to_mont": [_u64p, _u64p, sz], "oracle_fr_from_mont": [_u64p, _u64p, sz],
@@ -41,6 +43,7 @@ def load():
         "oracle_msm_g1": [_u64p, _u64p, sz, _u64p, ctypes.c_int],
         "oracle_ntt_fr": [_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int],
         "oracle_spmv_fr": [_u32p, _u32p, _u64p, _u64p, _u64p, sz],
+        "oracle_spmv_fr_mt": [_u32p, _u32p, _u64p, _u64p, _u64p, sz, ctypes.c_int],
     }.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
@@ -90,8 +93,8 @@ def h2i(s):
 class Oracle:
     """numpy-level convenience API over the C oracle."""
 
-    def __init__(self):
-        self.lib = load()
+    def __init__(self, path=None):
+        self.lib = load(path)
 
     # Fr / Fq conversions
     def fr_to_mont(self, std):
@@ -158,10 +161,10 @@ class Oracle:
         self.lib.oracle_ntt_fr(p64(d), log_n, inverse, coset, threads)
         return d
 
-    def spmv(self, rowptr, col, val_mont, z_mont):
+    def spmv(self, rowptr, col, val_mont, z_mont, threads=1):
         rows = len(rowptr) - 1
         out = np.zeros((rows, 4), dtype=np.uint64)
-        self.lib.oracle_spmv_fr(p32(rowptr), p32(col), p64(val_mont), p64(z_mont), p64(out), rows)
+        self.lib.oracle_spmv_fr_mt(p32(rowptr), p32(col), p64(val_mont), p64(z_mont), p64(out), rows, threads)
         return out
 
     def fixed_base_mul(self, base_mont12, scalars_std, threads=None):

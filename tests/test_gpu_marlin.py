@@ -321,16 +321,18 @@ def test_callback_rng_reproduces_golden_bytes(M, S, W):
     prove through the callback emit the golden bytes — including the bulk draw of the mask polynomial."""
     for name in ("synthetic_32", "random_sparse"):
         case = golden("marlin.json")[name]
-        src = M.generate_rand()  # stands for the caller's StdRng
+        src = M.generate_rand()  # stands for the caller's StdRng: a flat stream of 32-bit words
         served = [0]
+        pending = bytearray()
 
-        def fill(n):
+        def fill(n, pending=pending, src=src, served=served):
+            assert n % 4 == 0  # the library only asks for whole words (next_u32 / next_u64 / 32-byte candidates)
             served[0] += n
-            out = bytearray()
-            while len(out) < n:
-                out += src.next_u64().to_bytes(8, "little")
-            assert len(out) == n  # the library only asks for whole u64 / whole candidates
-            return bytes(out)
+            while len(pending) < n:
+                pending.extend(src.next_u64().to_bytes(8, "little"))
+            out = bytes(pending[:n])
+            del pending[:n]
+            return out
         rng = M.rng_from_fill_bytes(fill)
         srs = M.generate_universal_srs(*case["srs"], rng)
         if name.startswith("random_"):
@@ -398,3 +400,82 @@ def test_two_contexts_two_threads_prove_concurrently(M, W):
         pk.free()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("name", ["manual_constraints", "synthetic_8", "random_sparse"])
+def test_proving_key_bytes_are_the_ark_serialize_layout(M, S, W, name):
+    """serialize_proving_key (src/marlin/serialization.rs:33-39) emits IndexProverKey's CanonicalSerialize bytes: equal
+    (length, sha256, first bytes) to the pure-Python model's for a tight SRS, for |K| != |H| and for an SRS much larger
+    than the index (trimmed and shifted powers do not overlap); the bytes load back into a key that proves identically,
+    and corrupt bytes are refused with arkworks' checks."""
+    import hashlib
+    case = golden("pk_bytes.json")[name]
+    if name == "manual_constraints":
+        cs = W.manual_constraints_circuit(1, 1)
+    elif name == "synthetic_8":
+        cs = W.synthetic_circuit(8, 3, 5)
+    else:
+        cs = W.random_sparse_circuit(seed=20261002)
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*case["srs"], rng)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    blob = S.serialize_proving_key(pk)
+    assert blob[:64].hex() == case["head"]
+    assert len(blob) == case["len"]
+    assert hashlib.sha256(blob).hexdigest() == case["sha256"]
+    pk2 = S.deserialize_proving_key(blob)
+    assert S.serialize_proving_key(pk2) == blob
+    seed = bytes(range(32))
+    p1 = M.generate_proof(cs, pk, M.rng_from_seed(seed))
+    p2 = M.generate_proof(cs, pk2, M.rng_from_seed(seed))
+    assert p1.data == p2.data
+    assert M.verify_proof(vk, cs.instance[1:], p2, M.generate_rand())
+    # the committer key sits at the end: ... powers | 1 | shifted | gamma (3) | 1 | bounds | max_degree
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proving_key(blob[:-5])
+    with pytest.raises(M.MarlinError):
+        S.deserialize_proving_key(blob + b"\x00")
+    # a curve point outside the prime-order subgroup in place of the last shifted power
+    from oracle_lib import Q
+    from pyref import bls12_377 as bls
+    x = 5
+    while True:
+        y = bls.fq_sqrt((x * x * x + 1) % Q)
+        if y is not None and bls.g1_mul_fast((x, y), bls.R) is not None:
+            break
+        x += 1
+    enc = bytearray(x.to_bytes(48, "little"))
+    if y > (Q - y) % Q:
+        enc[47] |= 0x80
+    # locate the gamma-power count (u64 == 3) that follows the shifted powers
+    marker = (3).to_bytes(8, "little")
+    pos = blob.rfind(marker, 0, len(blob) - 3 * 48)
+    assert pos > 0
+    bad = bytearray(blob)
+    bad[pos - 48:pos] = enc
+    with pytest.raises(M.MarlinError) as e:
+        S.deserialize_proving_key(bytes(bad))
+    assert e.value.code == -7
+    pk.free()
+    pk2.free()
+    srs.free()
+
+
+def test_universal_srs_export_import(M, W):
+    """swm_srs_export / swm_srs_import: the fields of arkworks' UniversalParams leave and re-enter the library; a key
+    indexed from the re-imported SRS is the same key."""
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(32, 32, 32, rng)
+    powers, gamma, h, bh = srs.export()
+    assert powers.shape == (srs.max_degree + 1, 12)
+    assert np.array_equal(powers[1], srs.power_of_g(1))
+    srs2 = M.UniversalSRS.from_parts(powers, gamma, h, bh)
+    cs = W.synthetic_circuit(32, 3, 5)
+    from simpleworks_amd import serialization as S
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    pk2, vk2 = M.generate_proving_and_verifying_keys(srs2, cs)
+    assert S.serialize_verifying_key(vk) == S.serialize_verifying_key(vk2)
+    seed = bytes([3] * 32)
+    assert M.generate_proof(cs, pk, M.rng_from_seed(seed)).data == M.generate_proof(cs, pk2, M.rng_from_seed(seed)).data
+    for o in (pk, pk2, srs, srs2):
+        o.free()
