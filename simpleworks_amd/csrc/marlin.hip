@@ -1280,7 +1280,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
 // ================================================================================================ key (de)serialisation
 // serialize_proving_key / deserialize_proving_key (src/marlin/serialization.rs:33-45): the CanonicalSerialize bytes of
 // ark_marlin::IndexProverKey<Fr, MarlinKZG10<..>>, field order of ark-marlin / ark-poly-commit / ark-poly 0.3.0's derives
-// as recalled [U] (the same layout oracle/pyref/marlin.py::serialize_proving_key emits; parity test on small keys):
+// as recalled [U] (the test suite compares the bytes of small keys with an independent model's):
 //   IndexProverKey { index_vk, index_comm_rands: Vec<marlin_pc::Randomness>, index: Index, committer_key }
 //   Index { index_info, a, b, c: Matrix = Vec<Vec<(F, usize)>>, a_star_arith, b_star_arith, c_star_arith }
 //   MatrixArithmetization { row, col, val, row_col: LabeledPolynomial { label, coeffs, degree_bound, hiding_bound },
