@@ -1,0 +1,107 @@
+//! arkworks values <-> the packed limb buffers of the C ABI.  No `#[repr(C)]` exists on arkworks types, so everything is
+//! copied; nothing aliases a Rust struct.  Field elements travel as their Montgomery limbs (`Fp256(BigInteger256([u64; 4]))`
+//! holds exactly the bytes the library uses), points as affine Montgomery coordinates with all-zero for infinity.
+use crate::ffi;
+use ark_bls12_377::{Fq, Fq2, Fr, G1Affine, G2Affine};
+use ark_ff::{BigInteger256, BigInteger384, Fp256, Fp384, Zero};
+use ark_relations::r1cs::{ConstraintSystemRef, Matrix, SynthesisError};
+
+pub fn fr_limbs(f: &Fr) -> [u64; 4] {
+    (f.0).0
+}
+pub fn fr_from_limbs(l: [u64; 4]) -> Fr {
+    Fp256::new(BigInteger256(l)) // `new` takes the Montgomery representation as is
+}
+pub fn fq_from_limbs(l: &[u64]) -> Fq {
+    let mut a = [0u64; 6];
+    a.copy_from_slice(&l[..6]);
+    Fp384::new(BigInteger384(a))
+}
+pub fn g1_from_limbs(l: &[u64]) -> G1Affine {
+    if l[..12].iter().all(|w| *w == 0) {
+        return G1Affine::zero();
+    }
+    G1Affine::new(fq_from_limbs(&l[0..6]), fq_from_limbs(&l[6..12]), false)
+}
+pub fn g1_limbs(p: &G1Affine, out: &mut [u64]) {
+    if p.infinity {
+        out[..12].iter_mut().for_each(|w| *w = 0);
+    } else {
+        out[0..6].copy_from_slice(&(p.x.0).0);
+        out[6..12].copy_from_slice(&(p.y.0).0);
+    }
+}
+pub fn g2_from_limbs(l: &[u64]) -> G2Affine {
+    if l[..24].iter().all(|w| *w == 0) {
+        return G2Affine::zero();
+    }
+    let x = Fq2::new(fq_from_limbs(&l[0..6]), fq_from_limbs(&l[6..12]));
+    let y = Fq2::new(fq_from_limbs(&l[12..18]), fq_from_limbs(&l[18..24]));
+    G2Affine::new(x, y, false)
+}
+pub fn g2_limbs(p: &G2Affine, out: &mut [u64]) {
+    if p.infinity {
+        out[..24].iter_mut().for_each(|w| *w = 0);
+    } else {
+        out[0..6].copy_from_slice(&(p.x.c0.0).0);
+        out[6..12].copy_from_slice(&(p.x.c1.0).0);
+        out[12..18].copy_from_slice(&(p.y.c0.0).0);
+        out[18..24].copy_from_slice(&(p.y.c1.0).0);
+    }
+}
+
+/// `cs.to_matrices()` + the assignments, flattened to what `struct swm_r1cs` points at.  The buffers live as long as
+/// this value; `as_ffi` hands out pointers into them for the duration of one call.
+pub struct PackedR1cs {
+    instance: Vec<u64>,
+    witness: Vec<u64>,
+    mats: [(Vec<u32>, Vec<u32>, Vec<u64>); 3],
+    num_constraints: usize,
+}
+
+fn csr(m: &Matrix<Fr>) -> (Vec<u32>, Vec<u32>, Vec<u64>) {
+    let nnz: usize = m.iter().map(|r| r.len()).sum();
+    let (mut rowptr, mut col, mut val) = (Vec::with_capacity(m.len() + 1), Vec::with_capacity(nnz), Vec::with_capacity(4 * nnz));
+    rowptr.push(0u32);
+    for row in m {
+        for (coeff, j) in row {
+            col.push(*j as u32);
+            val.extend_from_slice(&fr_limbs(coeff));
+        }
+        rowptr.push(col.len() as u32);
+    }
+    (rowptr, col, val)
+}
+
+impl PackedR1cs {
+    /// What ark-marlin's `prove_from_constraint_system` / `index_from_constraint_system` (the fork the reference pins,
+    /// /root/reference/Cargo.toml:30) read from a live constraint system: finalise (inline the linear combinations), take
+    /// the matrices and the two assignment vectors.  Padding and squaring happen inside the library, as in ark-marlin.
+    pub fn from_cs(cs: &ConstraintSystemRef<Fr>) -> Result<Self, SynthesisError> {
+        cs.finalize();
+        let m = cs.to_matrices().ok_or(SynthesisError::MissingCS)?;
+        let b = cs.borrow().ok_or(SynthesisError::MissingCS)?;
+        let flat = |v: &[Fr]| -> Vec<u64> { v.iter().flat_map(|f| fr_limbs(f)).collect() };
+        Ok(PackedR1cs {
+            instance: flat(&b.instance_assignment),
+            witness: flat(&b.witness_assignment),
+            mats: [csr(&m.a), csr(&m.b), csr(&m.c)],
+            num_constraints: m.num_constraints,
+        })
+    }
+
+    pub fn as_ffi(&self) -> ffi::swm_r1cs {
+        let p32 = |v: &Vec<u32>| if v.is_empty() { std::ptr::null() } else { v.as_ptr() };
+        let p64 = |v: &Vec<u64>| if v.is_empty() { std::ptr::null() } else { v.as_ptr() };
+        ffi::swm_r1cs {
+            num_instance: self.instance.len() / 4,
+            num_witness: self.witness.len() / 4,
+            num_constraints: self.num_constraints,
+            instance: self.instance.as_ptr(),
+            witness: p64(&self.witness),
+            a_rowptr: self.mats[0].0.as_ptr(), a_col: p32(&self.mats[0].1), a_val: p64(&self.mats[0].2),
+            b_rowptr: self.mats[1].0.as_ptr(), b_col: p32(&self.mats[1].1), b_val: p64(&self.mats[1].2),
+            c_rowptr: self.mats[2].0.as_ptr(), c_col: p32(&self.mats[2].1), c_val: p64(&self.mats[2].2),
+        }
+    }
+}

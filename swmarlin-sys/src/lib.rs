@@ -1,0 +1,13 @@
+//! swmarlin-sys: `ffi` = the raw C ABI of include/swmarlin.h; `marlin` = safe functions with exactly the signatures of
+//! simpleworks' `src/marlin/mod.rs` (/root/reference/src/marlin/mod.rs:12-94), implemented on the MI355X library.
+//!
+//! simpleworks' own `src/marlin/mod.rs` shrinks to
+//! ```ignore
+//! pub use swmarlin_sys::marlin::*;
+//! pub mod serialization;            // unchanged: ark-serialize on arkworks types
+//! ```
+//! and every caller (`SimpleMerkleTree`, the examples, external VMs) compiles unchanged: the types are still the
+//! arkworks types, the rng is still the caller's `&mut StdRng`.
+pub mod ffi;
+pub mod marlin;
+mod convert;

@@ -1,0 +1,376 @@
+//! Drop-in for /root/reference/src/marlin/mod.rs:12-94 — same type aliases, same five functions, same signatures
+//! (`&mut StdRng`, arkworks `ProvingKey` / `VerifyingKey` by value, `Box<UniversalSRS>`), same error convention
+//! (`anyhow!("{:?}", e)`), with the arithmetic running in libswmarlin.so on an MI355X.
+//!
+//! How arkworks values cross the boundary
+//! * `&mut StdRng`         -> `swm_rng_from_callback` over a `fill_bytes` trampoline: the library draws from the caller's
+//!                            generator, word for word as arkworks would (setup trapdoor, zk blinding, verifier batching).
+//! * `ConstraintSystemRef` -> `PackedR1cs::from_cs` (matrices + assignments as flat arrays).
+//! * `UniversalSRS`        -> `swm_srs_export` / `swm_srs_import` (the fields of kzg10::UniversalParams).
+//! * `ProvingKey`, `VerifyingKey`, `MarlinProof` -> their CanonicalSerialize bytes, which the library reads and writes
+//!                            (`swm_pk_*`, `swm_vk_*`, proof bytes) — the interchange format src/marlin/serialization.rs defines.
+//! Device-resident twins of keys and SRS are cached per thread, keyed by a digest of the verifying key (resp. of the first
+//! SRS powers), so `generate_proof(cs, proving_key, rng)` — which takes the key BY VALUE in the reference — pays the
+//! import (serialise + upload + re-derive tables) once per key and thread, not once per proof.
+use crate::convert::*;
+use crate::ffi::*;
+use anyhow::{anyhow, Result};
+use ark_bls12_377::{Bls12_377, Fr, FrParameters, G1Affine, G2Affine, Parameters};
+use ark_ec::bls12::Bls12;
+use ark_ff::Fp256;
+use ark_marlin::{IndexProverKey, IndexVerifierKey, Marlin, Proof, SimpleHashFiatShamirRng};
+use ark_poly::univariate::DensePolynomial;
+use ark_poly_commit::marlin_pc::MarlinKZG10;
+use ark_serialize::{CanonicalDeserialize, CanonicalSerialize};
+use blake2::Blake2s;
+use digest::Digest;
+use rand::rngs::StdRng;
+use rand::RngCore;
+use rand_chacha::ChaChaRng;
+use std::cell::RefCell;
+use std::collections::{BTreeMap, HashMap};
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+
+pub type MultiPC = MarlinKZG10<Bls12_377, DensePolynomial<Fr>>;
+pub type FS = SimpleHashFiatShamirRng<Blake2s, ChaChaRng>;
+pub type MarlinInst = Marlin<Fr, MultiPC, FS>;
+pub type UniversalSRS = ark_marlin::UniversalSRS<Fr, MultiPC>;
+pub type ConstraintSystemRef = ark_relations::r1cs::ConstraintSystemRef<Fr>;
+pub type VerifyingKey =
+    IndexVerifierKey<Fp256<FrParameters>, MarlinKZG10<Bls12<Parameters>, DensePolynomial<Fp256<FrParameters>>>>;
+pub type ProvingKey =
+    IndexProverKey<Fp256<FrParameters>, MarlinKZG10<Bls12<Parameters>, DensePolynomial<Fp256<FrParameters>>>>;
+pub type MarlinProof = Proof<Fr, MarlinKZG10<Bls12<Parameters>, DensePolynomial<Fp256<FrParameters>>>>;
+/// `crate::gadgets::ConstraintF` in simpleworks (= ark_ed_on_bls12_377::Fq = BLS12-377 Fr, src/gadgets/mod.rs:29)
+pub type ConstraintF = Fr;
+
+// ------------------------------------------------------------------------------------------------ errors
+#[derive(Debug)]
+pub struct SwmError {
+    pub code: c_int,
+    pub what: &'static str,
+    pub detail: String,
+}
+fn cstr(p: *const std::os::raw::c_char) -> String {
+    if p.is_null() {
+        return String::new();
+    }
+    unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()
+}
+fn check(rc: c_int, what: &'static str, ctx: *mut swm_ctx) -> std::result::Result<(), SwmError> {
+    if rc == SWM_OK {
+        return Ok(());
+    }
+    let detail = format!("{}: {}", cstr(unsafe { swm_strerror(rc) }), cstr(unsafe { swm_last_error(ctx) }));
+    Err(SwmError { code: rc, what, detail })
+}
+
+// ------------------------------------------------------------------------------------------------ per-thread state
+// A ConstraintSystemRef is Rc<RefCell<..>> (!Send): one proof is driven by one thread, and so is one context.
+struct State {
+    ctx: *mut swm_ctx,
+    srs: HashMap<[u8; 32], *mut swm_srs>,
+    pks: HashMap<[u8; 32], *mut swm_pk>,
+}
+impl State {
+    fn new() -> std::result::Result<Self, SwmError> {
+        let device = std::env::var("SWM_DEVICE").ok().and_then(|s| s.parse::<c_int>().ok()).unwrap_or(0);
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { swm_init(device, &mut ctx) }, "swm_init", std::ptr::null_mut())?;
+        Ok(State { ctx, srs: HashMap::new(), pks: HashMap::new() })
+    }
+}
+impl Drop for State {
+    fn drop(&mut self) {
+        unsafe {
+            for (_, pk) in self.pks.drain() {
+                swm_pk_destroy(self.ctx, pk);
+            }
+            for (_, srs) in self.srs.drain() {
+                swm_srs_destroy(self.ctx, srs);
+            }
+            swm_destroy(self.ctx);
+        }
+    }
+}
+thread_local! {
+    static STATE: RefCell<Option<State>> = RefCell::new(None);
+}
+fn with_state<T>(f: impl FnOnce(&mut State) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+    STATE.with(|cell| {
+        let mut slot = cell.borrow_mut();
+        if slot.is_none() {
+            *slot = Some(State::new()?);
+        }
+        f(slot.as_mut().expect("state initialised above"))
+    })
+}
+
+// ------------------------------------------------------------------------------------------------ the caller's rng
+unsafe extern "C" fn fill_bytes_trampoline(user: *mut c_void, dest: *mut u8, len: usize) {
+    let rng = &mut *(user as *mut StdRng);
+    rng.fill_bytes(std::slice::from_raw_parts_mut(dest, len));
+}
+/// Runs `f` with a library handle that draws from `rng`; the handle does not outlive the borrow.
+fn with_rng<T>(rng: &mut StdRng, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+    let mut h = std::ptr::null_mut();
+    check(
+        unsafe { swm_rng_from_callback(fill_bytes_trampoline, rng as *mut StdRng as *mut c_void, &mut h) },
+        "swm_rng_from_callback",
+        std::ptr::null_mut(),
+    )?;
+    let out = f(h);
+    unsafe { swm_rng_free(h) };
+    out
+}
+
+fn digest32(bytes: &[u8]) -> [u8; 32] {
+    let mut out = [0u8; 32];
+    out.copy_from_slice(Blake2s::digest(bytes).as_slice());
+    out
+}
+fn srs_key(srs: &UniversalSRS) -> [u8; 32] {
+    // the first powers identify a setup (beta and g); cheap to compute, no need to hash 100 MB
+    let mut limbs = vec![0u64; 12 * 4];
+    for (i, p) in srs.powers_of_g.iter().take(4).enumerate() {
+        g1_limbs(p, &mut limbs[12 * i..12 * i + 12]);
+    }
+    let mut bytes = Vec::with_capacity(8 * limbs.len() + 8);
+    bytes.extend_from_slice(&(srs.powers_of_g.len() as u64).to_le_bytes());
+    for w in limbs {
+        bytes.extend_from_slice(&w.to_le_bytes());
+    }
+    digest32(&bytes)
+}
+fn vk_key(vk: &VerifyingKey) -> std::result::Result<([u8; 32], Vec<u8>), SwmError> {
+    let mut bytes = Vec::new();
+    vk.serialize(&mut bytes).map_err(|e| SwmError { code: -7, what: "VerifyingKey::serialize", detail: format!("{:?}", e) })?;
+    Ok((digest32(&bytes), bytes))
+}
+
+// ------------------------------------------------------------------------------------------------ the five functions
+/// Return a pseudorandom number generator (src/marlin/mod.rs:33-35).
+pub fn generate_rand() -> StdRng {
+    ark_std::test_rng()
+}
+
+/// Generate the universal prover and verifier keys for the argument system (src/marlin/mod.rs:45-55).
+pub fn generate_universal_srs(
+    num_constraints: usize,
+    num_variables: usize,
+    num_non_zero: usize,
+    rng: &mut StdRng,
+) -> Result<Box<UniversalSRS>> {
+    universal_setup(num_constraints, num_variables, num_non_zero, rng).map(Box::new).map_err(|e| anyhow!("{:?}", e))
+}
+
+fn universal_setup(nc: usize, nv: usize, nnz: usize, rng: &mut StdRng) -> std::result::Result<UniversalSRS, SwmError> {
+    with_state(|st| {
+        let ctx = st.ctx;
+        let handle = with_rng(rng, |r| {
+            let mut h = std::ptr::null_mut();
+            check(unsafe { swm_generate_universal_srs(ctx, nc, nv, nnz, r, &mut h) }, "swm_generate_universal_srs", ctx)?;
+            Ok(h)
+        })?;
+        let n = unsafe { swm_srs_max_degree(handle) } + 1;
+        let mut powers = vec![0u64; 12 * n];
+        let (mut gamma, mut h, mut bh) = ([0u64; 36], [0u64; 24], [0u64; 24]);
+        let rc = unsafe { swm_srs_export(ctx, handle, 0, n, powers.as_mut_ptr(), gamma.as_mut_ptr(), h.as_mut_ptr(), bh.as_mut_ptr()) };
+        if let Err(e) = check(rc, "swm_srs_export", ctx) {
+            unsafe { swm_srs_destroy(ctx, handle) };
+            return Err(e);
+        }
+        let powers_of_g: Vec<G1Affine> = powers.chunks_exact(12).map(g1_from_limbs).collect();
+        // arkworks keeps max_degree + 2 gamma powers; MarlinKZG10::trim reads indices 0..=hiding_bound + 1 = 0..=2 only
+        let mut powers_of_gamma_g = BTreeMap::new();
+        for i in 0..3 {
+            powers_of_gamma_g.insert(i, g1_from_limbs(&gamma[12 * i..12 * i + 12]));
+        }
+        let (h_pt, beta_h): (G2Affine, G2Affine) = (g2_from_limbs(&h), g2_from_limbs(&bh));
+        let srs = UniversalSRS {
+            powers_of_g,
+            powers_of_gamma_g,
+            h: h_pt,
+            beta_h,
+            neg_powers_of_h: BTreeMap::new(),
+            prepared_h: h_pt.into(),
+            prepared_beta_h: beta_h.into(),
+        };
+        st.srs.insert(srs_key(&srs), handle); // index() finds the resident twin instead of uploading it again
+        Ok(srs)
+    })
+}
+
+fn resident_srs(st: &mut State, srs: &UniversalSRS) -> std::result::Result<*mut swm_srs, SwmError> {
+    let key = srs_key(srs);
+    if let Some(h) = st.srs.get(&key) {
+        return Ok(*h);
+    }
+    let n = srs.powers_of_g.len();
+    let mut powers = vec![0u64; 12 * n];
+    for (i, p) in srs.powers_of_g.iter().enumerate() {
+        g1_limbs(p, &mut powers[12 * i..12 * i + 12]);
+    }
+    let mut gamma = [0u64; 36];
+    for i in 0..3usize {
+        let p = srs.powers_of_gamma_g.get(&i).ok_or(SwmError { code: -1, what: "UniversalSRS", detail: "missing gamma power".into() })?;
+        g1_limbs(p, &mut gamma[12 * i..12 * i + 12]);
+    }
+    let (mut h, mut bh) = ([0u64; 24], [0u64; 24]);
+    g2_limbs(&srs.h, &mut h);
+    g2_limbs(&srs.beta_h, &mut bh);
+    let mut out = std::ptr::null_mut();
+    check(unsafe { swm_srs_import(st.ctx, powers.as_ptr(), n, gamma.as_ptr(), h.as_ptr(), bh.as_ptr(), &mut out) }, "swm_srs_import", st.ctx)?;
+    st.srs.insert(key, out);
+    Ok(out)
+}
+
+/// src/marlin/mod.rs:88-94
+pub fn generate_proving_and_verifying_keys(
+    universal_srs: &UniversalSRS,
+    constraint_system: ConstraintSystemRef,
+) -> Result<(ProvingKey, VerifyingKey)> {
+    index(universal_srs, constraint_system).map_err(|e| anyhow!("{:?}", e))
+}
+
+fn bytes_of(mut call: impl FnMut(*mut u8, usize, *mut usize) -> c_int, what: &'static str, ctx: *mut swm_ctx) -> std::result::Result<Vec<u8>, SwmError> {
+    let mut len = 0usize;
+    check(call(std::ptr::null_mut(), 0, &mut len), what, ctx)?;
+    let mut buf = vec![0u8; len];
+    check(call(buf.as_mut_ptr(), len, &mut len), what, ctx)?;
+    buf.truncate(len);
+    Ok(buf)
+}
+
+fn index(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(ProvingKey, VerifyingKey), SwmError> {
+    let packed = PackedR1cs::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "to_matrices", detail: format!("{:?}", e) })?;
+    with_state(|st| {
+        let ctx = st.ctx;
+        let srs_h = resident_srs(st, srs)?;
+        let (mut pk_h, mut vk_h) = (std::ptr::null_mut(), std::ptr::null_mut());
+        let r1cs = packed.as_ffi();
+        check(unsafe { swm_generate_proving_and_verifying_keys(ctx, srs_h, &r1cs, &mut pk_h, &mut vk_h) },
+              "swm_generate_proving_and_verifying_keys", ctx)?;
+        let vk_bytes = bytes_of(|p, cap, len| unsafe { swm_vk_serialize(vk_h, p, cap, len) }, "swm_vk_serialize", ctx);
+        unsafe { swm_vk_destroy(vk_h) };
+        let pk_bytes = bytes_of(|p, cap, len| unsafe { swm_pk_serialize(ctx, pk_h, p, cap, len) }, "swm_pk_serialize", ctx);
+        let (vk_bytes, pk_bytes) = match (vk_bytes, pk_bytes) {
+            (Ok(v), Ok(p)) => (v, p),
+            (Err(e), _) | (_, Err(e)) => {
+                unsafe { swm_pk_destroy(ctx, pk_h) };
+                return Err(e);
+            }
+        };
+        let de = |e: ark_serialize::SerializationError| SwmError { code: -7, what: "CanonicalDeserialize", detail: format!("{:?}", e) };
+        let vk = VerifyingKey::deserialize(&mut vk_bytes.as_slice()).map_err(de);
+        let pk = ProvingKey::deserialize(&mut pk_bytes.as_slice()).map_err(de);
+        match (pk, vk) {
+            (Ok(pk), Ok(vk)) => {
+                if let Some(old) = st.pks.insert(digest32(&vk_bytes), pk_h) {
+                    unsafe { swm_pk_destroy(ctx, old) };
+                }
+                Ok((pk, vk))
+            }
+            (Err(e), _) | (_, Err(e)) => {
+                unsafe { swm_pk_destroy(ctx, pk_h) };
+                Err(e)
+            }
+        }
+    })
+}
+
+fn resident_pk(st: &mut State, pk: &ProvingKey) -> std::result::Result<*mut swm_pk, SwmError> {
+    let (key, _) = vk_key(&pk.index_vk)?;
+    if let Some(h) = st.pks.get(&key) {
+        return Ok(*h);
+    }
+    // a key this thread has not seen (deserialised from disk, built by arkworks): move it in through its bytes
+    let mut bytes = Vec::new();
+    pk.serialize(&mut bytes).map_err(|e| SwmError { code: -7, what: "ProvingKey::serialize", detail: format!("{:?}", e) })?;
+    let mut h = std::ptr::null_mut();
+    check(unsafe { swm_pk_deserialize(st.ctx, bytes.as_ptr(), bytes.len(), &mut h) }, "swm_pk_deserialize", st.ctx)?;
+    st.pks.insert(key, h);
+    Ok(h)
+}
+
+/// Return the marlin proof for the given circuit/constraint system (src/marlin/mod.rs:70-77).
+pub fn generate_proof(
+    constraint_system: ConstraintSystemRef,
+    proving_key: ProvingKey,
+    rng: &mut StdRng,
+) -> Result<MarlinProof> {
+    prove(&proving_key, constraint_system, rng).map_err(|e| anyhow!("{:?}", e))
+}
+
+fn prove(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut StdRng) -> std::result::Result<MarlinProof, SwmError> {
+    let packed = PackedR1cs::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "to_matrices", detail: format!("{:?}", e) })?;
+    with_state(|st| {
+        let ctx = st.ctx;
+        let pk_h = resident_pk(st, pk)?;
+        let r1cs = packed.as_ffi();
+        let mut buf = vec![0u8; 2048];
+        let mut len = 0usize;
+        with_rng(rng, |r| check(unsafe { swm_generate_proof(ctx, pk_h, &r1cs, r, buf.as_mut_ptr(), buf.len(), &mut len) }, "swm_generate_proof", ctx))?;
+        MarlinProof::deserialize(&mut &buf[..len]).map_err(|e| SwmError { code: -7, what: "Proof::deserialize", detail: format!("{:?}", e) })
+    })
+}
+
+/// src/marlin/mod.rs:79-86.  Host arithmetic (two pairings) in the library as in the reference; needs no GPU.
+pub fn verify_proof(
+    verifying_key: VerifyingKey,
+    public_inputs: &[ConstraintF],
+    proof: &MarlinProof,
+    rng: &mut StdRng,
+) -> Result<bool> {
+    verify(&verifying_key, public_inputs, proof, rng).map_err(|e| anyhow!("{:?}", e))
+}
+
+fn verify(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mut StdRng) -> std::result::Result<bool, SwmError> {
+    let (_, vk_bytes) = vk_key(vk)?;
+    let mut proof_bytes = Vec::new();
+    proof.serialize(&mut proof_bytes).map_err(|e| SwmError { code: -7, what: "Proof::serialize", detail: format!("{:?}", e) })?;
+    let inputs: Vec<u64> = public_inputs.iter().flat_map(|f| fr_limbs(f)).collect();
+    let mut vk_h = std::ptr::null_mut();
+    check(unsafe { swm_vk_deserialize(vk_bytes.as_ptr(), vk_bytes.len(), &mut vk_h) }, "swm_vk_deserialize", std::ptr::null_mut())?;
+    let mut ok: c_int = 0;
+    let out = with_rng(rng, |r| {
+        check(
+            unsafe {
+                swm_verify_proof(vk_h, if inputs.is_empty() { std::ptr::null() } else { inputs.as_ptr() }, public_inputs.len(),
+                                 proof_bytes.as_ptr(), proof_bytes.len(), r, &mut ok)
+            },
+            "swm_verify_proof",
+            std::ptr::null_mut(),
+        )
+    });
+    unsafe { swm_vk_destroy(vk_h) };
+    out.map(|_| ok != 0)
+}
+
+#[cfg(test)]
+mod tests {
+    //! The reference's own plumbing test (examples/manual-constraints.rs:86-100) against this module: needs an MI355X.
+    use super::*;
+    use ark_relations::{lc, r1cs::{ConstraintSynthesizer, ConstraintSystem, SynthesisError, Variable}};
+
+    struct ManualConstraints { a: Fr, b: Fr }
+    impl ConstraintSynthesizer<Fr> for ManualConstraints {
+        fn generate_constraints(self, cs: ark_relations::r1cs::ConstraintSystemRef<Fr>) -> std::result::Result<(), SynthesisError> {
+            let a = cs.new_input_variable(|| Ok(self.a))?;
+            let b = cs.new_witness_variable(|| Ok(self.b))?;
+            cs.enforce_constraint(lc!() + a - b, lc!() + Variable::One, lc!())
+        }
+    }
+
+    #[test]
+    fn manual_constraints_prove_and_verify() {
+        let mut rng = generate_rand();
+        let srs = generate_universal_srs(100, 25, 300, &mut rng).unwrap();
+        let cs = ConstraintSystem::<Fr>::new_ref();
+        ManualConstraints { a: Fr::from(1u64), b: Fr::from(1u64) }.generate_constraints(cs.clone()).unwrap();
+        let (pk, vk) = generate_proving_and_verifying_keys(&srs, cs.clone()).unwrap();
+        let proof = generate_proof(cs, pk, &mut rng).unwrap();
+        assert!(verify_proof(vk, &[Fr::from(1u64)], &proof, &mut rng).unwrap());
+    }
+}
