@@ -224,6 +224,19 @@ int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_
 typedef int (*swm_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
 int swm_set_msm_sharding(swm_ctx *ctx, unsigned rank, unsigned world, swm_allgather_fn allgather, void *user);
 
+/* The same exchange through RCCL INSIDE the library (one process per GPU, backend RCCL over xGMI): the partial sums of
+ * ALL commitments of a prover round travel in ONE ncclAllGather on the context's stream (k x 192 bytes per rank;
+ * 3-4 exchanges per proof), no callback, no host framework in the data path.  librccl is resolved at run time (the copy
+ * already loaded in the process if there is one, else librccl.so.1).
+ *   swm_rccl_unique_id  rank 0 creates the 128-byte ncclUniqueId and hands it to the other ranks by any means;
+ *   swm_rccl_init       every rank: ncclCommInitRank(world, id, rank) for this context, then sharding is on;
+ *   swm_set_rccl_comm   alternatively adopt a communicator the caller owns (same RCCL build); NULL switches back;
+ *   swm_exchange_stats  all-gathers issued so far and bytes contributed per rank (what a bench reports). */
+int swm_rccl_unique_id(uint8_t out[128]);
+int swm_rccl_init(swm_ctx *ctx, const uint8_t id[128], unsigned rank, unsigned world);
+int swm_set_rccl_comm(swm_ctx *ctx, void *nccl_comm, unsigned rank, unsigned world);
+int swm_exchange_stats(swm_ctx *ctx, uint64_t *calls, uint64_t *bytes_per_rank);
+
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every
  * kernel launch is bracketed by hipEventRecord on the stream it is launched on (on = 1), or only the launches of the

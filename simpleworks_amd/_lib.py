@@ -24,6 +24,10 @@ ABI = {
     "swm_last_error": (ctypes.c_char_p, [_vp]),
     "swm_set_stream": (_int, [_vp, _vp]),
     "swm_set_msm_sharding": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, _vp, _vp]),
+    "swm_rccl_unique_id": (_int, [ctypes.c_void_p]),
+    "swm_rccl_init": (_int, [_vp, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    "swm_set_rccl_comm": (_int, [_vp, _vp, ctypes.c_uint, ctypes.c_uint]),
+    "swm_exchange_stats": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "swm_synchronize": (_int, [_vp]),
     "swm_malloc": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
     "swm_free": (_int, [_vp, _vp]),
@@ -76,6 +80,15 @@ ABI = {
     "swm_selftest_g1_add": (_int, [_vp, _u64p, _u64p, _u64p, _sz]),
     "swm_selftest_mul_throughput": (_int, [_vp, _int, _sz, _int, ctypes.POINTER(ctypes.c_float)]),
 }
+
+
+def rccl_unique_id():
+    """swm_rccl_unique_id: 128 bytes created on rank 0, to be handed to every rank (swm_rccl_init)."""
+    buf = (ctypes.c_uint8 * 128)()
+    rc = load_library().swm_rccl_unique_id(buf)
+    if rc != 0:
+        raise SwmError(rc, "swm_rccl_unique_id", load_library().swm_last_error(None).decode(errors="replace"))
+    return bytes(buf)
 
 
 class SwmError(RuntimeError):
@@ -217,6 +230,17 @@ class Context:
         self._check(self.lib.swm_set_msm_sharding(self.h, rank, world, ctypes.cast(cb, ctypes.c_void_p), None),
                     "swm_set_msm_sharding")
         self._shard_cb = cb  # keep the trampoline alive as long as the library may call it
+
+    def rccl_init(self, unique_id, rank, world):
+        """swm_rccl_init: the library's own RCCL communicator for this context (one process per GPU); the sharded
+        prover then exchanges its partial sums with one ncclAllGather per round."""
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.swm_rccl_init(self.h, buf, rank, world), "swm_rccl_init")
+
+    def exchange_stats(self):
+        calls, nbytes = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.lib.swm_exchange_stats(self.h, ctypes.byref(calls), ctypes.byref(nbytes)), "swm_exchange_stats")
+        return calls.value, nbytes.value
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -2,6 +2,7 @@
 // Host-side plumbing only: argument checks, staging of host buffers into HBM, status codes.  The kernels live in
 // msm.hip / ntt.hip / vec.hip.  Nothing here falls back to a CPU implementation: without a usable gfx950 device
 // swm_init fails with SWM_ERR_NO_DEVICE and every compute entry point needs a context.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
@@ -9,6 +10,10 @@
 #include "context.h"
 #include "g1.cuh"
 #include "msm.h"
+
+struct swm_rccl_id_arg {  // ncclUniqueId, passed by value to ncclCommInitRank
+    char internal[128];
+};
 
 namespace swm {
 
@@ -40,6 +45,7 @@ void drain_streams(swm_ctx* ctx) {
     for (int i = 0; i < swm_ctx::MSM_LANES; i++)
         if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
     for (int i = 0; i < swm_ctx::MSM_SLOTS; i++) ctx->slot_busy[i] = false;
+    ctx->pending_tails.clear();
 }
 
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -130,6 +136,74 @@ void prof_flush(swm_ctx* ctx) {
 }
 }  // namespace swm
 
+// ------------------------------------------------------------------------------------------------ RCCL (resolved at run time)
+namespace {
+struct RcclApi {
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, swm_rccl_id_arg, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        // prefer the RCCL already mapped into the process (e.g. the one torch.distributed uses): a communicator must be
+        // driven by the library that created it
+        void* h = dlsym(RTLD_DEFAULT, "ncclAllGather") ? RTLD_DEFAULT : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+        a.CommInitRank = (int (*)(void**, int, swm_rccl_id_arg, int))dlsym(h, "ncclCommInitRank");
+        a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+        a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
+        return a;
+    }();
+    return api;
+}
+int rccl_fail(swm_ctx* ctx, const char* what, int rc) {
+    return swm::set_err(ctx, SWM_ERR_INTERNAL, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+namespace swm {
+int shard_exchange(swm_ctx* ctx, const void* send, size_t bytes, void* recv) {
+    ctx->stat_exchanges++;
+    ctx->stat_exchange_bytes += bytes;
+    if (ctx->rccl_comm) {
+        const size_t need = bytes * ctx->shard_world;
+        if (ctx->rccl_cap < need) {
+            if (ctx->rccl_send) (void)hipFree(ctx->rccl_send);
+            if (ctx->rccl_recv) (void)hipFree(ctx->rccl_recv);
+            ctx->rccl_send = ctx->rccl_recv = nullptr;
+            ctx->rccl_cap = 0;
+            SWM_HIP(ctx, hipMalloc(&ctx->rccl_send, need));
+            SWM_HIP(ctx, hipMalloc(&ctx->rccl_recv, need));
+            ctx->rccl_cap = need;
+        }
+        SWM_HIP(ctx, hipMemcpyAsync(ctx->rccl_send, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = rccl().AllGather(ctx->rccl_send, ctx->rccl_recv, bytes, /*ncclUint8*/ 1, ctx->rccl_comm, ctx->stream);
+        if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+        SWM_HIP(ctx, hipMemcpyAsync(recv, ctx->rccl_recv, need, hipMemcpyDeviceToHost, ctx->stream));
+        SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SWM_OK;
+    }
+    if (!ctx->shard_allgather) return set_err(ctx, SWM_ERR_INTERNAL, "msm sharding: no exchange configured");
+    if (ctx->shard_allgather(ctx->shard_user, send, bytes, recv) != 0)
+        return set_err(ctx, SWM_ERR_INTERNAL, "msm sharding: the all-gather callback failed");
+    return SWM_OK;
+}
+}  // namespace swm
+
+static void rccl_release(swm_ctx* ctx) {
+    if (ctx->rccl_comm && ctx->rccl_own && rccl().ok) (void)rccl().CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+    ctx->rccl_own = false;
+}
+
 using namespace swm;
 
 extern "C" {
@@ -194,6 +268,11 @@ void swm_destroy(swm_ctx* ctx) {
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     for (auto e : ctx->slot_event)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : ctx->acc_event)
+        if (e) (void)hipEventDestroy(e);
+    rccl_release(ctx);
+    if (ctx->rccl_send) (void)hipFree(ctx->rccl_send);
+    if (ctx->rccl_recv) (void)hipFree(ctx->rccl_recv);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx->host_pool;
@@ -204,6 +283,7 @@ const char* swm_last_error(swm_ctx* ctx) { return ctx ? ctx->err : tls_err; }
 
 int swm_set_msm_sharding(swm_ctx* ctx, unsigned rank, unsigned world, swm_allgather_fn allgather, void* user) {
     if (!ctx) return SWM_ERR_INVALID_ARG;
+    rccl_release(ctx);
     if (world <= 1 || !allgather) {
         ctx->shard_rank = 0;
         ctx->shard_world = 1;
@@ -216,6 +296,55 @@ int swm_set_msm_sharding(swm_ctx* ctx, unsigned rank, unsigned world, swm_allgat
     ctx->shard_world = world;
     ctx->shard_allgather = allgather;
     ctx->shard_user = user;
+    return SWM_OK;
+}
+
+int swm_rccl_unique_id(uint8_t out[128]) {
+    if (!out) return SWM_ERR_INVALID_ARG;
+    if (!rccl().ok) return set_err(nullptr, SWM_ERR_INTERNAL, "RCCL is not available in this process (librccl.so.1 not found)");
+    int rc = rccl().GetUniqueId(out);
+    return rc == 0 ? SWM_OK : rccl_fail(nullptr, "ncclGetUniqueId", rc);
+}
+int swm_rccl_init(swm_ctx* ctx, const uint8_t id[128], unsigned rank, unsigned world) {
+    if (!ctx || !id || world == 0 || rank >= world) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
+    if (!rccl().ok) return set_err(ctx, SWM_ERR_INTERNAL, "RCCL is not available in this process (librccl.so.1 not found)");
+    rccl_release(ctx);
+    swm_rccl_id_arg arg;
+    memcpy(arg.internal, id, 128);
+    void* comm = nullptr;
+    int rc = rccl().CommInitRank(&comm, (int)world, arg, (int)rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    ctx->rccl_comm = comm;
+    ctx->rccl_own = true;
+    ctx->shard_rank = rank;
+    ctx->shard_world = world;
+    ctx->shard_allgather = nullptr;
+    ctx->shard_user = nullptr;
+    return SWM_OK;
+}
+int swm_set_rccl_comm(swm_ctx* ctx, void* nccl_comm, unsigned rank, unsigned world) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    rccl_release(ctx);
+    if (!nccl_comm) {  // back to a single GPU
+        ctx->shard_rank = 0;
+        ctx->shard_world = 1;
+        return SWM_OK;
+    }
+    if (world == 0 || rank >= world) return SWM_ERR_INVALID_ARG;
+    if (!rccl().ok) return set_err(ctx, SWM_ERR_INTERNAL, "RCCL is not available in this process (librccl.so.1 not found)");
+    ctx->rccl_comm = nccl_comm;
+    ctx->rccl_own = false;
+    ctx->shard_rank = rank;
+    ctx->shard_world = world;
+    ctx->shard_allgather = nullptr;
+    ctx->shard_user = nullptr;
+    return SWM_OK;
+}
+int swm_exchange_stats(swm_ctx* ctx, uint64_t* calls, uint64_t* bytes_per_rank) {
+    if (!ctx) return SWM_ERR_INVALID_ARG;
+    if (calls) *calls = ctx->stat_exchanges;
+    if (bytes_per_rank) *bytes_per_rank = ctx->stat_exchange_bytes;
     return SWM_OK;
 }
 

@@ -12,6 +12,7 @@
 
 namespace swm {
 
+struct MsmJob;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -53,6 +54,8 @@ struct swm_ctx {
     void* pinned = nullptr;
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
     bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
+    hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (deferred bucket stages)
+    std::vector<swm::MsmJob*> pending_tails;      // jobs whose bucket stage waits for msm_flush_tails
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
@@ -77,6 +80,14 @@ struct swm_ctx {
     unsigned shard_rank = 0, shard_world = 1;
     swm_allgather_fn shard_allgather = nullptr;
     void* shard_user = nullptr;
+    // the same exchange through RCCL inside the library (swm_rccl_init / swm_set_rccl_comm): ncclAllGather on the context's
+    // stream between device staging buffers; librccl is resolved at run time (the copy already loaded in the process, else
+    // librccl.so.1), so the library carries no link-time dependency on it
+    void* rccl_comm = nullptr;
+    bool rccl_own = false;
+    void *rccl_send = nullptr, *rccl_recv = nullptr;
+    size_t rccl_cap = 0;
+    uint64_t stat_exchanges = 0, stat_exchange_bytes = 0;  // all-gathers issued / bytes contributed per rank
     swm::HostPool* host_pool = nullptr;  // created on first use (msm_finish), joined in swm_destroy
 };
 
@@ -93,6 +104,8 @@ int set_err(swm_ctx* ctx, int code, const char* fmt, ...);
 // Waits for everything enqueued on the context's stream and on its auxiliary MSM streams, and forgets the jobs that
 // were in flight.  Error paths call it before buffers that queued kernels may still read go back to the pool.
 void drain_streams(swm_ctx* ctx);
+// all-gather of `bytes` bytes per rank over the exchange configured on the context (RCCL communicator or caller's callback)
+int shard_exchange(swm_ctx* ctx, const void* send, size_t bytes, void* recv);
 
 // Every extern "C" entry point that takes a context runs on that context's GPU, whatever device the calling thread had
 // current (another context, torch, a thread that never called hipSetDevice); the caller's device is restored on exit.

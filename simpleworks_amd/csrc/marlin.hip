@@ -373,28 +373,65 @@ G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeff
 struct AsyncMsm {
     MsmJob job;
     bool sharded = false;
+    bool have_result = false;  // set by commit_gather (the exchange of a whole round) before commit_wait is reached
+    G1XYZZ result;
 };
 void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
     const G1Affine *b = nullptr, *b28 = nullptr;
     if (n) pk.bases_at(offset, n, &b, &b28);
     static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
     size_t lo = 0, hi = n;
-    out->sharded = ctx->shard_world > 1;
+    out->have_result = false;
+    const bool force_exchange = getenv("SWM_SHARD_FORCE") != nullptr;  // test hook: exchange with a world of one
+    out->sharded = ctx->shard_world > 1 || (force_exchange && (ctx->rccl_comm || ctx->shard_allgather));
     if (out->sharded) {
         lo = (size_t)(((unsigned __int128)n * ctx->shard_rank) / ctx->shard_world);
         hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
     }
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job));
+    // Small MSMs defer their bucket stage to the end of the round, where the stages of all its commitments run as one
+    // launch (one chain latency instead of four; measured r02: 2^12 proofs 10.3 -> 9.8 ms).  Above ~2^15 points a single
+    // bucket stage already fills the chip with one 96-KB workgroup per CU, so a joint launch only queues them behind
+    // one another and gives up the overlap with the next commitment's accumulation (2^16: 16.5 -> 20.3 ms, 2^20: 85.6 ->
+    // 89.6 ms): those keep their own tail.
+    static const long batch_below = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : 32768;
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
+                              (long)(hi - lo) <= batch_below));
+}
+// every commitment of a round is enqueued: run their bucket stages together
+void commit_flush(swm_ctx* ctx) { rc_check(ctx, msm_flush_tails(ctx)); }
+// Sum of the per-rank partial sums in rank order: the same group element on every rank.
+static G1XYZZ fold_ranks(const G1XYZZ* all, unsigned world) {
+    G1XYZZ r = all[0];
+    for (unsigned g = 1; g < world; g++) g1_add(r, all[g]);
+    return r;
+}
+// All commitments of a round at once (sharded proving only): wait for every job, then ONE all-gather of k partial sums
+// per rank (k x 192 bytes) instead of one exchange per commitment; commit_wait then finds the folded results.
+void commit_gather(swm_ctx* ctx, std::initializer_list<AsyncMsm*> jobs) {
+    std::vector<AsyncMsm*> sh;
+    for (AsyncMsm* a : jobs)
+        if (a && a->sharded && !a->have_result) sh.push_back(a);
+    if (sh.empty()) return;
+    const unsigned world = ctx->shard_world;
+    const size_t k = sh.size();
+    std::vector<G1XYZZ> mine(k), all(k * world);
+    for (size_t i = 0; i < k; i++) rc_check(ctx, msm_finish(ctx, &sh[i]->job, &mine[i]));
+    rc_check(ctx, shard_exchange(ctx, mine.data(), k * sizeof(G1XYZZ), all.data()));
+    for (size_t i = 0; i < k; i++) {
+        std::vector<G1XYZZ> col(world);
+        for (unsigned g = 0; g < world; g++) col[g] = all[(size_t)g * k + i];
+        sh[i]->result = fold_ranks(col.data(), world);
+        sh[i]->have_result = true;
+    }
 }
 G1XYZZ commit_wait(swm_ctx* ctx, AsyncMsm* a) {
+    if (a->have_result) return a->result;
     G1XYZZ r;
     rc_check(ctx, msm_finish(ctx, &a->job, &r));
     if (a->sharded) {
         std::vector<G1XYZZ> all(ctx->shard_world);
-        int rc = ctx->shard_allgather(ctx->shard_user, &r, sizeof(G1XYZZ), all.data());
-        if (rc != 0) throw MarlinError(SWM_ERR_INTERNAL, "msm sharding: the all-gather callback failed");
-        r = all[0];
-        for (unsigned g = 1; g < ctx->shard_world; g++) g1_add(r, all[g]);
+        rc_check(ctx, shard_exchange(ctx, &r, sizeof(G1XYZZ), all.data()));
+        r = fold_ranks(all.data(), ctx->shard_world);
     }
     return r;
 }
@@ -737,6 +774,8 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
         const DVec* polys[4] = {&pk->ar[i].row, &pk->ar[i].col, &pk->ar[i].val, &pk->ar[i].row_col};
         AsyncMsm jobs[4];
         for (int j = 0; j < 4; j++) commit_enqueue(ctx, &lane, *pk, 0, polys[j]->p, pk->K, &jobs[j]);
+        commit_flush(ctx);
+        commit_gather(ctx, {&jobs[0], &jobs[1], &jobs[2], &jobs[3]});
         for (int j = 0; j < 4; j++) {
             Commitment c;
             c.comm = g1_to_affine(commit_wait(ctx, &jobs[j]));
@@ -901,6 +940,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     std::vector<Commitment> comms1(4);
     P_mask.p = mask.p; P_mask.n = mask_len;
     pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    commit_flush(ctx);  // the four bucket stages of round 1 in one launch
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
@@ -925,6 +965,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
         e_z = on_mul_domain(z_poly.p, H + 1);
     }
+    commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
     comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
     comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
     comms1[2] = pc_commit_end(ctx, pk, &j1[2], &zk, &P_zb.rand);
@@ -1008,9 +1049,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
         pc_commit_begin(ctx, pk, &lane, P_h1.p, P_h1.n, false, 0, false, &j2[2]);  // largest first
         pc_commit_begin(ctx, pk, &lane, P_g1.p, P_g1.n, true, H - 2, true, &j2[1]);
+        commit_flush(ctx);
         // the sumcheck remainder check needs a download; do it while the MSMs run
         Fr rem0 = g1x.download(0, 1)[0];
         bool unsat = !fp_is_zero(rem0);
+        commit_gather(ctx, {&j2[0].plain, &j2[1].plain, &j2[1].shifted, &j2[2].plain});
         comms2[0] = pc_commit_end(ctx, pk, &j2[0], nullptr, &P_t.rand);
         comms2[1] = pc_commit_end(ctx, pk, &j2[1], &zk, &P_g1.rand);
         comms2[2] = pc_commit_end(ctx, pk, &j2[2], nullptr, &P_h1.rand);
@@ -1084,6 +1127,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     std::vector<Commitment> comms3(2);
     P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
     pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j3[1]);
+    commit_flush(ctx);
     // ================= evaluations, part 1: everything asked at beta depends on rounds 1-2 only, so it is enqueued here
     // and runs under the round-3 commitments
     std::map<std::string, LPoly*> polys;
@@ -1113,6 +1157,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             LPoly* lp = polys.at(want[i].first);
             poly_eval_async(ctx, lp->p, lp->n, ep_beta, slots.p + i);
         }
+        commit_gather(ctx, {&j3[0].plain, &j3[0].shifted, &j3[1].plain});
         comms3[0] = pc_commit_end(ctx, pk, &j3[0], nullptr, &P_g2.rand);
         comms3[1] = pc_commit_end(ctx, pk, &j3[1], nullptr, &P_h2.rand);
         tr.mark("round 3 commitments");
@@ -1254,6 +1299,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             commit_enqueue(ctx, &lane, pk, pk.srs_max_degree - stt.lp->bound, q + 1, qn, &o.sjobs[i]);
         }
     }
+    commit_flush(ctx);  // both opening points: up to four bucket stages, one launch
+    commit_gather(ctx, {&po[0].wjob, po[0].sjobs.empty() ? nullptr : &po[0].sjobs[0], &po[1].wjob,
+                        po[1].sjobs.empty() ? nullptr : &po[1].sjobs[0]});
     for (int pi = 0; pi < 2; pi++) {
         PointOpen& o = po[pi];
         G1XYZZ w = commit_wait(ctx, &o.wjob);

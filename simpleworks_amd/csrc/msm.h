@@ -24,6 +24,12 @@ struct MsmJob {
     WinLayout pl;
     unsigned red_blocks = 0, log_m = 0;
     int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
+    // deferred bucket stage (msm_flush_tails): what it reads / writes, the stream the job ran on and its "partials ready" event
+    bool tail_pending = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t acc_done = nullptr;
+    G1XYZZ *d_partial = nullptr, *d_wpart = nullptr;
+    const uint32_t *d_seg_off = nullptr, *d_status = nullptr, *d_entries = nullptr;
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
     const uint32_t* host_flags = nullptr;  // tail of the slot: [0] != 0 when a scalar was not a canonical field element
     hipEvent_t done = nullptr;
@@ -39,8 +45,12 @@ struct MsmInfMask {
     const uint32_t* mask = nullptr;  // bit (first + i) belongs to point i of this MSM
     size_t first = 0;
 };
+// defer_tail: stop after the bucket folds and leave the bucket stage (the latency-bound tail) to msm_flush_tails, which
+// runs the tails of every job enqueued so far in one launch.  The MsmJob must stay at its address until msm_finish.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask());
+                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false);
+int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k);
+int msm_flush_tails(swm_ctx* ctx);
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
             G1XYZZ* result, MsmInfMask inf = MsmInfMask());

@@ -654,9 +654,29 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
 //     slot[dst] <- slot[dst] + *src          (dst: an LDS slot; src: an LDS slot or a partial sum in HBM)
 // issued from ONE loop around ONE copy of the adder; the phases only differ in how (dst, src, active) are chosen.
 // LDS: two packed slots per lane (running sum, weighted sum) + one for R = 96 KB per workgroup.
-__global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __restrict__ partial,
-                                                               const uint32_t* __restrict__ seg_off, WinLayout L,
-                                                               unsigned log_m, G1XYZZ* __restrict__ out) {
+//
+// Batch form: the bucket stages of up to TAIL_MAX MSMs (the commitments of one prover round) run as ONE launch,
+// blockIdx.z = job.  The stage is a ~25-deep chain of ~20 us group operations whatever the number of buckets, so the
+// jobs of a round share one chain latency instead of paying it one after the other.
+static constexpr int TAIL_MAX = 4;
+struct TailJob {
+    const G1XYZZ* partial;
+    const uint32_t* seg_off;
+    G1XYZZ* out;
+    unsigned log_m, red_blocks;
+    WinLayout L;
+};
+struct TailBatch {
+    TailJob j[TAIL_MAX];
+};
+__global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) {
+    const TailJob& job = batch.j[blockIdx.z];
+    if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
+    const G1XYZZ* __restrict__ partial = job.partial;
+    const uint32_t* __restrict__ seg_off = job.seg_off;
+    const WinLayout& L = job.L;
+    const unsigned log_m = job.log_m;
+    G1XYZZ* __restrict__ out = job.out;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
     G1XYZZ* sm_acc = sm_run + RED_BLOCK;
@@ -746,7 +766,7 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(const G1XYZZ* __r
         __syncthreads();
     }
     if (t == 0) {
-        size_t o = ((size_t)w * gridDim.x + blockIdx.x) * 2;
+        size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
         p28_store_384(out[o], p28_load(sm_acc[0]));
         p28_store_384(out[o + 1], p28_load(sm_r[0]));
     }
@@ -801,8 +821,9 @@ int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* 
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf) {
+                int mont, MsmJob* job, MsmInfMask inf, bool defer_tail) {
     job->active = false;
+    job->tail_pending = false;
     job->n = n;
     if (n == 0) return SWM_OK;
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
@@ -814,7 +835,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stat_msm_digits += total;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
     // buckets per lane in the reduction: at most 16 workgroups per window (the host folds one (A, R) pair per workgroup)
-    unsigned log_m = pl.maxB <= 2048 ? 0 : 2;  // small windows: one bucket per lane shortens the serial walk (r01 sweep)
+    // small windows: one bucket per lane shortens the serial walk of a lone MSM (r01 sweep); inside a round's batch the
+    // workgroups of all jobs have to be resident together (one per CU: 96 KB of LDS each), which four buckets per lane allow
+    unsigned log_m = pl.maxB <= 2048 ? (defer_tail ? 2 : 0) : 2;
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > 16) log_m++;  // 16 (A, R) pairs per window fit a result slot
     unsigned red_blocks = ((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK;
@@ -843,6 +866,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->host = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned + slot_bytes * slot);
     job->host_flags = reinterpret_cast<const uint32_t*>((char*)job->host + flags_off);
     job->done = ctx->slot_event[slot];
+    if (!ctx->acc_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->acc_event[slot], hipEventDisableTiming));
+    job->acc_done = ctx->acc_event[slot];
+    job->stream = st;
     job->pl = pl;
     job->red_blocks = red_blocks;
     job->log_m = log_m;
@@ -857,7 +883,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stream = st;
     char nm[10][32];
     const char* base[10] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points", "pairs"};
-    for (int i = 0; i < 10; i++) snprintf(nm[i], sizeof(nm[i]), "msm%d.%s", lane < 0 ? 9 : lane, base[i]);
+    // what the deferred bucket stage of a job still reads (histogram block with the status words, bucket / segment offsets,
+    // big-bucket list, partial sums) is kept per result SLOT; the rest is per lane (stream-ordered reuse)
+    for (int i = 0; i < 10; i++) {
+        const bool per_slot = i == 0 || i == 2 || i == 3 || i == 7 || i == 8;
+        snprintf(nm[i], sizeof(nm[i]), per_slot ? "msmS%d.%s" : "msm%d.%s", per_slot ? slot : (lane < 0 ? 9 : lane), base[i]);
+    }
 
     // Segment bound.  Long segments mean one partial sum per bucket (the bucket stage walks fewer partials) but fewer,
     // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
@@ -968,22 +999,78 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
-    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
-    SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(red_blocks, pl.nwin), dim3(RED_BLOCK),
-               (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), partial, seg_off, pl, log_m, wpart);
-    SWM_HIP(ctx, hipMemcpyAsync(job->host, wpart, (size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    SWM_HIP(ctx, hipMemcpyAsync((void*)job->host_flags, big_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SWM_HIP(ctx, hipMemcpyAsync((void*)(job->host_flags + 1), bucket_off + pl.NB, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SWM_HIP(ctx, hipEventRecord(job->done, ctx->stream));
+    job->d_partial = partial;
+    job->d_wpart = wpart;
+    job->d_seg_off = seg_off;
+    job->d_status = big_count + 1;
+    job->d_entries = bucket_off + pl.NB;
     job->active = true;
+    job->tail_pending = true;
     ctx->slot_busy[slot] = true;
+    if (defer_tail) {  // the bucket stage runs with the other jobs of the round (msm_flush_tails)
+        SWM_HIP(ctx, hipEventRecord(job->acc_done, ctx->stream));
+        ctx->pending_tails.push_back(job);
+        return SWM_OK;
+    }
+    MsmJob* one[1] = {job};
+    return msm_launch_tails(ctx, one, 1);
+}
+
+// One bucket-stage launch + the downloads for k <= TAIL_MAX jobs, on the stream of the last one.
+int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
+    if (k <= 0) return SWM_OK;
+    hipStream_t st = jobs[k - 1]->stream;
+    struct StreamSwap {
+        swm_ctx* c;
+        hipStream_t old;
+        ~StreamSwap() { c->stream = old; }
+    } swap{ctx, ctx->stream};
+    ctx->stream = st;
+    TailBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    unsigned max_red = 1, max_win = 1;
+    for (int i = 0; i < k; i++) {
+        MsmJob* j = jobs[i];
+        if (j->stream != st) SWM_HIP(ctx, hipStreamWaitEvent(st, j->acc_done, 0));
+        batch.j[i].partial = j->d_partial;
+        batch.j[i].seg_off = j->d_seg_off;
+        batch.j[i].out = j->d_wpart;
+        batch.j[i].log_m = j->log_m;
+        batch.j[i].red_blocks = j->red_blocks;
+        batch.j[i].L = j->pl;
+        max_red = std::max(max_red, j->red_blocks);
+        max_win = std::max(max_win, j->pl.nwin);
+    }
+    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+    SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
+               (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+    for (int i = 0; i < k; i++) {
+        MsmJob* j = jobs[i];
+        SWM_HIP(ctx, hipMemcpyAsync(j->host, j->d_wpart, (size_t)j->pl.nwin * j->red_blocks * 2 * sizeof(G1XYZZ),
+                                    hipMemcpyDeviceToHost, st));
+        SWM_HIP(ctx, hipMemcpyAsync((void*)j->host_flags, j->d_status, 4, hipMemcpyDeviceToHost, st));
+        SWM_HIP(ctx, hipMemcpyAsync((void*)(j->host_flags + 1), j->d_entries, 4, hipMemcpyDeviceToHost, st));
+    }
+    for (int i = 0; i < k; i++) {
+        SWM_HIP(ctx, hipEventRecord(jobs[i]->done, st));
+        jobs[i]->tail_pending = false;
+    }
+    return SWM_OK;
+}
+
+// Launches the deferred bucket stages (all jobs enqueued with defer_tail since the last flush), TAIL_MAX per launch.
+int msm_flush_tails(swm_ctx* ctx) {
+    std::vector<MsmJob*> jobs;
+    jobs.swap(ctx->pending_tails);
+    for (size_t i = 0; i < jobs.size(); i += TAIL_MAX)
+        SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)std::min<size_t>(TAIL_MAX, jobs.size() - i)));
     return SWM_OK;
 }
 
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     *result = g1_xyzz_identity();
     if (!job->active) return SWM_OK;
+    if (job->tail_pending) SWM_TRY(msm_flush_tails(ctx));  // awaited before its round was flushed
     SWM_HIP(ctx, hipEventSynchronize(job->done));
     job->active = false;
     ctx->slot_busy[job->slot] = false;
@@ -1044,7 +1131,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
             G1XYZZ* result, MsmInfMask inf) {
     MsmJob job;
-    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job, inf));
+    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job, inf, false));
     return msm_finish(ctx, &job, result);
 }
 

@@ -81,18 +81,45 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
         }
     }
     __syncthreads();
-    // ---- r radix-2 DIF levels in LDS (natural in, bit-reversed rows out)
-    for (unsigned h = R >> 1; h >= 1; h >>= 1) {
-        unsigned tw_step = (R >> 1) / h;  // w_{2h}^pos = w_R^(pos * R/(2h))
+    // ---- r radix-2 DIF levels in LDS (natural in, bit-reversed rows out), TWO levels per LDS round trip: a lane takes
+    // the four elements of a radix-4 group (i0, i0 + h/2, i0 + h, i0 + 3h/2), runs the level-h butterflies and then the
+    // level-h/2 butterflies on them in registers (same four multiplications as two radix-2 levels — in a prime field the
+    // fourth root of unity is not free — but half the LDS traffic and half the barriers).  An odd r starts with one
+    // plain radix-2 level.
+    unsigned h = R >> 1;
+    if (a.log_r & 1) {
         for (unsigned bq = threadIdx.x; bq < (R >> 1) * J; bq += NTT_THREADS) {
-            unsigned jj = bq % J, q = bq / J;
-            unsigned pos = q & (h - 1), blk = q / h;
-            unsigned i0 = blk * 2 * h + pos, i1 = i0 + h;
+            unsigned jj = bq % J, pos = bq / J;  // h = R/2: one block, pos = q
+            unsigned i0 = pos, i1 = i0 + h;
             Fr u = tile[i0 * J + jj], v = tile[i1 * J + jj];
             tile[i0 * J + jj] = fp_add(u, v);
             Fr d = fp_sub(u, v);
-            if (pos) d = fp_mul(d, a.tw_small[pos * tw_step]);
+            if (pos) d = fp_mul(d, a.tw_small[pos]);
             tile[i1 * J + jj] = d;
+        }
+        h >>= 1;
+        __syncthreads();
+    }
+    for (; h >= 2; h >>= 2) {
+        const unsigned hh = h >> 1, s1 = (R >> 1) / h, s2 = 2 * s1;
+        for (unsigned q = threadIdx.x; q < (R >> 2) * J; q += NTT_THREADS) {
+            unsigned jj = q % J, qq = q / J;
+            unsigned p = qq & (hh - 1), blk = qq / hh;
+            unsigned i0 = blk * 2 * h + p, i1 = i0 + hh, i2 = i0 + h, i3 = i2 + hh;
+            Fr x0 = tile[i0 * J + jj], x1 = tile[i1 * J + jj], x2 = tile[i2 * J + jj], x3 = tile[i3 * J + jj];
+            Fr a0 = fp_add(x0, x2), a2 = fp_sub(x0, x2);
+            if (p) a2 = fp_mul(a2, a.tw_small[p * s1]);
+            Fr a1 = fp_add(x1, x3), a3 = fp_mul(fp_sub(x1, x3), a.tw_small[(p + hh) * s1]);
+            Fr y1 = fp_sub(a0, a1), y3 = fp_sub(a2, a3);
+            if (p) {
+                Fr w = a.tw_small[p * s2];
+                y1 = fp_mul(y1, w);
+                y3 = fp_mul(y3, w);
+            }
+            tile[i0 * J + jj] = fp_add(a0, a1);
+            tile[i1 * J + jj] = y1;
+            tile[i2 * J + jj] = fp_add(a2, a3);
+            tile[i3 * J + jj] = y3;
         }
         __syncthreads();
     }
@@ -223,21 +250,24 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
             rem -= r;
         }
     }
-    Fr* tmp = nullptr;
+    Fr *tmp = nullptr, *tmp2 = nullptr;
     SWM_TRY(scratch(ctx, "ntt.tmp", n * sizeof(Fr), (void**)&tmp));
-    // ping-pong so that the last pass lands in `data`
-    Fr* bufs[2] = {data, tmp};
-    int cur = 0;
-    if (npass % 2 == 1 && npass > 0) {
-        // odd number of passes: first pass data -> tmp would end in tmp; copy data to tmp first and start there
+    // The last pass has to land in `data`.  Even pass counts ping-pong data <-> tmp; an odd count of three or more goes
+    // data -> tmp -> tmp2 -> ... -> data through a second scratch buffer (one more n-element buffer in HBM instead of a
+    // full device-to-device copy in front of every such transform); a single pass (n <= 2^10) copies, it is tiny.
+    if (npass % 2 == 1 && npass >= 3) SWM_TRY(scratch(ctx, "ntt.tmp2", n * sizeof(Fr), (void**)&tmp2));
+    const Fr* src = data;
+    if (npass == 1) {
         SWM_HIP(ctx, hipMemcpyAsync(tmp, data, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-        cur = 1;
+        src = tmp;
     }
     unsigned log_ns = 0;
     for (unsigned p = 0; p < npass; p++) {
         NttPassArgs a;
-        a.src = bufs[cur];
-        a.dst = bufs[cur ^ 1];
+        a.src = src;
+        if (p == npass - 1) a.dst = data;
+        else if (tmp2) a.dst = (p % 2 == 0) ? tmp : tmp2;
+        else a.dst = (src == tmp) ? data : tmp;
         a.log_n = log_n;
         a.log_r = radices[p];
         a.log_ns = log_ns;
@@ -271,7 +301,7 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
             }
         }
         log_ns += a.log_r;
-        cur ^= 1;
+        src = a.dst;
     }
     return SWM_OK;
 }

@@ -243,13 +243,15 @@ def test_ntt_golden(ctx, orc):
         assert orc.fr_ints_from_mont(y) == [h2i(v) for v in c["out"]], c["name"]
 
 
-@pytest.mark.parametrize("log_n", [9, 10, 12, 15, 16, 17, 18, 20])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_ntt_vs_oracle(ctx, orc, log_n):
+    """Every pass plan up to the BASELINE sizes (one, two and three passes; odd and even radices; with and without the
+    second scratch buffer), forward / inverse x plain / coset, bit-exact against the C oracle (all host threads)."""
     from pyref.prng import fr_array
     x = orc.fr_to_mont(fr_array(1 << log_n, 300 + log_n))
     for inverse in (0, 1):
         for coset in (0, 1):
-            ref = orc.ntt(x, log_n, inverse, coset, threads=8)
+            ref = orc.ntt(x, log_n, inverse, coset, threads=orc.lib.oracle_max_threads())
             assert np.array_equal(ctx.ntt_fr(x, log_n, inverse, coset), ref), (log_n, inverse, coset)
 
 
@@ -263,6 +265,20 @@ def test_ntt_roundtrip_2_22(ctx, orc):
     assert not np.array_equal(x, y)
     ctx.ntt_fr_dev(d, log_n, True, True)
     assert np.array_equal(d.download(x.shape), x)
+    d.free()
+
+
+def test_ntt_roundtrip_2_25(ctx, orc):
+    """SURVEY.md §8d's largest size: 2^25 elements (1 GiB), forward then inverse is the identity, coset variant too."""
+    from pyref.prng import fr_array
+    x = np.ascontiguousarray(np.tile(fr_array(1 << 20, 325), (32, 1)))
+    x[:, 0] ^= np.arange(x.shape[0], dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 60) - 1)
+    d = ctx.to_device(x)
+    for coset in (False, True):
+        ctx.ntt_fr_dev(d, 25, False, coset)
+        ctx.ntt_fr_dev(d, 25, True, coset)
+        assert np.array_equal(d.download(x.shape), x)
     d.free()
 
 

@@ -479,3 +479,100 @@ def test_universal_srs_export_import(M, W):
     assert M.generate_proof(cs, pk, M.rng_from_seed(seed)).data == M.generate_proof(cs, pk2, M.rng_from_seed(seed)).data
     for o in (pk, pk2, srs, srs2):
         o.free()
+
+
+def test_rccl_exchange_inside_the_library(M, S, W):
+    """swm_rccl_unique_id / swm_rccl_init: the library's own RCCL communicator carries the sharded prover's exchange
+    (one ncclAllGather per round on the context's stream).  One GPU here, so the communicator has one rank and
+    SWM_SHARD_FORCE keeps the exchange path active: the bytes must still be the golden ones, and a proof makes
+    exactly four exchanges (rounds 1-3 and the openings), the indexer three (one per matrix)."""
+    import os
+    import simpleworks_amd as swm
+    from simpleworks_amd._lib import rccl_unique_id
+    case = golden("marlin.json")["random_sparse"]
+    ctx = swm.Context(0)
+    ctx.rccl_init(rccl_unique_id(), 0, 1)
+    os.environ["SWM_SHARD_FORCE"] = "1"
+    try:
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+        cs = W.random_sparse_circuit(**case["circuit"])
+        c0, b0 = ctx.exchange_stats()
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        c1, b1 = ctx.exchange_stats()
+        assert (c1 - c0, b1 - b0) == (3, 12 * 192)
+        proof = M.generate_proof(cs, pk, rng)
+        c2, b2 = ctx.exchange_stats()
+        assert c2 - c1 == 4 and b2 - b1 == 15 * 192  # 4 + 4 + 3 + 4 partial sums
+        assert S.serialize_verifying_key(vk).hex() == case["vk"]
+        assert S.serialize_proof(proof).hex() == case["proof"]
+        pk.free()
+        srs.free()
+    finally:
+        del os.environ["SWM_SHARD_FORCE"]
+        ctx.close()
+
+
+_TWO_PROC_WORKER = r"""
+import json, os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import torch.distributed as dist
+import simpleworks_amd as swm
+from simpleworks_amd import marlin as M, serialization as S, workloads as W
+from simpleworks_amd.dist import enable_sharded_prover
+from oracle_lib import golden, h2i
+dist.init_process_group("gloo")
+ctx = swm.Context(0)              # both ranks share GPU 0: real kernels, real point-range shards
+enable_sharded_prover(ctx)
+ok = True
+for name in ("synthetic_32", "random_sparse"):
+    case = golden("marlin.json")[name]
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+    cs = (W.random_sparse_circuit(**case["circuit"]) if name.startswith("random_")
+          else W.synthetic_circuit(case["num_constraints"], h2i(case["a"]), h2i(case["b"])))
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    proof = M.generate_proof(cs, pk, rng)
+    ok = ok and S.serialize_verifying_key(vk).hex() == case["vk"] and S.serialize_proof(proof).hex() == case["proof"]
+n = 1 << 14
+rng = M.generate_rand()
+srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
+cs, public = W.synthetic_r1cs(n, 11, 13)
+pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+proof = M.generate_proof(cs, pk, M.rng_from_seed(bytes(range(32))))
+ok = ok and M.verify_proof(vk, public, proof, M.generate_rand())
+calls, nbytes = ctx.exchange_stats()
+print(json.dumps({"rank": dist.get_rank(), "ok": bool(ok), "proof": proof.data.hex(), "exchanges": calls}))
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_prover_two_processes_real_kernels(tmp_path):
+    """Two PROCESSES (gloo rendezvous on 127.0.0.1, both on GPU 0) prove through the real kernels with their commitment
+    MSMs split by point range: golden bytes on the small cases, identical and valid proofs at 2^14."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_PROC_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-2000:]
+        outs.append(json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1]))
+    assert all(o["ok"] for o in outs)
+    assert outs[0]["proof"] == outs[1]["proof"]
+    assert outs[0]["exchanges"] == outs[1]["exchanges"] > 0
