@@ -278,6 +278,60 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # N > 1, workload prove: besides the replicas figure (value), ONE proof over all ranks through the library's own RCCL
+    # exchange (swm_rccl_init; point-range sharded commitment MSMs, one ncclAllGather per prover round) is measured and
+    # reported as the `sharded` sub-object.  Runs in a watchdog thread: a stuck collective must not cost the headline line.
+    sharded_info = None
+    if use_dist and args.workload == "prove" and not os.environ.get("SWM_BENCH_NO_SHARDED"):
+        import hashlib
+        import threading
+        box = {}
+
+        def run_sharded():
+            try:
+                from simpleworks_amd._lib import rccl_unique_id
+                idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
+                dist.broadcast(idt, 0)
+                ctx.rccl_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                rng_s = M.generate_rand()
+                if args.circuit == "merkle":
+                    scs = W.merkle_membership_circuit(leaf_u8=0xA7)[0].pack()
+                    srs_s = M.generate_universal_srs(scs.num_constraints, scs.instance.shape[0] + scs.witness.shape[0],
+                                                     max(int(m[0][-1]) for m in scs.mats), rng_s)
+                else:
+                    srs_s = M.generate_universal_srs(n, n, n, rng_s)
+                    scs, _ = W.synthetic_r1cs(n, 0x1234567, 0x7654321)  # the SAME system on every rank
+                pk_s, vk_s = M.generate_proving_and_verifying_keys(srs_s, scs)
+                srs_s.free()
+                M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
+                c0, b0 = ctx.exchange_stats()
+                reps = 3
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    pr = M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
+                sync()
+                dts = time.perf_counter() - t0
+                c1, b1 = ctx.exchange_stats()
+                h = torch.frombuffer(bytearray(hashlib.sha256(pr.data).digest()), dtype=torch.uint8).to(coll_dev)
+                hs = [torch.empty_like(h) for _ in range(world)]
+                dist.all_gather(hs, h)
+                tt2 = torch.tensor([dts], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+                box["res"] = {"ms_per_proof": float(tt2.item()) / reps * 1e3, "constraints_per_s": n * reps / float(tt2.item()),
+                              "ranks": world, "exchange": "ncclAllGather inside libswmarlin (swm_rccl_init), one per prover round",
+                              "exchanges_per_proof": (c1 - c0) / reps, "bytes_per_rank_per_proof": (b1 - b0) / reps,
+                              "proof_bytes_identical_on_all_ranks": all(bool((x == hs[0]).all()) for x in hs)}
+                pk_s.free()
+            except Exception as e:  # noqa: BLE001
+                box["res"] = {"error": repr(e)}
+        th = threading.Thread(target=run_sharded, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240")))
+        sharded_info = box.get("res", {"error": "timed out"})
+
     if rank == 0:
         dom = prof[dominant]
         launches_per_step = dom["calls"] / args.steps
@@ -343,6 +397,7 @@ def main():
                          "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
                          "issue_ceiling_mixed_adds_per_s": 8.2e9},
             "roofline_secondary": secondary,
+            "sharded": sharded_info,
             "work_per_step": {k: v / args.steps for k, v in work.items()},
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }
@@ -363,6 +418,8 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:
+        if sharded_info is not None and "error" in sharded_info:
+            os._exit(0)  # a watchdog-abandoned collective may never return: leave without the orderly teardown
         dist.destroy_process_group()
 
 

@@ -8,11 +8,15 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python3 bench.py > $out/bench_prove.json 2> $out/bench_prove.err
+python3 bench.py --steps 10 --warmup 2 > $out/bench_prove.json 2> $out/bench_prove.err
+python3 bench.py --circuit merkle --steps 10 --warmup 2 > $out/bench_merkle.json 2> $out/bench_merkle.err
 python3 bench.py --workload msm --steps 12 --warmup 2 > $out/bench_msm.json 2> $out/bench_msm.err
 python3 bench.py --workload msm --log-n 22 --steps 8 --warmup 2 --cpu-log-n 18 > $out/bench_msm_2p22.json 2> $out/bench_msm22.err
 rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/prof_prove.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/prof_merkle -o run --output-format csv -- python3 bench.py --circuit merkle --steps 5 --warmup 1 --no-cpu-baseline > $out/prof_merkle.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/prof_msm -o run --output-format csv -- python3 bench.py --workload msm --steps 12 --warmup 2 --no-cpu-baseline > $out/prof_msm.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_fetch -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_write -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+python3 tools/ubench/ntt_time.py > $out/ntt_time.log 2>&1
+python3 tools/small_proofs.py 12 14 16 18 > $out/small_proofs.log 2>&1
 ls -R $out | head -40
