@@ -194,20 +194,27 @@ def ser_g1(P):
 
 
 def deser_g1(b):
+    """CanonicalDeserialize::deserialize for G1Affine (ark-ec 0.3, the CHECKED form): flags 0xC0 invalid, x a field
+    element, on the curve, in the prime-order subgroup."""
     b = bytearray(b)
     flags = b[47] & 0xC0
     b[47] &= 0x3F
-    if flags & 0x40:
-        return None
+    if flags == 0xC0:
+        raise MarlinError("invalid G1 flags")
     x = int.from_bytes(b, "little")
     if x >= Q:
         raise MarlinError("invalid G1 encoding")
+    if flags & 0x40:
+        return None
     y = bls.fq_sqrt((x * x * x + 1) % Q)
     if y is None:
         raise MarlinError("G1 x not on curve")
     neg = (Q - y) % Q
     big, small = (y, neg) if y > neg else (neg, y)
-    return (x, big if flags & 0x80 else small)
+    P = (x, big if flags & 0x80 else small)
+    if bls.g1_mul_fast(P, R) is not None:
+        raise MarlinError("G1 point not in the prime-order subgroup")
+    return P
 
 
 def ser_g2(P):

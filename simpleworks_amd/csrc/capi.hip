@@ -46,14 +46,17 @@ void drain_streams(swm_ctx* ctx) {
         if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
     for (int i = 0; i < swm_ctx::MSM_SLOTS; i++) ctx->slot_busy[i] = false;
     ctx->pending_tails.clear();
+    ctx->set_acc_event[0] = ctx->set_acc_event[1] = nullptr;
 }
 
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
     DevBuf& b = ctx->scratch[name];
     if (b.cap < bytes) {
         if (b.p) {
-            // in-flight kernels may still read the old buffer
+            // in-flight kernels — on this stream or on one of the MSM stage streams — may still read the old buffer
             SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < swm_ctx::MSM_LANES; i++)
+                if (ctx->aux_stream[i]) SWM_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[i]));
             SWM_HIP(ctx, hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -64,6 +67,14 @@ int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
     }
     *out = b.p;
     return SWM_OK;
+}
+
+void scratch_release(swm_ctx* ctx, const char* name) {
+    auto it = ctx->scratch.find(name);
+    if (it == ctx->scratch.end()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (it->second.p) (void)hipFree(it->second.p);
+    ctx->scratch.erase(it);
 }
 
 int pool_alloc(swm_ctx* ctx, size_t bytes, void** out, size_t* cap) {
@@ -270,6 +281,8 @@ void swm_destroy(swm_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->acc_event)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : ctx->sort_event)
+        if (e) (void)hipEventDestroy(e);
     rccl_release(ctx);
     if (ctx->rccl_send) (void)hipFree(ctx->rccl_send);
     if (ctx->rccl_recv) (void)hipFree(ctx->rccl_recv);
@@ -402,7 +415,8 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
     }
     e = hipMemcpyAsync(b->d_points, xy, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&b->d_points28, n * sizeof(G1Affine));
+    b->table_c = msm_table_width(n);
+    if (e == hipSuccess && !b->table_c) e = hipMalloc(&b->d_points28, n * sizeof(G1Affine));
     if (e != hipSuccess) {
         (void)hipFree(b->d_points);
         delete b;
@@ -415,6 +429,12 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
     if (hipMalloc((void**)&b->d_inf_mask, mask_words * 4) != hipSuccess ||
         hipMemsetAsync(b->d_inf_mask, 0, mask_words * 4, ctx->stream) != hipSuccess)
         rc = set_err(ctx, SWM_ERR_OOM, "srs_upload: infinity mask");
+    if (rc == SWM_OK && b->table_c) {  // large resident sets get the window-multiple tables (row 0 = the scaled copy)
+        G1Affine* tab = nullptr;
+        rc = msm_table_build(ctx, (const G1Affine*)b->d_points, n, b->table_c, &tab);
+        b->d_points28 = tab;
+    }
+    // (with a table the scaled copy exists already; the call below then only fills the infinity mask)
     if (rc == SWM_OK) rc = msm_scale_bases_run(ctx, (const G1Affine*)b->d_points, n, (G1Affine*)b->d_points28, b->d_inf_mask);
     std::vector<uint32_t> hmask(mask_words);
     if (rc == SWM_OK && (hipMemcpyAsync(hmask.data(), b->d_inf_mask, mask_words * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -462,7 +482,9 @@ int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const vo
     G1XYZZ r;
     SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset,
                     reinterpret_cast<const G1Affine*>(bases->d_points28) + offset, d_scalars, n, scalars_montgomery, &r,
-                    MsmInfMask{bases->d_inf_mask, offset}));
+                    MsmInfMask{bases->d_inf_mask, offset},
+                    bases->table_c ? MsmTable{reinterpret_cast<const G1Affine*>(bases->d_points28), bases->n, bases->table_c, offset}
+                                   : MsmTable()));
     write_jac(r, out_jac);
     return SWM_OK;
 }

@@ -54,7 +54,9 @@ struct swm_ctx {
     void* pinned = nullptr;
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
     bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
-    hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (deferred bucket stages)
+    hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (stage A -> stage T, deferred bucket stages)
+    hipEvent_t sort_event[MSM_SLOTS] = {nullptr};  // "sorted" per slot (stage S -> stage A)
+    hipEvent_t set_acc_event[2] = {nullptr, nullptr};  // accumulation that last read each per-lane scratch set (not owned)
     std::vector<swm::MsmJob*> pending_tails;      // jobs whose bucket stage waits for msm_flush_tails
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
@@ -95,6 +97,7 @@ struct swm_bases {
     void* d_points = nullptr;    // n x G1Affine (96 B, Montgomery radix 2^384)
     void* d_points28 = nullptr;  // same points, coordinates x 2^8 (radix 2^392) for the MSM inner loop
     uint32_t* d_inf_mask = nullptr;  // n bits, allocated only when some base is the point at infinity
+    unsigned table_c = 0;            // != 0: d_points28 is the table of window multiples (msm_table_build), row 0 = the scaled copy
     size_t n = 0;
 };
 
@@ -129,6 +132,7 @@ struct DeviceGuard {
     if (!dev_guard__.ok) return swm::set_err(ctx, SWM_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
 // returns device pointer of a scratch buffer with at least `bytes` capacity (contents undefined)
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out);
+void scratch_release(swm_ctx* ctx, const char* name);  // frees a named scratch buffer (one-off builders)
 // pooled device allocations for the prover's polynomial temporaries
 int pool_alloc(swm_ctx* ctx, size_t bytes, void** out, size_t* cap);
 void pool_free(swm_ctx* ctx, void* p, size_t cap);

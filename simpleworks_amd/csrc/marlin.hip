@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <memory>
 #include "devops.cuh"
 #include "g1.cuh"
@@ -76,7 +77,7 @@ struct GammaTable {
 struct swm_pk {
     ~swm_pk() {  // also runs when index_impl / pk_deserialize unwind with a half-built key
         if (d_powers) (void)hipFree(d_powers);
-        if (d_powers28) (void)hipFree(d_powers28);
+        if (d_powers28) (void)hipFree(d_powers28);   // the whole table when tab_c != 0
         if (d_shifted) (void)hipFree(d_shifted);
         if (d_shifted28) (void)hipFree(d_shifted28);
     }
@@ -95,14 +96,20 @@ struct swm_pk {
     G1Affine* d_shifted28 = nullptr;
     size_t n_powers = 0, n_shifted = 0, shift_base = 0;
     size_t srs_max_degree = 0;
+    // precomputed window multiples of both ranges (msm_table_build; width 0: none, the key is small).  Row 0 of a table IS
+    // the scaled copy, so d_powers28 / d_shifted28 then point into the tables.
+    unsigned tab_c = 0, shtab_c = 0;
     // bases for an MSM of n points starting at SRS power `offset`
-    void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28) const {
+    void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28, MsmTable* tab) const {
+        *tab = MsmTable();
         if (offset + n <= n_powers) {
             *b = d_powers + offset;
             *b28 = d_powers28 + offset;
+            if (tab_c) *tab = MsmTable{d_powers28, n_powers, tab_c, offset};
         } else if (offset >= shift_base && offset + n <= shift_base + n_shifted) {
             *b = d_shifted + (offset - shift_base);
             *b28 = d_shifted28 + (offset - shift_base);
+            if (shtab_c) *tab = MsmTable{d_shifted28, n_shifted, shtab_c, offset - shift_base};
         } else {
             throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
         }
@@ -362,9 +369,10 @@ uint64_t ahp_max_degree(uint64_t num_constraints, uint64_t num_variables, uint64
 G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n) {
     if (n == 0) return g1_xyzz_identity();
     const G1Affine *b, *b28;
-    pk.bases_at(offset, n, &b, &b28);
+    MsmTable tab;
+    pk.bases_at(offset, n, &b, &b28, &tab);
     G1XYZZ r;
-    rc_check(ctx, msm_run(ctx, b, b28, coeffs, n, 1, &r));
+    rc_check(ctx, msm_run(ctx, b, b28, coeffs, n, 1, &r, MsmInfMask(), tab));
     return r;
 }
 // asynchronous form: alternates between the two MSM lanes of the context
@@ -378,7 +386,8 @@ struct AsyncMsm {
 };
 void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
     const G1Affine *b = nullptr, *b28 = nullptr;
-    if (n) pk.bases_at(offset, n, &b, &b28);
+    MsmTable tab;
+    if (n) pk.bases_at(offset, n, &b, &b28, &tab);
     static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
     size_t lo = 0, hi = n;
     out->have_result = false;
@@ -394,8 +403,9 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // one another and gives up the overlap with the next commitment's accumulation (2^16: 16.5 -> 20.3 ms, 2^20: 85.6 ->
     // 89.6 ms): those keep their own tail.
     static const long batch_below = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : 32768;
+    tab.offset += lo;
     rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
-                              (long)(hi - lo) <= batch_below));
+                              (long)(hi - lo) <= batch_below, tab));
 }
 // every commitment of a round is enqueued: run their bucket stages together
 void commit_flush(swm_ctx* ctx) { rc_check(ctx, msm_flush_tails(ctx)); }
@@ -710,13 +720,24 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     pk.n_shifted = n_shifted;
     pk.shift_base = pk.srs_max_degree + 1 - n_shifted;
     hip_check(ctx, hipMalloc((void**)&pk.d_powers, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers)");
-    hip_check(ctx, hipMalloc((void**)&pk.d_powers28, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers28)");
     hip_check(ctx, hipMalloc((void**)&pk.d_shifted, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted)");
-    hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted28)");
     hip_check(ctx, hipMemcpyAsync(pk.d_powers, powers, n_powers * sizeof(G1Affine), kind, ctx->stream), "copy powers");
     if (n_shifted) hip_check(ctx, hipMemcpyAsync(pk.d_shifted, shifted, n_shifted * sizeof(G1Affine), kind, ctx->stream), "copy shifted");
-    rc_check(ctx, msm_scale_bases_run(ctx, pk.d_powers, n_powers, pk.d_powers28));
-    rc_check(ctx, msm_scale_bases_run(ctx, pk.d_shifted, n_shifted, pk.d_shifted28));
+    // scaled twins, or — for keys large enough to profit — the tables of window multiples whose first row they are
+    pk.tab_c = msm_table_width(n_powers);
+    pk.shtab_c = n_shifted ? msm_table_width(n_shifted) : 0;
+    if (pk.tab_c) {
+        rc_check(ctx, msm_table_build(ctx, pk.d_powers, n_powers, pk.tab_c, &pk.d_powers28));
+    } else {
+        hip_check(ctx, hipMalloc((void**)&pk.d_powers28, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers28)");
+        rc_check(ctx, msm_scale_bases_run(ctx, pk.d_powers, n_powers, pk.d_powers28));
+    }
+    if (pk.shtab_c) {
+        rc_check(ctx, msm_table_build(ctx, pk.d_shifted, n_shifted, pk.shtab_c, &pk.d_shifted28));
+    } else {
+        hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted28)");
+        rc_check(ctx, msm_scale_bases_run(ctx, pk.d_shifted, n_shifted, pk.d_shifted28));
+    }
     hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
 }
 
@@ -904,9 +925,31 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const size_t w_len = H + 1 - X;
     LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
     int lane = 0;
+    // Every commitment MSM is enqueued as soon as its polynomial exists.  SWM_COMMIT_LATE=1 (experiment, r02): enqueue the
+    // commitments of a round together once ALL its polynomials are built.  The idea: an accumulation in flight holds every
+    // SIMD's register file (3 waves x 168 VGPRs) for ~1.5 ms per wave, so transforms issued beside it wait for retiring
+    // waves and run 3-5x slower than alone (25 ms of ntt_pass event time per 2^20 proof against 5 ms stand-alone).
+    // Measured: no gain (2^20: 77.6 vs 76.1 ms early, 2^18: 33.3 vs 32.2) — the early MSMs cover more than the slowed
+    // transforms cost.
+    static const bool commit_early = getenv("SWM_COMMIT_LATE") == nullptr;
+    std::vector<std::function<void()>> late;
+    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job) {
+        if (commit_early) {
+            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
+        } else {
+            late.push_back([&, coeffs, n, has_bound, bound, hiding, job] {
+                pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
+            });
+        }
+    };
+    auto flush_commits = [&] {
+        for (auto& f : late) f();
+        late.clear();
+        commit_flush(ctx);
+    };
     CommitJob j1[4];
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
-    pc_commit_begin(ctx, pk, &lane, P_w.p, P_w.n, false, 0, true, &j1[0]);
+    begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0]);
     Fr rho_a = zk.rand_fr();
     DVec za_poly = dv_zeros(ctx, H + 1);
     {
@@ -915,7 +958,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         add_rho_vh(za_poly.p, rho_a);
     }
     P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
-    pc_commit_begin(ctx, pk, &lane, P_za.p, P_za.n, false, 0, true, &j1[1]);
+    begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
     Fr rho_b = zk.rand_fr();
     DVec zb_poly = dv_zeros(ctx, H + 1);
     {
@@ -924,7 +967,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         add_rho_vh(zb_poly.p, rho_b);
     }
     P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
-    pc_commit_begin(ctx, pk, &lane, P_zb.p, P_zb.n, false, 0, true, &j1[2]);
+    begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
     // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
     const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
     DVec mask(ctx, mask_len);
@@ -939,8 +982,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
     P_mask.p = mask.p; P_mask.n = mask_len;
-    pc_commit_begin(ctx, pk, &lane, P_mask.p, P_mask.n, false, 0, false, &j1[3]);
-    commit_flush(ctx);  // the four bucket stages of round 1 in one launch
+    begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
@@ -1007,7 +1050,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     CommitJob j2[3];
     P_t.p = t_poly.p; P_t.n = H;
-    pc_commit_begin(ctx, pk, &lane, P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
+    begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
     DVec q1(ctx, M);
     {
         DVec ra_poly = dv_copy_padded(ctx, r_alpha_evals.p, H, H);
@@ -1047,9 +1090,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     {
         P_g1.p = g1x.p + 1; P_g1.n = H - 1; P_g1.has_bound = true; P_g1.bound = H - 2; P_g1.hiding = true;
         P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
-        pc_commit_begin(ctx, pk, &lane, P_h1.p, P_h1.n, false, 0, false, &j2[2]);  // largest first
-        pc_commit_begin(ctx, pk, &lane, P_g1.p, P_g1.n, true, H - 2, true, &j2[1]);
-        commit_flush(ctx);
+        begin_commit(P_h1.p, P_h1.n, false, 0, false, &j2[2]);  // largest first
+        begin_commit(P_g1.p, P_g1.n, true, H - 2, true, &j2[1]);
+        flush_commits();
         // the sumcheck remainder check needs a download; do it while the MSMs run
         Fr rem0 = g1x.download(0, 1)[0];
         bool unsat = !fp_is_zero(rem0);
@@ -1090,7 +1133,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     CommitJob j3[2];
     P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
-    pc_commit_begin(ctx, pk, &lane, P_g2.p, P_g2.n, true, K - 2, false, &j3[0]);  // overlaps the 4|K|-domain work below
+    begin_commit(P_g2.p, P_g2.n, true, K - 2, false, &j3[0]);  // overlaps the 4|K|-domain work below
     // h_2 = (a - b f) / v_K via evaluations on the 4K domain
     DVec h2(ctx, 3 * K);
     {
@@ -1126,8 +1169,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     tr.mark("round 3 polynomials");
     std::vector<Commitment> comms3(2);
     P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
-    pc_commit_begin(ctx, pk, &lane, P_h2.p, P_h2.n, false, 0, false, &j3[1]);
-    commit_flush(ctx);
+    begin_commit(P_h2.p, P_h2.n, false, 0, false, &j3[1]);
+    flush_commits();
     // ================= evaluations, part 1: everything asked at beta depends on rounds 1-2 only, so it is enqueued here
     // and runs under the round-3 commitments
     std::map<std::string, LPoly*> polys;

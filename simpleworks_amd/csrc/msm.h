@@ -18,6 +18,23 @@ struct WinLayout {
     uint32_t boff[MAX_WIN + 1];
 };
 
+// Precomputed window multiples of a resident base set (msm_table_build): row w holds 2^(w c) P_i for every point of the
+// set, coordinates in the scaled form of the accumulation kernel.  `offset` is the index (within the set) of the first
+// point of the MSM at hand.
+struct MsmTable {
+    const G1Affine* t28 = nullptr;  // [windows][stride]
+    size_t stride = 0;
+    unsigned c = 0;
+    size_t offset = 0;
+};
+unsigned msm_table_windows(unsigned c);
+WinLayout msm_table_layout(unsigned c);
+// window width for the table of a base set of n points (0: no table, the set is too small to profit)
+unsigned msm_table_width(size_t n_bases);
+// builds the table of d_points[0 .. n) (affine, radix 2^384) for width c into *out (hipMalloc'd, windows * n points);
+// row 0 is the plain scaled copy of the set (what msm_scale_bases_run produces)
+int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c, G1Affine** out);
+
 struct MsmJob {
     bool active = false;
     size_t n = 0;
@@ -26,6 +43,7 @@ struct MsmJob {
     int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
     // deferred bucket stage (msm_flush_tails): what it reads / writes, the stream the job ran on and its "partials ready" event
     bool tail_pending = false;
+    bool needs_acc_wait = false;
     hipStream_t stream = nullptr;
     hipEvent_t acc_done = nullptr;
     G1XYZZ *d_partial = nullptr, *d_wpart = nullptr;
@@ -48,11 +66,11 @@ struct MsmInfMask {
 // defer_tail: stop after the bucket folds and leave the bucket stage (the latency-bound tail) to msm_flush_tails, which
 // runs the tails of every job enqueued so far in one launch.  The MsmJob must stay at its address until msm_finish.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false);
+                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false, MsmTable tab = MsmTable());
 int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k);
 int msm_flush_tails(swm_ctx* ctx);
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
-            G1XYZZ* result, MsmInfMask inf = MsmInfMask());
+            G1XYZZ* result, MsmInfMask inf = MsmInfMask(), MsmTable tab = MsmTable());
 
 }  // namespace swm

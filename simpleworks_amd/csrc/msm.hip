@@ -32,6 +32,7 @@
 #include "g1.cuh"
 #include "msm.h"
 #include <atomic>
+#include <chrono>
 
 namespace swm {
 
@@ -74,6 +75,35 @@ WinLayout msm_plan(size_t n) {
     }
     L.boff[L.nwin] = L.NB;
     return L;
+}
+
+unsigned msm_table_windows(unsigned c) { return (254 + c - 1) / c; }
+// Windows of the flat schedule for a table of width c: ceil(254 / c) windows whose widths differ by at most one (as in
+// msm_plan: a short top window would put a quarter of all points into two buckets), the widest being c bits; all of them
+// index ONE set of 2^(c-1) buckets.  c[0] is always the widest window.
+WinLayout msm_table_layout(unsigned c) {
+    WinLayout L;
+    memset(&L, 0, sizeof(L));
+    L.nwin = msm_table_windows(c);
+    const unsigned base = 254 / L.nwin, extra = 254 % L.nwin;
+    unsigned bit = 0;
+    for (unsigned w = 0; w < L.nwin; w++) {
+        const unsigned cw = base + (w < extra ? 1 : 0);
+        L.c[w] = (uint8_t)cw;
+        L.bit[w] = (uint16_t)bit;
+        L.boff[w] = 0;
+        bit += cw;
+    }
+    L.NB = L.maxB = 1u << (L.c[0] - 1);
+    L.boff[L.nwin] = L.NB;
+    return L;
+}
+unsigned msm_table_width(size_t n_bases) {
+    if (const char* e = getenv("SWM_MSM_TABLE_C")) return (unsigned)std::min(22, std::max(12, atoi(e)));
+    if (n_bases < (1u << 17)) return 0;  // small base sets keep the per-window schedule
+    unsigned lg = 0;
+    while (((size_t)2 << lg) <= n_bases) lg++;
+    return std::min(20u, std::max(17u, lg));
 }
 
 // ---------------------------------------------------------------------------------------------- digits
@@ -314,6 +344,231 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort(const uint2* __restr
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage32[i];
+}
+
+
+// ---------------------------------------------------------------------------------------------- precomputed-window ("flat") schedule
+// For a RESIDENT base set the multiples 2^(bit_w) P_i of every point are precomputed once (msm_table_build: W copies
+// of the set, 96 B x n x W in HBM — what 288 GB are for).  A digit of window w then selects table row w instead of a
+// bucket set of its own: ALL windows share ONE set of 2^(c-1) buckets, so
+//   * the window width is no longer capped by "buckets per window x windows" (the bucket stage runs once): c = 20 gives
+//     13 windows instead of 16, i.e. 19 % fewer mixed additions in msm_accumulate for the same result;
+//   * there is no Horner chain over the windows at the end (the shifts are in the table).
+// The counting sort over 2^19 buckets cannot histogram in LDS in one go; it is two-level from the start:
+//   msm_flat_coarse_hist / msm_flat_scan_bins  entries per COARSE bin (bucket >> fb, <= 4096 bins) — LDS histogram per tile,
+//   msm_flat_partition                         entries grouped by bin in LDS and written out in runs (as msm_partition),
+//   msm_flat_bin_sort                          one workgroup per bin: fine counts (they ARE the bucket histogram the
+//                                              scans below consume), placement in LDS, coalesced copy-out; a bin that
+//                                              does not fit LDS (structured scalars) is placed directly in HBM.
+static constexpr uint32_t FLAT_MAX_BINS = 4096;
+static constexpr uint32_t FLAT_MAX_FINE = 2048;  // buckets per bin at most (2^fb): fine counts + offsets (16 KB) next to the 128-KB stage
+static constexpr uint32_t FLAT_BIN_CAP = 32768;  // entries a bin may hold to be placed in LDS (128 KB)
+__global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t total, unsigned fb,
+                                                                     uint32_t nbins, uint32_t tile, uint32_t* __restrict__ bin_count) {
+    __shared__ uint32_t lh[FLAT_MAX_BINS];
+    for (uint32_t b = threadIdx.x; b < nbins; b += SORT_THREADS) lh[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)blockIdx.x * tile, hi = min(lo + (size_t)tile, total);
+    for (size_t i = lo + threadIdx.x; i < hi; i += 4 * SORT_THREADS) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? digits[i + u * SORT_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u]) atomicAdd(&lh[((c[u] - 1) >> 1) >> fb], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += SORT_THREADS) {
+        uint32_t v = lh[b];
+        if (v) atomicAdd(&bin_count[b], v);
+    }
+}
+// exclusive scan of <= 4096 bin counts by one workgroup: bin_off[0 .. nbins]
+__global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins,
+                                                           uint32_t* __restrict__ bin_off) {
+    __shared__ uint32_t sm[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        v[u] = 4 * t + u < nbins ? bin_count[4 * t + u] : 0u;
+        s += v[u];
+    }
+    sm[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = t >= d ? sm[t - d] : 0u;
+        __syncthreads();
+        sm[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = sm[t] - s;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (4 * t + u < nbins) bin_off[4 * t + u] = run;
+        run += v[u];
+    }
+    if (t == 1023) bin_off[nbins] = sm[1023];
+}
+// (entry, bucket) pairs grouped by coarse bin; grid (tiles over the points, windows).  entry = table row of the point:
+// w * tstride + toff + i, with the sign of the digit in bit 31.
+__global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
+                                                           uint32_t toff, unsigned fb, uint32_t nbins,
+                                                           const uint32_t* __restrict__ bin_off, uint32_t* __restrict__ bin_cursor,
+                                                           uint2* __restrict__ tmp) {
+    __shared__ uint32_t cnt[FLAT_MAX_BINS], start[FLAT_MAX_BINS], gpos[FLAT_MAX_BINS], scan[1024];
+    extern __shared__ uint2 stage[];  // PART_TILE pairs
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * PART_TILE;
+    for (uint32_t b = t; b < nbins; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)w * n;
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        size_t i = lo + t + (size_t)u * 1024;
+        c[u] = i < n ? d[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        if (c[u]) atomicAdd(&cnt[((c[u] - 1) >> 1) >> fb], 1u);
+    __syncthreads();
+    // exclusive scan of cnt over <= 4096 bins: four bins per lane
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        v[u] = 4 * t + u < nbins ? cnt[4 * t + u] : 0u;
+        sum += v[u];
+    }
+    scan[t] = sum;
+    __syncthreads();
+    for (uint32_t dd = 1; dd < 1024; dd <<= 1) {
+        uint32_t x = t >= dd ? scan[t - dd] : 0u;
+        __syncthreads();
+        scan[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = scan[t] - sum;
+    const uint32_t total = scan[1023];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t b = 4 * t + u;
+        if (b < nbins) {
+            start[b] = run;
+            cnt[b] = run;  // running cursor of the bin inside the staged tile
+            gpos[b] = v[u] ? bin_off[b] + atomicAdd(&bin_cursor[b], v[u]) : 0u;
+        }
+        run += v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        if (c[u]) {
+            const uint32_t bucket = (c[u] - 1) >> 1;
+            const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
+            const uint32_t row = w * tstride + toff + (uint32_t)(lo + t + (size_t)u * 1024);
+            stage[p] = make_uint2(row | (((c[u] - 1) & 1u) << 31), bucket);
+        }
+    __syncthreads();
+    for (uint32_t i = t; i < total; i += 1024) {
+        uint2 e = stage[i];
+        uint32_t b = e.y >> fb;
+        tmp[gpos[b] + (i - start[b])] = e;
+    }
+}
+// one workgroup per bin: bucket histogram of the bin (written out: hist[first bucket + f]), then placement by bucket
+__global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
+                                                                 const uint32_t* __restrict__ bin_off,
+                                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t stage32[];  // fc[nf] | fo[nf] | FLAT_BIN_CAP entries
+    uint32_t* fc = stage32;
+    uint32_t* fo = fc + (1u << fb);
+    uint32_t* stage = fo + (1u << fb);
+    const uint32_t bin = blockIdx.x, nf = 1u << fb, first = bin << fb, fmask = nf - 1;
+    const uint32_t lo = bin_off[bin], cnt = bin_off[bin + 1] - lo;
+    for (uint32_t f = threadIdx.x; f < nf; f += BIN_THREADS) fc[f] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
+    __syncthreads();
+    {   // exclusive prefix of the fine counts (nf <= 2048): chunk per lane, then a scan over the 1024 lane totals
+        __shared__ uint32_t lt[BIN_THREADS];
+        const uint32_t per = (nf + BIN_THREADS - 1) / BIN_THREADS, f0 = threadIdx.x * per, f1 = min(f0 + per, nf);
+        uint32_t sum = 0;
+        for (uint32_t f = f0; f < f1; f++) sum += fc[f];
+        lt[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < BIN_THREADS; d <<= 1) {
+            uint32_t x = threadIdx.x >= d ? lt[threadIdx.x - d] : 0u;
+            __syncthreads();
+            lt[threadIdx.x] += x;
+            __syncthreads();
+        }
+        uint32_t run = lt[threadIdx.x] - sum;
+        for (uint32_t f = f0; f < f1; f++) {
+            fo[f] = run;
+            run += fc[f];
+        }
+    }
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < nf; f += BIN_THREADS)
+        if (first + f < NB) hist[first + f] = fc[f];
+    __syncthreads();
+    if (cnt <= FLAT_BIN_CAP) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += 4 * BIN_THREADS) {
+            uint2 e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + u * BIN_THREADS < cnt) stage[atomicAdd(&fo[e[u].y & fmask], 1u)] = e[u].x;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage[i];
+    } else {  // oversized bin (many equal digits): scattered 4-byte stores, correct for any size
+        for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) {
+            uint2 e = tmp[lo + i];
+            sorted[lo + atomicAdd(&fo[e.y & fmask], 1u)] = e.x;
+        }
+    }
+}
+
+// ---- table construction: out[i] = 2^k in[i] as XYZZ (k doublings), then batch normalisation back to affine
+__global__ void __launch_bounds__(256) msm_table_shift(const G1Affine* __restrict__ in, size_t n, unsigned k, G1XYZZ* __restrict__ out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = in[i];
+    G1XYZZ acc = g1_is_inf(p) ? g1_xyzz_identity() : g1_dbl_affine(p);
+    for (unsigned j = 1; j < k; j++) acc = g1_dbl(acc);
+    out[i] = acc;
+}
+static constexpr int TAB_NORM_CHUNK = 16;
+__global__ void __launch_bounds__(256) msm_table_normalize(const G1XYZZ* __restrict__ in, size_t n, Fq* __restrict__ pref,
+                                                           G1Affine* __restrict__ out) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t lo = t * TAB_NORM_CHUNK;
+    if (lo >= n) return;
+    size_t hi = lo + TAB_NORM_CHUNK < n ? lo + TAB_NORM_CHUNK : n;
+    Fq acc = fp_one<Fq>();
+    for (size_t i = lo; i < hi; i++) {
+        pref[i] = acc;
+        if (!fp_is_zero(in[i].zz)) acc = fp_mul(acc, fp_mul(in[i].zz, in[i].zzz));
+    }
+    Fq inv = fp_inv(acc);
+    for (size_t i = hi; i-- > lo;) {
+        G1XYZZ p = in[i];
+        G1Affine a;
+        if (fp_is_zero(p.zz)) {
+            a.x = fp_zero<Fq>();
+            a.y = fp_zero<Fq>();
+        } else {
+            Fq zi = fp_mul(inv, pref[i]);
+            inv = fp_mul(inv, fp_mul(p.zz, p.zzz));
+            a.x = fp_mul(p.x, fp_mul(zi, p.zzz));
+            a.y = fp_mul(p.y, fp_mul(zi, p.zz));
+        }
+        out[i] = a;
+    }
 }
 
 __device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
@@ -584,7 +839,18 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
     G1XYZZ acc32 = g1_xyzz_identity();
     for (uint32_t k = k0; k < e; k++) {
         uint32_t ent = sorted[k];
-        G1Affine p = bases[ent & 0x7fffffffu];
+        G1Affine p;
+        if (bases) {
+            p = bases[ent & 0x7fffffffu];
+        } else {  // table rows exist only in the scaled form: x 2^-8 (a Montgomery product with the integer 2^376)
+            p = bases28[ent & 0x7fffffffu];
+            Fq d256 = fp_zero<Fq>();
+            d256.v[11] = 0x01000000u;
+            if (!g1_is_inf(p)) {
+                p.x = fp_mul(p.x, d256);
+                p.y = fp_mul(p.y, d256);
+            }
+        }
         if (ent >> 31) p.y = fp_neg(p.y);
         g1_add_mixed(acc32, p);
     }
@@ -604,6 +870,8 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
 // (112 VGPRs) live; a third live point spills to scratch, i.e. to HBM-backed private memory with nothing to hide the
 // latency at one wave per SIMD (measured: 5x slower).  So each lane parks the point it is not currently adding in LDS
 // (packed 192-B slots) and at most two points are ever in registers.
+// (the unfenced multiplier with a 512-register budget — amdgpu_waves_per_eu(1, 1) — was measured in r02: the bucket stage
+// takes the same 0.85 ms either way)
 __device__ __forceinline__ void p28_add_ool(P28& a, const P28& q) { p28_add<MulFenced>(a, q); }
 
 // Oversized buckets (> BIG_NSEG segments: structured scalars) are folded first, one workgroup each: strided partial
@@ -776,7 +1044,7 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
 // Kernels that want more than 64 KB of dynamic LDS need the attribute raised once per device; `slot` names the kernel
 // (0 hist, 1 scatter, 2 bucket_reduce, 3 partition, 4 bin_sort) in a small process-wide cache so that the runtime call is not repeated per MSM.
 static int allow_big_lds(swm_ctx* ctx, int slot, const void* fn, size_t bytes) {
-    static std::atomic<size_t> granted[64][5];
+    static std::atomic<size_t> granted[64][8];
     if (bytes <= 64 * 1024) return SWM_OK;
     const int dev = ctx->device & 63;
     if (granted[dev][slot].load(std::memory_order_acquire) >= bytes) return SWM_OK;
@@ -812,6 +1080,46 @@ int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* 
     return SWM_OK;
 }
 
+int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c, G1Affine** out) {
+    *out = nullptr;
+    if (n == 0 || c < 2) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm table: bad arguments");
+    const WinLayout L = msm_table_layout(c);
+    const unsigned W = L.nwin;
+    G1Affine* tab = nullptr;
+    hipError_t e = hipMalloc((void**)&tab, (size_t)W * n * sizeof(G1Affine));
+    if (e != hipSuccess) return set_err(ctx, SWM_ERR_OOM, "msm table (%u windows x %zu points): %s", W, n, hipGetErrorString(e));
+    G1XYZZ* x = nullptr;
+    Fq* pref = nullptr;
+    G1Affine* cur = nullptr;  // 2^(w c) P in the plain form, input of the next shift
+    int rc = SWM_OK;
+    do {
+        if ((rc = scratch(ctx, "tab.xyzz", n * sizeof(G1XYZZ), (void**)&x)) != SWM_OK) break;
+        if ((rc = scratch(ctx, "tab.pref", n * sizeof(Fq), (void**)&pref)) != SWM_OK) break;
+        if ((rc = scratch(ctx, "tab.cur", n * sizeof(G1Affine), (void**)&cur)) != SWM_OK) break;
+        if ((rc = msm_scale_bases_run(ctx, d_points, n, tab)) != SWM_OK) break;
+        const G1Affine* src = d_points;
+        const unsigned grid = (unsigned)((n + 255) / 256), gridn = (unsigned)(((n + TAB_NORM_CHUNK - 1) / TAB_NORM_CHUNK + 255) / 256);
+        for (unsigned w = 1; w < W && rc == SWM_OK; w++) {
+            hipLaunchKernelGGL(msm_table_shift, dim3(grid), dim3(256), 0, ctx->stream, src, n, (unsigned)L.c[w - 1], x);
+            hipLaunchKernelGGL(msm_table_normalize, dim3(gridn), dim3(256), 0, ctx->stream, (const G1XYZZ*)x, n, pref, cur);
+            if (hipGetLastError() != hipSuccess) rc = set_err(ctx, SWM_ERR_HIP, "msm table: launch failed");
+            if (rc == SWM_OK) rc = msm_scale_bases_run(ctx, cur, n, tab + (size_t)w * n);
+            src = cur;
+        }
+        if (rc == SWM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, SWM_ERR_HIP, "msm table: sync failed");
+    } while (0);
+    scratch_release(ctx, "tab.xyzz");
+    scratch_release(ctx, "tab.pref");
+    scratch_release(ctx, "tab.cur");
+    if (rc != SWM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tab);
+        return rc;
+    }
+    *out = tab;
+    return SWM_OK;
+}
+
 // ---- asynchronous form -------------------------------------------------------------------------------------
 // msm_enqueue launches every kernel of one MSM plus the download of its window sums WITHOUT host synchronisation;
 // msm_finish waits for that download and does the host Horner fold.  `lane` selects the stream + device scratch set:
@@ -821,7 +1129,7 @@ int msm_scale_bases_run(swm_ctx* ctx, const G1Affine* d_in, size_t n, G1Affine* 
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf, bool defer_tail) {
+                int mont, MsmJob* job, MsmInfMask inf, bool defer_tail, MsmTable tab) {
     job->active = false;
     job->tail_pending = false;
     job->n = n;
@@ -830,7 +1138,17 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stat_msm_calls++;
     ctx->stat_msm_points += n;
     ctx->log_call('m', n);
-    WinLayout pl = msm_plan(n);
+    // flat schedule: the base set comes with its precomputed window multiples and the MSM is large enough to populate the
+    // shared bucket set (below ~2^(c-4) points the per-window schedule with its small windows wins)
+    static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
+    const bool flat = tab.t28 && !no_table && n >= ((size_t)1 << (tab.c - 4)) && (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+    WinLayout pl = flat ? msm_table_layout(tab.c) : msm_plan(n);
+    // rl: the layout the bucket stage and the host fold see — one window of 2^(c-1) buckets in the flat schedule
+    WinLayout rl = pl;
+    if (flat) {
+        rl.nwin = 1;
+        rl.boff[1] = rl.NB;
+    }
     const size_t total = n * (size_t)pl.nwin;
     ctx->stat_msm_digits += total;
     if (total >= (1ull << 32)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n * windows must be < 2^32");
@@ -839,23 +1157,50 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // workgroups of all jobs have to be resident together (one per CU: 96 KB of LDS each), which four buckets per lane allow
     unsigned log_m = pl.maxB <= 2048 ? (defer_tail ? 2 : 0) : 2;
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
-    while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > 16) log_m++;  // 16 (A, R) pairs per window fit a result slot
+    // (A, R) pairs per window that fit a result slot and that the host folds: 16 per window, or 256 for the single
+    // window of the flat schedule (one workgroup per CU either way)
+    const unsigned max_blocks = flat ? 256 : 16;
+    while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK;
     if (red_blocks == 0) red_blocks = 1;
-    // ---- lane set-up: stream, pinned result slot, event
+    // ---- stage set-up.  An asynchronous MSM (lane >= 0) is a three-stage pipeline over three auxiliary streams:
+    //   S  digits + counting sort          (HBM / LDS-atomic bound)
+    //   A  segment planning + accumulation (saturates the integer pipes)      waits for the job's sort
+    //   T  bucket stage + download         (a latency-bound chain at one wave per SIMD)   waits for the job's accumulation
+    // so that consecutive jobs keep stage A busy back to back while the tail of the previous job and the sort of the
+    // next one run beside it.  (r02 timeline: with two lanes that each ran sort -> accumulate -> tail in order, both
+    // lanes reached their tails together and ~10 ms of bucket stage per 2^20 proof ran with nothing beside it.)
+    // `lane` only selects the scratch set of the per-lane buffers (two sets: a job's sort may overwrite a set once
+    // the accumulation that last read it has finished).  lane < 0: everything on the context's stream (K1 ABI).
     hipStream_t main_stream = ctx->stream;
-    hipStream_t st = main_stream;
+    hipStream_t st_sort = main_stream, st_acc = main_stream, st_tail = main_stream;
+    // SWM_MSM_PIPE: 0 = lane is the stream for all three stages (r01 schedule), 1 = S | A | T, 2 = S | A0, A1 by lane | T
+    // (two accumulations may overlap: one alone leaves bubbles at the end of its length-sorted grid).  Small MSMs keep
+    // the single stream: the extra event hops cost more than they hide.
+    static const int pipe_mode = getenv("SWM_MSM_PIPE") ? atoi(getenv("SWM_MSM_PIPE")) : 2;
+    static const size_t pipe_min = getenv("SWM_MSM_PIPE_MIN") ? (size_t)atol(getenv("SWM_MSM_PIPE_MIN")) : 131072;
+    const bool one_stream = pipe_mode == 0 || n < pipe_min;
     if (lane >= 0) {
-        lane %= swm_ctx::MSM_LANES;
-        if (!ctx->aux_stream[lane]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[lane], hipStreamNonBlocking));
-        st = ctx->aux_stream[lane];
+        lane %= 2;
+        for (int i = 0; i < 4; i++)
+            if (!ctx->aux_stream[i]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
+        if (one_stream) {
+            st_sort = st_acc = st_tail = ctx->aux_stream[1 + lane];
+        } else {
+            st_sort = ctx->aux_stream[0];
+            st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + lane];
+            st_tail = ctx->aux_stream[3];
+        }
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
-        SWM_HIP(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
+        SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->fork_event, 0));  // the scalars are ready
+        // the scratch set of this lane was last read by the accumulation of the job two back
+        if (!one_stream && ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
     }
+    hipStream_t st = st_sort;
     const size_t slot_bytes = (size_t)MAX_WIN * 16 * sizeof(G1XYZZ);
     const size_t flags_off = slot_bytes - 16;  // the last 16 bytes of a slot carry the status words of the job
-    if ((size_t)pl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
+    if ((size_t)rl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
     if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
     int slot = ctx->next_slot;
     if (ctx->slot_busy[slot])  // its previous job has not been collected: the download would overwrite live results
@@ -868,8 +1213,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->done = ctx->slot_event[slot];
     if (!ctx->acc_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->acc_event[slot], hipEventDisableTiming));
     job->acc_done = ctx->acc_event[slot];
-    job->stream = st;
-    job->pl = pl;
+    if (!ctx->sort_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->sort_event[slot], hipEventDisableTiming));
+    job->stream = st_tail;
+    job->pl = rl;
     job->red_blocks = red_blocks;
     job->log_m = log_m;
 
@@ -899,7 +1245,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
     // two-level scatter for large MSMs (see msm_partition): bins of ~8 k entries, sized per window
-    bool two_level = n >= 262144 && pl.maxB >= 8192 && !getenv("SWM_MSM_ONE_LEVEL");
+    bool two_level = !flat && n >= 262144 && pl.maxB >= 8192 && !getenv("SWM_MSM_ONE_LEVEL");
     BinPlan bp;
     memset(&bp, 0, sizeof(bp));
     if (two_level) {
@@ -935,15 +1281,33 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         }
     }
     const uint32_t maxbins = two_level ? PART_MAX_BINS : 0;
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1) + MAX_WIN + (size_t)pl.nwin * maxbins;
+    // flat schedule: coarse bins of the shared bucket set (<= 4096 bins, <= 512 buckets each, ~8 k entries per bin)
+    unsigned flat_fb = 0;
+    uint32_t flat_bins = 0;
+    if (flat) {
+        // as few bins as the LDS of msm_flat_bin_sort allows (FLAT_BIN_CAP entries): every (tile, bin) run of the partition
+        // costs one global atomic, and with ~2 entries per run those atomics (27 M at 2^22 points) were the whole kernel
+        static const size_t bin_target = getenv("SWM_FLAT_BIN_TARGET") ? (size_t)atol(getenv("SWM_FLAT_BIN_TARGET")) : 28000;
+        uint32_t want = 64;
+        while (want < FLAT_MAX_BINS && (size_t)want * bin_target < total) want <<= 1;
+        while ((pl.NB >> flat_fb) > want) flat_fb++;
+        while ((1u << flat_fb) > FLAT_MAX_FINE) flat_fb--;  // keeps the fine-count arrays of msm_flat_bin_sort within LDS
+        flat_bins = (pl.NB + (1u << flat_fb) - 1) >> flat_fb;
+        if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
+    }
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1) + MAX_WIN + (size_t)pl.nwin * maxbins +
+                              (flat ? 3 * (size_t)FLAT_MAX_BINS + 2 : 0);
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
     uint32_t* two_level_bad = len_hist + (SEG_MAX + 1);  // one flag per window, then the per-(window, bin) cursors
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
+    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;  // [bins] counts | [bins] cursors | [bins + 1] offsets
+    uint32_t* flat_cur = flat_cnt + FLAT_MAX_BINS;
+    uint32_t* flat_off = flat_cur + FLAT_MAX_BINS;
     uint2* pairs = nullptr;
-    if (two_level) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
+    if (two_level || flat) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
     seg_len = seg_start + nseg_max;
     order = seg_len + nseg_max;
@@ -957,7 +1321,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_TRY(scratch(ctx, nm[7], (size_t)pl.NB * 4, (void**)&big_list));
     // XYZZ scratch: partial[nseg_max] | wpart[nwin * red_blocks * 2]
     G1XYZZ *partial, *wpart;
-    SWM_TRY(scratch(ctx, nm[8], (nseg_max + (size_t)pl.nwin * red_blocks * 2) * sizeof(G1XYZZ), (void**)&partial));
+    SWM_TRY(scratch(ctx, nm[8], (nseg_max + (size_t)rl.nwin * red_blocks * 2) * sizeof(G1XYZZ), (void**)&partial));
     wpart = partial + nseg_max;
 
     SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
@@ -965,40 +1329,70 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
                big_count + 1 /* zeroed with the histogram */);
-    // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
-    uint32_t SORT_TILE = SORT_TILE_MIN;
-    if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
-    unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
-    size_t lds_sort = (size_t)pl.maxB * 4;
-    SWM_TRY(allow_big_lds(ctx, 0, (const void*)msm_hist, lds_sort));
-    SWM_TRY(allow_big_lds(ctx, 1, (const void*)msm_scatter, lds_sort));
-    SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, SORT_TILE, hist);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
-    SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
-               scan_tiles, bucket_off, seg_off, big_count, big_list);
-    if (two_level) {
-        SWM_TRY(allow_big_lds(ctx, 3, (const void*)msm_partition, (size_t)PART_TILE * sizeof(uint2)));
-        SWM_TRY(allow_big_lds(ctx, 4, (const void*)msm_bin_sort, (size_t)BIN_CAP * 4));
-        SWM_LAUNCH(ctx, "msm_bin_check", msm_bin_check, dim3((bp.max_nbins + 255) / 256, pl.nwin), dim3(256), 0, bucket_off, pl, bp,
-                   two_level_bad);
-        SWM_LAUNCH(ctx, "msm_partition", msm_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin), dim3(1024),
-                   (size_t)PART_TILE * sizeof(uint2), digits, n, pl, bp, bucket_off, bin_cursor, two_level_bad, pairs);
-        SWM_LAUNCH(ctx, "msm_bin_sort", msm_bin_sort, dim3(bp.max_nbins, pl.nwin), dim3(BIN_THREADS), (size_t)BIN_CAP * 4,
-                   (const uint2*)pairs, pl, bp, bucket_off, two_level_bad, sorted);
+    const unsigned scan_tiles_ = scan_tiles;
+    if (flat) {
+        // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the
+        // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
+        const uint32_t ctile = 65536;
+        SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, (size_t)PART_TILE * sizeof(uint2)));
+        const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
+        SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((total + ctile - 1) / ctile)), dim3(SORT_THREADS), 0,
+                   digits, total, flat_fb, flat_bins, ctile, flat_cnt);
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off);
+        SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
+                   dim3(1024), (size_t)PART_TILE * sizeof(uint2), digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, flat_fb,
+                   flat_bins, flat_off, flat_cur, pairs);
+        SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
+                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, hist, sorted);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles_);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
+                   scan_tiles_, bucket_off, seg_off, big_count, big_list);
+    } else {
+        // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
+        uint32_t SORT_TILE = SORT_TILE_MIN;
+        if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
+        unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+        size_t lds_sort = (size_t)pl.maxB * 4;
+        SWM_TRY(allow_big_lds(ctx, 0, (const void*)msm_hist, lds_sort));
+        SWM_TRY(allow_big_lds(ctx, 1, (const void*)msm_scatter, lds_sort));
+        SWM_LAUNCH(ctx, "msm_hist", msm_hist, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl, SORT_TILE, hist);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
+        SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
+                   scan_tiles, bucket_off, seg_off, big_count, big_list);
+        if (two_level) {
+            SWM_TRY(allow_big_lds(ctx, 3, (const void*)msm_partition, (size_t)PART_TILE * sizeof(uint2)));
+            SWM_TRY(allow_big_lds(ctx, 4, (const void*)msm_bin_sort, (size_t)BIN_CAP * 4));
+            SWM_LAUNCH(ctx, "msm_bin_check", msm_bin_check, dim3((bp.max_nbins + 255) / 256, pl.nwin), dim3(256), 0, bucket_off, pl, bp,
+                       two_level_bad);
+            SWM_LAUNCH(ctx, "msm_partition", msm_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin), dim3(1024),
+                       (size_t)PART_TILE * sizeof(uint2), digits, n, pl, bp, bucket_off, bin_cursor, two_level_bad, pairs);
+            SWM_LAUNCH(ctx, "msm_bin_sort", msm_bin_sort, dim3(bp.max_nbins, pl.nwin), dim3(BIN_THREADS), (size_t)BIN_CAP * 4,
+                       (const uint2*)pairs, pl, bp, bucket_off, two_level_bad, sorted);
+        }
+        SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
+                   SORT_TILE, bucket_off, cursor, sorted, two_level ? (const uint32_t*)two_level_bad : (const uint32_t*)nullptr);
     }
-    SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
-               SORT_TILE, bucket_off, cursor, sorted, two_level ? (const uint32_t*)two_level_bad : (const uint32_t*)nullptr);
+    // ---- stage A
+    if (st_acc != st_sort) {
+        SWM_HIP(ctx, hipEventRecord(ctx->sort_event[slot], st_sort));
+        SWM_HIP(ctx, hipStreamWaitEvent(st_acc, ctx->sort_event[slot], 0));
+        ctx->stream = st_acc;
+    }
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                SEG, seg_start, seg_len, len_hist);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, SEG,
                len_hist, order);
-    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0, d_bases,
-               d_bases28, sorted, seg_start, seg_len, order, seg_off + pl.NB, partial);
+    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0,
+               flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
+               seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
                RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
+    job->needs_acc_wait = st_tail != ctx->stream || defer_tail;  // the tail runs on another stream (or later, with others)
     job->d_partial = partial;
     job->d_wpart = wpart;
     job->d_seg_off = seg_off;
@@ -1007,8 +1401,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->active = true;
     job->tail_pending = true;
     ctx->slot_busy[slot] = true;
-    if (defer_tail) {  // the bucket stage runs with the other jobs of the round (msm_flush_tails)
+    if (lane >= 0 || defer_tail) {
         SWM_HIP(ctx, hipEventRecord(job->acc_done, ctx->stream));
+        if (lane >= 0) ctx->set_acc_event[lane] = job->acc_done;
+    }
+    if (defer_tail) {  // the bucket stage runs with the other jobs of the round (msm_flush_tails)
         ctx->pending_tails.push_back(job);
         return SWM_OK;
     }
@@ -1031,7 +1428,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
     unsigned max_red = 1, max_win = 1;
     for (int i = 0; i < k; i++) {
         MsmJob* j = jobs[i];
-        if (j->stream != st) SWM_HIP(ctx, hipStreamWaitEvent(st, j->acc_done, 0));
+        if (j->acc_done && j->stream != nullptr && j->needs_acc_wait) SWM_HIP(ctx, hipStreamWaitEvent(st, j->acc_done, 0));
         batch.j[i].partial = j->d_partial;
         batch.j[i].seg_off = j->d_seg_off;
         batch.j[i].out = j->d_wpart;
@@ -1071,7 +1468,21 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     *result = g1_xyzz_identity();
     if (!job->active) return SWM_OK;
     if (job->tail_pending) SWM_TRY(msm_flush_tails(ctx));  // awaited before its round was flushed
+    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    auto tw0 = std::chrono::steady_clock::now();
     SWM_HIP(ctx, hipEventSynchronize(job->done));
+    auto tw1 = std::chrono::steady_clock::now();
+    struct FoldTimer {
+        bool on;
+        std::chrono::steady_clock::time_point t0, t1;
+        size_t n;
+        ~FoldTimer() {
+            if (on)
+                fprintf(stderr, "[swm trace]   msm_finish n=%zu: waited %.3f ms, host fold %.3f ms\n", n,
+                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+        }
+    } fold_timer{trace, tw0, tw1, job->n};
     job->active = false;
     ctx->slot_busy[job->slot] = false;
     ctx->stat_msm_adds += job->host_flags[1];  // entries the sort placed = non-zero digits
@@ -1086,24 +1497,47 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     unsigned shift = job->log_m;
     for (unsigned v = RED_BLOCK; v > 1; v >>= 1) shift++;
     G1XYZZ sum_a[MAX_WIN], weighted[MAX_WIN];
-    auto fold_window = [&](int w) {
-        const G1XYZZ* h = job->host + (size_t)w * nb * 2;
+    auto fold_range = [&](const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out, G1XYZZ* sr_out, G1XYZZ* wt_out) {
+        // over the workgroups blk in [lo, hi): sum of A, sum of R, and sum of (blk - lo) R_blk by suffix sums
         G1XYZZ sa = g1_xyzz_identity(), suffix = g1_xyzz_identity(), wt = g1_xyzz_identity();
-        for (unsigned blk = nb; blk-- > 0;) {
+        for (unsigned blk = hi; blk-- > lo;) {
             g1_add(sa, h[2 * blk]);
-            if (blk >= 1) {
-                g1_add(suffix, h[2 * blk + 1]);  // Suffix_blk = sum_{u >= blk} R_u
-                g1_add(wt, suffix);              // sum_{blk >= 1} Suffix_blk = sum_blk blk R_blk
-            }
+            g1_add(suffix, h[2 * blk + 1]);                // Suffix_blk = sum_{u >= blk} R_u
+            if (blk > lo) g1_add(wt, suffix);              // sum_{blk > lo} Suffix_blk = sum (blk - lo) R_blk
         }
-        sum_a[w] = sa;
-        weighted[w] = wt;
+        *sa_out = sa;
+        *sr_out = suffix;
+        *wt_out = wt;
     };
-    if (nb > 1 && pl.nwin > 1) {
-        if (!ctx->host_pool) {
-            unsigned hw = std::thread::hardware_concurrency();
-            ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
+    auto fold_window = [&](int w) {
+        G1XYZZ sr;
+        fold_range(job->host + (size_t)w * nb * 2, 0, nb, &sum_a[w], &sr, &weighted[w]);
+    };
+    if (!ctx->host_pool && nb > 1) {
+        unsigned hw = std::thread::hardware_concurrency();
+        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
+    }
+    if (pl.nwin == 1 && nb > 16) {
+        // flat schedule: one window, up to 256 workgroups.  Groups of 16 consecutive workgroups are folded in parallel;
+        // with g0 = 16 g the first workgroup of group g:  sum blk R_blk = sum_g [W_g + 16 g SR_g], and sum_g g SR_g comes
+        // from suffix sums over the groups, times 16 by four doublings.
+        const unsigned G = (nb + 15) / 16;
+        std::vector<G1XYZZ> ga(G), gr(G), gw(G);
+        ctx->host_pool->parallel_for((int)G, [&](int g) {
+            fold_range(job->host, 16u * g, std::min(nb, 16u * (g + 1)), &ga[g], &gr[g], &gw[g]);
+        });
+        G1XYZZ sa = g1_xyzz_identity(), wsum = g1_xyzz_identity(), suffix = g1_xyzz_identity(), gsum = g1_xyzz_identity();
+        for (unsigned g = G; g-- > 0;) {
+            g1_add(sa, ga[g]);
+            g1_add(wsum, gw[g]);
+            g1_add(suffix, gr[g]);
+            if (g > 0) g1_add(gsum, suffix);  // sum_g g SR_g
         }
+        for (int k = 0; k < 4; k++) gsum = g1_dbl(gsum);
+        g1_add(wsum, gsum);
+        sum_a[0] = sa;
+        weighted[0] = wsum;
+    } else if (nb > 1 && pl.nwin > 1) {
         ctx->host_pool->parallel_for((int)pl.nwin, fold_window);
     } else {
         for (unsigned w = 0; w < pl.nwin; w++) fold_window((int)w);
@@ -1129,9 +1563,9 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 
 // Synchronous form on the context's stream (K1 ABI).
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
-            G1XYZZ* result, MsmInfMask inf) {
+            G1XYZZ* result, MsmInfMask inf, MsmTable tab) {
     MsmJob job;
-    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job, inf, false));
+    SWM_TRY(msm_enqueue(ctx, -1, d_bases, d_bases28, d_scalars, n, mont, &job, inf, false, tab));
     return msm_finish(ctx, &job, result);
 }
 

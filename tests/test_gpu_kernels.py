@@ -114,7 +114,7 @@ def test_msm_golden(ctx, orc):
     srs_h.free()
 
 
-@pytest.mark.parametrize("log_n", [10, 13, 16])
+@pytest.mark.parametrize("log_n", [10, 13, 16, 17, 18, 19])
 def test_msm_vs_oracle(ctx, orc, log_n):
     from pyref.prng import fr_array
     n = 1 << log_n
@@ -334,6 +334,19 @@ def test_msm_infinity_bases(ctx, orc):
         ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[3:67][keep]), np.ascontiguousarray(sc[keep])))
         assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc, offset=3)) == ref
         bh.free()
+    # a base set large enough for the precomputed-window schedule (>= 2^17 points): the mask is honoured there, too
+    n = 1 << 17
+    bases = orc.srs_bases(n, h2i(g["tau"]), G)
+    holes = [0, 1, 77, n // 2, n - 1] + list(range(1000, n, 4099))
+    b = bases.copy()
+    b[holes] = 0
+    bh = ctx.srs_upload(b)
+    keep = np.ones(n, dtype=bool)
+    keep[holes] = False
+    for sc in (fr_array(n, 302), np.ascontiguousarray(np.tile(ints_to_limbs([0xABCDEF123], 4), (n, 1)))):
+        ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[keep]), np.ascontiguousarray(sc[keep]), threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref
+    bh.free()
     only = np.zeros((1, 12), dtype=np.uint64)
     bh = ctx.srs_upload(only)
     assert _affine_of(ctx, orc, ctx.msm_g1(bh, ints_to_limbs([12345], 4))) is None

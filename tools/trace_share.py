@@ -30,6 +30,22 @@ for t, d, k in pts:
                 if n == c: alone[kk] += t - last
     live[k] += d; last = t
 print("window %.2f ms, GPU busy %.2f ms" % ((t1 - t0) / 1e6, busy / 1e6))
+# the dominant kernel saturates the chip: what runs while NO msm_accumulate is in flight is the exposed part of a proof
+live2 = collections.Counter(); last2 = pts[0][0]; noacc = collections.Counter(); noacc_t = 0; acc_t = 0
+for t, d, k in pts:
+    if t > last2:
+        n = sum(live2.values())
+        if live2.get("msm_accumulate", 0) > 0:
+            acc_t += t - last2
+        else:
+            noacc_t += t - last2
+            for kk, c in live2.items():
+                if c: noacc[kk] += (t - last2) * c / n
+            if n == 0: noacc["(idle)"] += t - last2
+    live2[k] += d; last2 = t
+print("msm_accumulate in flight %.2f ms, not in flight %.2f ms; what runs then (share ms):" % (acc_t / 1e6, noacc_t / 1e6))
+for k, v in noacc.most_common(14):
+    print("   %-28s %7.2f" % (k[:28], v / 1e6))
 print("%-28s %9s %9s" % ("kernel", "share ms", "alone ms"))
 for k, v in share.most_common(25):
     print("%-28s %9.2f %9.2f" % (k[:28], v / 1e6, alone[k] / 1e6))
