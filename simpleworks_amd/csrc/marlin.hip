@@ -825,9 +825,22 @@ struct PhaseTrace {
     swm_ctx* ctx;
     bool on;
     std::chrono::steady_clock::time_point t0;
-    explicit PhaseTrace(swm_ctx* c) : ctx(c), on(getenv("SWM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    bool host_only;  // SWM_TRACE=2: host timestamps only (no synchronisation: the schedule is left undisturbed)
+    std::chrono::steady_clock::time_point start;
+    explicit PhaseTrace(swm_ctx* c)
+        : ctx(c), on(getenv("SWM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()),
+          host_only(getenv("SWM_TRACE") && atoi(getenv("SWM_TRACE")) == 2), start(t0) {}
+    void tick(const char* what) {
+        if (!host_only) return;
+        fprintf(stderr, "[swm host] %-34s at %8.3f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count());
+    }
     void mark(const char* what) {
         if (!on) return;
+        if (host_only) {
+            tick(what);
+            return;
+        }
         (void)hipStreamSynchronize(ctx->stream);
         auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[swm trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
@@ -1009,10 +1022,15 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         e_z = on_mul_domain(z_poly.p, H + 1);
     }
     commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
+    tr.tick("r1: pre-work enqueued");
     comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
+    tr.tick("r1: w done");
     comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
+    tr.tick("r1: z_a done");
     comms1[2] = pc_commit_end(ctx, pk, &j1[2], &zk, &P_zb.rand);
+    tr.tick("r1: z_b done");
     comms1[3] = pc_commit_end(ctx, pk, &j1[3], nullptr, &P_mask.rand);
+    tr.tick("r1: mask done");
     tr.mark("round 1 commitments");
     fs_absorb_commitments(fs, comms1);
     VerifierState st;
@@ -1048,6 +1066,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
         dv_ntt(ctx, t_poly, pk.logH, true);
     }
+    tr.tick("r2: t polynomial enqueued");
     CommitJob j2[3];
     P_t.p = t_poly.p; P_t.n = H;
     begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
