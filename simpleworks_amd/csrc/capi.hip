@@ -219,7 +219,7 @@ using namespace swm;
 
 extern "C" {
 
-int swm_version(void) { return 100; }
+int swm_version(void) { return 200; }
 
 const char* swm_strerror(int code) {
     switch (code) {

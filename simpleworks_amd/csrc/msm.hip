@@ -793,13 +793,15 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
                                                       const uint32_t* __restrict__ order,
                                                       const uint32_t* __restrict__ nseg_ptr,
                                                       G1XYZZ* __restrict__ partial) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *nseg_ptr) return;
+    // grid-stride over the length-sorted segments: the host may launch fewer workgroups than segments (SWM_ACC_WGS) so that
+    // the kernel leaves register-file room on every SIMD for the kernels that run beside it
+    const uint32_t nseg_total = *nseg_ptr;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nseg_total; t += gridDim.x * blockDim.x) {
     uint32_t seg = order[t];
     const uint32_t k0 = seg_start[seg], e = k0 + seg_len[seg];
     if (k0 >= e) {
         p28_store(partial[seg], p28_identity());
-        return;
+        continue;
     }
     bool ok = true;
     Acc28 acc;
@@ -832,7 +834,7 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
         // partial sums stay in the 28-bit domain (radix 2^392, "point form" of fq28.cuh) for the bucket stage
         P28 out{acc.x, acc.y, acc.zz, acc.zzz};
         p28_store(partial[seg], out);
-        return;
+        continue;
     }
     // cold path: a point met +-(the running sum); redo this segment with the fully reducing adder, then move the
     // result into the 28-bit domain (coordinates x 2^8)
@@ -863,6 +865,7 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
     acc32.zz = fp_mul(acc32.zz, c);   // identity (zz = 0) stays exactly zero
     acc32.zzz = fp_mul(acc32.zzz, c);
     partial[seg] = acc32;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- bucket stage (28-bit domain)
@@ -1387,7 +1390,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, SEG,
                len_hist, order);
-    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3((unsigned)((nseg_max + 255) / 256)), dim3(256), 0,
+    unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
+    static const unsigned acc_cap = getenv("SWM_ACC_WGS") ? (unsigned)atoi(getenv("SWM_ACC_WGS")) : 0u;
+    if (acc_cap && lane >= 0) acc_grid = std::min(acc_grid, acc_cap);
+    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3(acc_grid), dim3(256), 0,
                flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
                seg_off + pl.NB, partial);
     SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
