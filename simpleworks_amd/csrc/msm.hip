@@ -877,6 +877,89 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
 // takes the same 0.85 ms either way)
 __device__ __forceinline__ void p28_add_ool(P28& a, const P28& q) { p28_add<MulFenced>(a, q); }
 
+// Streamed form of the general addition for the bucket stage:  *dst = *pa + *pq  (dst may be pa), operands in memory
+// (LDS slots or HBM, packed 192-B points of the 28-bit domain).  Coordinates are loaded when they are needed and results
+// stored as soon as they exist, so that about eight field elements are live at the peak instead of two whole points plus
+// temporaries: the kernel then fits the 168-VGPR footprint of an msm_accumulate wave.  That matters more than the
+// instruction count: with 248 VGPRs a bucket-stage wave could only be placed on a SIMD that holds at most ONE
+// accumulation wave, i.e. never while an accumulation grid was in flight — the r02 timeline showed all 12.6 ms of
+// bucket stage per 2^20 proof running with no accumulation beside it.  Same formulas and bounds as p28_add_fast.
+// *dst = 2 * *pa, streamed (EFD dbl-2008-s-1, a = 0; the identity stays the identity: zz, zzz are only multiplied)
+__device__ __forceinline__ void p28_slot_dbl(G1XYZZ* dst, const G1XYZZ* pa) {
+    typedef MulFenced M;
+    Fq28 y = fq28_unpack(pa->y);
+    Fq28 u = fq28_add(y, y);                    // limbs < 2^29, value < 12p
+    Fq28 v = M::sqr(u);
+    Fq28 w = M::mul(u, v);
+    Fq28 ny;                                    // 8p - Y1 > 0 (Y1 < 6p), limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < 14; i++) ny.l[i] = Fq28Consts::SPREAD8[i] - y.l[i];
+    Fq28 zz3 = M::mul(v, fq28_unpack(pa->zz));
+    Fq28 zzz3 = M::mul(w, fq28_unpack(pa->zzz));
+    Fq28 x = fq28_unpack(pa->x);
+    Fq28 sv = M::mul(x, v);
+    Fq28 xx = M::sqr(x);
+    dst->zz = fq28_pack(zz3);
+    dst->zzz = fq28_pack(zzz3);
+    Fq28 m = fq28_add(fq28_add(xx, xx), xx);   // limbs < 3 * 2^28, value < 6p
+    Fq28 mm = M::sqr(m);
+    Fq28 x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = mm.l[i] + Fq28Consts::SPREAD16_3[i] - sv.l[i] - sv.l[i];
+    x3 = fq28_normalize(x3);                   // (12p, 18p)
+    dst->x = fq28_pack(x3);
+    dst->y = fq28_pack(M::mul2(m, FQ28_SUB(sv, x3, SPREAD32), ny, w));  // M (S - X3) - W Y1, one reduction
+}
+__device__ __forceinline__ bool fq28_all_zero(const Fq28& a) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) z |= a.l[i];
+    return z == 0;
+}
+__device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) {
+    typedef MulFenced M;
+    Fq28 azz = fq28_unpack(pa->zz), qzz = fq28_unpack(pq->zz);
+    if (fq28_all_zero(qzz)) {  // q is the identity
+        if (dst != pa) *dst = *pa;
+        return;
+    }
+    if (fq28_all_zero(azz)) {  // a is the identity
+        *dst = *pq;
+        return;
+    }
+    Fq28 u1 = M::mul(fq28_unpack(pa->x), qzz);
+    Fq28 p = M::mul(fq28_unpack(pq->x), azz);  // U2
+    p = FQ28_SUB(p, u1, SPREAD4);               // P = U2 - U1, limbs < 2^30, value in (2p, 6p)
+    Fq28 t = M::mul(azz, qzz);
+    Fq28 pp = M::sqr(p);
+    if (fq28_is_zero_mod_p(pp)) {  // q = +-a: doubling or cancellation, decided on (S2 - S1)^2 (cold)
+        Fq28 c1 = M::mul(fq28_unpack(pa->y), fq28_unpack(pq->zzz)), c2 = M::mul(fq28_unpack(pq->y), fq28_unpack(pa->zzz));
+        if (fq28_is_zero_mod_p(M::sqr(FQ28_SUB(c2, c1, SPREAD4)))) p28_slot_dbl(dst, pa);
+        else p28_store(*dst, p28_identity());
+        return;
+    }
+    Fq28 azzz = fq28_unpack(pa->zzz), qzzz = fq28_unpack(pq->zzz);
+    Fq28 s1 = M::mul(fq28_unpack(pa->y), qzzz);
+    Fq28 r = M::mul(fq28_unpack(pq->y), azzz);  // S2
+    r = FQ28_SUB(r, s1, SPREAD4);                // R = S2 - S1
+    Fq28 t2 = M::mul(azzz, qzzz);
+    // every coordinate of a and q has been read: dst may be overwritten from here on
+    dst->zz = fq28_pack(M::mul(t, pp));
+    Fq28 ppp = M::mul(p, pp);
+    dst->zzz = fq28_pack(M::mul(t2, ppp));
+    Fq28 qq = M::mul(u1, pp);
+    Fq28 rr = M::sqr(r);
+    Fq28 x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = rr.l[i] + Fq28Consts::SPREAD16_3[i] - ppp.l[i] - qq.l[i] - qq.l[i];
+    x3 = fq28_normalize(x3);  // (10p, 18p)
+    dst->x = fq28_pack(x3);
+    Fq28 ns1;  // 4p - S1 > 0 (S1 < 2p), limbs < 2^29
+#pragma unroll
+    for (int i = 0; i < 14; i++) ns1.l[i] = Fq28Consts::SPREAD4[i] - s1.l[i];
+    dst->y = fq28_pack(M::mul2(r, FQ28_SUB(qq, x3, SPREAD32), ns1, ppp));  // R (Q - X3) - S1 PPP, one reduction
+}
+
 // Oversized buckets (> BIG_NSEG segments: structured scalars) are folded first, one workgroup each: strided partial
 // sums + LDS tree; the result replaces the bucket's first partial.
 __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restrict__ partial,
@@ -889,20 +972,13 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
     for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
         uint32_t b = big_list[j];
         uint32_t s = seg_off[b], e = seg_off[b + 1];
-        P28 acc = p28_identity();
-        for (uint32_t k = s + threadIdx.x; k < e; k += RED_BLOCK) {
-            P28 q = p28_load(partial[k]);
-            p28_add_ool(acc, q);
-        }
-        p28_store(sm[threadIdx.x], acc);
+        p28_store(sm[threadIdx.x], p28_identity());
+#pragma unroll 1
+        for (uint32_t k = s + threadIdx.x; k < e; k += RED_BLOCK) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &partial[k]);
         __syncthreads();
+#pragma unroll 1
         for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
-            if (threadIdx.x < stride) {
-                P28 a = p28_load(sm[threadIdx.x]);
-                P28 q = p28_load(sm[threadIdx.x + stride]);
-                p28_add_ool(a, q);
-                p28_store(sm[threadIdx.x], a);
-            }
+            if (threadIdx.x < stride) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &sm[threadIdx.x + stride]);
             __syncthreads();
         }
         if (threadIdx.x == 0) partial[s] = sm[0];
@@ -949,9 +1025,13 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
     const unsigned log_m = job.log_m;
     G1XYZZ* __restrict__ out = job.out;
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS: three packed slots per lane — the running sum in two copies (the scan and the shift read a NEIGHBOUR's slot
+    // while every lane rewrites its own, so those steps go from one copy to the other) and the weighted sum — plus one
+    // slot for R_blk: (3 x 256 + 1) x 192 B = 144 KB per workgroup.
     G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
-    G1XYZZ* sm_acc = sm_run + RED_BLOCK;
-    G1XYZZ* sm_r = sm_acc + RED_BLOCK;  // one slot: R_blk, saved before the scan slots are reused
+    G1XYZZ* sm_alt = sm_run + RED_BLOCK;
+    G1XYZZ* sm_acc = sm_alt + RED_BLOCK;
+    G1XYZZ* sm_r = sm_acc + RED_BLOCK;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RED_BLOCK + t) << log_m;
@@ -974,9 +1054,11 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
     __syncthreads();
 #pragma unroll 1
     for (;;) {
+        // one micro-operation per iteration: *dst = *pa + *pq (act), or *dst = *pa (copy: inactive lane of a scan step)
         G1XYZZ* dst = &sm_run[t];
-        const G1XYZZ* src = &sm_run[t];
-        bool act = false;
+        const G1XYZZ* pa = &sm_run[t];
+        const G1XYZZ* pq = &sm_run[t];
+        bool act = false, copy = false;
         if (phase == WALK) {
             if (!__syncthreads_or(walking)) {
                 phase = SCAN;
@@ -985,9 +1067,10 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
             if (walking) {
                 act = true;
                 if (s < e) {
-                    src = &partial[s++];
+                    pq = &partial[s++];
                 } else {
                     dst = &sm_acc[t];
+                    pa = &sm_acc[t];
                     if (b == lo) {
                         walking = false;
                     } else {
@@ -998,43 +1081,50 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
                     }
                 }
             }
-        } else if (phase == SCAN) {  // inclusive suffix scan of run over the workgroup (Hillis-Steele)
+        } else if (phase == SCAN) {  // inclusive suffix scan of run over the workgroup (Hillis-Steele), copy to copy
             if (d >= RED_BLOCK) {
                 phase = SHIFT;
                 continue;
             }
+            dst = &sm_alt[t];
             act = t + d < RED_BLOCK;
-            if (act) src = &sm_run[t + d];
+            copy = !act;
+            if (act) pq = &sm_run[t + d];
             d <<= 1;
-        } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1}; R_blk = Suffix_0 is parked first
-            P28 next = t + 1 < RED_BLOCK ? p28_load(sm_run[t + 1]) : p28_identity();
+        } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1} (into the other copy); R_blk = Suffix_0 is parked
+            if (t + 1 < RED_BLOCK) sm_alt[t] = sm_run[t + 1];
+            else p28_store(sm_alt[t], p28_identity());
             if (t == 0) sm_r[0] = sm_run[0];
-            __syncthreads();
 #pragma unroll 1
-            for (unsigned i = 0; i < log_m; i++) next = p28_dbl<MulFenced>(next);
-            p28_store(sm_run[t], next);
+            for (unsigned i = 0; i < log_m; i++) p28_slot_dbl(&sm_alt[t], &sm_alt[t]);
+            __syncthreads();
+            G1XYZZ* x = sm_run;
+            sm_run = sm_alt;
+            sm_alt = x;
             phase = FOLD;
             continue;
         } else if (phase == FOLD) {  // acc_t += m Suffix_{t+1}; summed over t this is A_blk
             dst = &sm_acc[t];
+            pa = &sm_acc[t];
             act = true;
             phase = TREE;
             d = RED_BLOCK / 2;
         } else {
             if (d == 0) break;
             dst = &sm_acc[t];
+            pa = &sm_acc[t];
             act = t < d;
-            src = act ? &sm_acc[t + d] : &sm_acc[t];
+            if (act) pq = &sm_acc[t + d];  // the lanes t + d .. are idle in this step: nobody rewrites what is read
             d >>= 1;
         }
-        P28 a = p28_load(*dst);
-        P28 q = p28_load(*src);
-        __syncthreads();  // scan steps read their neighbour's slot before it is rewritten
-        if (act) {
-            p28_add_ool(a, q);
-            p28_store(*dst, a);
-        }
+        if (act) p28_slot_add(dst, pa, pq);
+        else if (copy) *dst = *pa;
         __syncthreads();
+        if (dst == &sm_alt[t]) {  // a scan step went from one copy of the running sums to the other (uniform per step)
+            G1XYZZ* x = sm_run;
+            sm_run = sm_alt;
+            sm_alt = x;
+        }
     }
     if (t == 0) {
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
@@ -1444,9 +1534,9 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);
     }
-    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (2 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
     SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
-               (2 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+               (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
     for (int i = 0; i < k; i++) {
         MsmJob* j = jobs[i];
         SWM_HIP(ctx, hipMemcpyAsync(j->host, j->d_wpart, (size_t)j->pl.nwin * j->red_blocks * 2 * sizeof(G1XYZZ),
