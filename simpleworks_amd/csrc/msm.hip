@@ -938,16 +938,17 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
         else p28_store(*dst, p28_identity());
         return;
     }
+    // the x / zz side is finished first (its inputs die early): of a only y and zzz are still to be read, and those slots
+    // are written last
+    dst->zz = fq28_pack(M::mul(t, pp));
+    Fq28 ppp = M::mul(p, pp);
+    Fq28 qq = M::mul(u1, pp);
     Fq28 azzz = fq28_unpack(pa->zzz), qzzz = fq28_unpack(pq->zzz);
     Fq28 s1 = M::mul(fq28_unpack(pa->y), qzzz);
     Fq28 r = M::mul(fq28_unpack(pq->y), azzz);  // S2
     r = FQ28_SUB(r, s1, SPREAD4);                // R = S2 - S1
     Fq28 t2 = M::mul(azzz, qzzz);
-    // every coordinate of a and q has been read: dst may be overwritten from here on
-    dst->zz = fq28_pack(M::mul(t, pp));
-    Fq28 ppp = M::mul(p, pp);
     dst->zzz = fq28_pack(M::mul(t2, ppp));
-    Fq28 qq = M::mul(u1, pp);
     Fq28 rr = M::sqr(r);
     Fq28 x3;
 #pragma unroll
