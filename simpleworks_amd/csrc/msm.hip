@@ -1017,7 +1017,8 @@ struct TailJob {
 struct TailBatch {
     TailJob j[TAIL_MAX];
 };
-__global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) {
+template <int RB>
+__global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
     const G1XYZZ* __restrict__ partial = job.partial;
@@ -1030,12 +1031,12 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
     // while every lane rewrites its own, so those steps go from one copy to the other) and the weighted sum — plus one
     // slot for R_blk: (3 x 256 + 1) x 192 B = 144 KB per workgroup.
     G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
-    G1XYZZ* sm_alt = sm_run + RED_BLOCK;
-    G1XYZZ* sm_acc = sm_alt + RED_BLOCK;
-    G1XYZZ* sm_r = sm_acc + RED_BLOCK;
+    G1XYZZ* sm_alt = sm_run + RB;
+    G1XYZZ* sm_acc = sm_alt + RB;
+    G1XYZZ* sm_r = sm_acc + RB;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
-    const uint32_t lo = (blockIdx.x * RED_BLOCK + t) << log_m;
+    const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
     p28_store(sm_run[t], p28_identity());
     p28_store(sm_acc[t], p28_identity());
@@ -1083,17 +1084,17 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
                 }
             }
         } else if (phase == SCAN) {  // inclusive suffix scan of run over the workgroup (Hillis-Steele), copy to copy
-            if (d >= RED_BLOCK) {
+            if (d >= RB) {
                 phase = SHIFT;
                 continue;
             }
             dst = &sm_alt[t];
-            act = t + d < RED_BLOCK;
+            act = t + d < RB;
             copy = !act;
             if (act) pq = &sm_run[t + d];
             d <<= 1;
         } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1} (into the other copy); R_blk = Suffix_0 is parked
-            if (t + 1 < RED_BLOCK) sm_alt[t] = sm_run[t + 1];
+            if (t + 1 < RB) sm_alt[t] = sm_run[t + 1];
             else p28_store(sm_alt[t], p28_identity());
             if (t == 0) sm_r[0] = sm_run[0];
 #pragma unroll 1
@@ -1109,7 +1110,7 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_bucket_reduce(TailBatch batch) 
             pa = &sm_acc[t];
             act = true;
             phase = TREE;
-            d = RED_BLOCK / 2;
+            d = RB / 2;
         } else {
             if (d == 0) break;
             dst = &sm_acc[t];
@@ -1253,9 +1254,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     // (A, R) pairs per window that fit a result slot and that the host folds: 16 per window, or 256 for the single
     // window of the flat schedule (one workgroup per CU either way)
-    const unsigned max_blocks = flat ? 256 : 16;
-    while (((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK > max_blocks) log_m++;
-    unsigned red_blocks = ((pl.maxB >> log_m) + RED_BLOCK - 1) / RED_BLOCK;
+    // workgroup width of the bucket stage: 256 lanes.  SWM_RED_LANES=64 (flat schedule only) switches to single-wave
+    // workgroups of 64 lanes (36 KB of LDS) that could be placed on ANY SIMD with room, i.e. beside accumulation waves,
+    // where the 256-lane form needs all four SIMDs of a CU at once — measured r02: the stage itself takes 1.00 instead of
+    // 0.72 ms (1024 workgroup results to fold instead of 256) and a 2^20 proof 82.7 instead of 77.4 ms: not the default.
+    static const unsigned flat_rb = getenv("SWM_RED_LANES") ? (unsigned)atoi(getenv("SWM_RED_LANES")) : 256u;
+    const unsigned rb = flat ? (flat_rb == 64 ? 64u : 256u) : 256u;
+    const unsigned max_blocks = flat ? (rb == 64 ? 1024u : 256u) : 16u;
+    while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
+    unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
     if (red_blocks == 0) red_blocks = 1;
     // ---- stage set-up.  An asynchronous MSM (lane >= 0) is a three-stage pipeline over three auxiliary streams:
     //   S  digits + counting sort          (HBM / LDS-atomic bound)
@@ -1292,7 +1299,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (!one_stream && ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
     }
     hipStream_t st = st_sort;
-    const size_t slot_bytes = (size_t)MAX_WIN * 16 * sizeof(G1XYZZ);
+    const size_t slot_bytes = (size_t)MAX_WIN * 32 * sizeof(G1XYZZ) + 64;  // up to 1024 (A, R) pairs + status words
     const size_t flags_off = slot_bytes - 16;  // the last 16 bytes of a slot carry the status words of the job
     if ((size_t)rl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
     if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
@@ -1312,6 +1319,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->pl = rl;
     job->red_blocks = red_blocks;
     job->log_m = log_m;
+    job->rb = rb;
 
     // everything below is enqueued on `st`: temporarily make it the context's stream so that launches, memsets,
     // scratch growth and the profiling events all refer to it
@@ -1535,9 +1543,14 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);
     }
-    SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
-    SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce, dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
-               (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+    if (jobs[0]->rb == 64) {
+        SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce<64>, dim3(max_red, max_win, (unsigned)k), dim3(64),
+                   (3 * 64 + 1) * sizeof(G1XYZZ), batch);
+    } else {
+        SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce<256>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+        SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce<256>, dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
+                   (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+    }
     for (int i = 0; i < k; i++) {
         MsmJob* j = jobs[i];
         SWM_HIP(ctx, hipMemcpyAsync(j->host, j->d_wpart, (size_t)j->pl.nwin * j->red_blocks * 2 * sizeof(G1XYZZ),
@@ -1556,8 +1569,12 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
 int msm_flush_tails(swm_ctx* ctx) {
     std::vector<MsmJob*> jobs;
     jobs.swap(ctx->pending_tails);
-    for (size_t i = 0; i < jobs.size(); i += TAIL_MAX)
-        SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)std::min<size_t>(TAIL_MAX, jobs.size() - i)));
+    for (size_t i = 0; i < jobs.size();) {  // one launch per run of up to TAIL_MAX jobs of the same workgroup width
+        size_t k = 1;
+        while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb) k++;
+        SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)k));
+        i += k;
+    }
     return SWM_OK;
 }
 
@@ -1592,7 +1609,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     const WinLayout& pl = job->pl;
     const unsigned nb = job->red_blocks;
     unsigned shift = job->log_m;
-    for (unsigned v = RED_BLOCK; v > 1; v >>= 1) shift++;
+    for (unsigned v = job->rb; v > 1; v >>= 1) shift++;
     G1XYZZ sum_a[MAX_WIN], weighted[MAX_WIN];
     auto fold_range = [&](const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out, G1XYZZ* sr_out, G1XYZZ* wt_out) {
         // over the workgroups blk in [lo, hi): sum of A, sum of R, and sum of (blk - lo) R_blk by suffix sums

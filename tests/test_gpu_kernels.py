@@ -469,3 +469,28 @@ def test_batch_inverse_and_vec_mul(ctx, orc):
     ref = np.empty_like(x)
     orc.lib.oracle_fr_mul(p64(x), p64(y), p64(ref), x.shape[0])
     assert np.array_equal(ctx.vec_mul_fr(x, y), ref)
+
+
+def test_msm_table_schedule_equals_window_schedule(ctx, orc):
+    """The same base set through both schedules (SWM_MSM_NO_TABLE is read once per process, so the comparison is between a
+    resident set large enough for the precomputed-window tables and its first 2^16 points re-uploaded as a small set):
+    MSMs at an offset, of uneven length, with structured scalars."""
+    from pyref.prng import fr_array
+    n = 1 << 17
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    big = ctx.srs_upload(bases)                                     # table schedule (n >= 2^17)
+    off, m = 12345, 60000
+    small = ctx.srs_upload(np.ascontiguousarray(bases[off:off + m]))  # per-window schedule
+    for seed, shape in ((1, "uniform"), (2, "bits"), (3, "equal")):
+        sc = fr_array(m, 900 + seed)
+        if shape == "bits":
+            sc[0::2] = 0
+            sc[0::4, 0] = 1
+        elif shape == "equal":
+            sc[:] = sc[7]
+        a = _affine_of(ctx, orc, ctx.msm_g1(big, sc, offset=off))
+        b = _affine_of(ctx, orc, ctx.msm_g1(small, sc))
+        assert a == b, shape
+    big.free()
+    small.free()

@@ -576,3 +576,51 @@ def test_sharded_prover_two_processes_real_kernels(tmp_path):
     assert all(o["ok"] for o in outs)
     assert outs[0]["proof"] == outs[1]["proof"]
     assert outs[0]["exchanges"] == outs[1]["exchanges"] > 0
+
+
+def test_sharded_prover_with_window_tables_2p17(M, S, W):
+    """Keys of >= 2^17 SRS powers carry the precomputed window multiples: a rank's shard then starts at a table OFFSET.
+    Three thread-ranks (uneven ranges) must reproduce the single-context bytes."""
+    n = 1 << 17
+    cs, public = W.synthetic_r1cs(n, 0x1717, 0x7171)
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        proof = M.generate_proof(cs, pk, M.rng_from_seed(bytes([5] * 32)))
+        out = (S.serialize_verifying_key(vk), S.serialize_proof(proof))
+        pk.free()
+        return out
+
+    from simpleworks_amd._lib import Context
+    single_ctx = Context(0)
+    vk1, proof1 = build(single_ctx)
+    single_ctx.close()
+    for vk_b, proof_b in _run_sharded(3, build):
+        assert vk_b == vk1
+        assert proof_b == proof1
+    assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
+
+
+def test_proving_key_roundtrip_2p16_and_table_schedule(M, S, W):
+    """serialize -> deserialize of a 2^16 key (IndexProverKey bytes, ~0.2 GB: compressed committer key re-checked on the GPU,
+    window tables rebuilt): the loaded key proves to the same bytes."""
+    n = 1 << 16
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 21, 34)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
+    blob = S.serialize_proving_key(pk)
+    assert len(blob) > 100 << 20
+    pk2 = S.deserialize_proving_key(blob)
+    del blob
+    seed = bytes(range(32))
+    p1 = M.generate_proof(cs, pk, M.rng_from_seed(seed))
+    p2 = M.generate_proof(cs, pk2, M.rng_from_seed(seed))
+    assert p1.data == p2.data
+    assert M.verify_proof(vk, public, p2, M.generate_rand())
+    pk.free()
+    pk2.free()
