@@ -188,7 +188,8 @@ fn universal_setup(nc: usize, nv: usize, nnz: usize, rng: &mut StdRng) -> std::r
             powers_of_gamma_g.insert(i, g1_from_limbs(&gamma[12 * i..12 * i + 12]));
         }
         let (h_pt, beta_h): (G2Affine, G2Affine) = (g2_from_limbs(&h), g2_from_limbs(&bh));
-        let srs = UniversalSRS {
+        // (built under its concrete name: a struct expression cannot go through the associated-type alias UniversalSRS)
+        let srs: UniversalSRS = ark_poly_commit::kzg10::UniversalParams::<Bls12_377> {
             powers_of_g,
             powers_of_gamma_g,
             h: h_pt,
