@@ -398,11 +398,13 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
         hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
     }
     // Small MSMs defer their bucket stage to the end of the round, where the stages of all its commitments run as one
-    // launch (one chain latency instead of four; measured r02: 2^12 proofs 10.3 -> 9.8 ms).  Above ~2^15 points a single
-    // bucket stage already fills the chip with one 96-KB workgroup per CU, so a joint launch only queues them behind
-    // one another and gives up the overlap with the next commitment's accumulation (2^16: 16.5 -> 20.3 ms, 2^20: 85.6 ->
-    // 89.6 ms): those keep their own tail.
-    static const long batch_below = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : 32768;
+    // launch: one chain latency instead of four.  With the flat schedule (a table: one bucket set, <= 64 workgroups per
+    // stage below 2^18 points) the four stages of a round are resident together (up to 3 x 2^16 points: the commitments of a 2^16 proof) — measured r02: 2^14 proofs 11.7 -> 9.9 ms,
+    // 2^16 17.4 -> 14.7 ms.  Per-window schedule (no table): a single stage fills the chip from ~2^15 points, a joint
+    // launch only queues them behind one another (2^16: 16.5 -> 20.3 ms) — those keep their own tail, as do large MSMs,
+    // whose tail overlaps the next commitment's accumulation.
+    static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
+    const long batch_below = batch_env >= 0 ? batch_env : (tab.t28 ? 200000 : 32768);
     tab.offset += lo;
     rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));

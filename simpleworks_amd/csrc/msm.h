@@ -39,6 +39,7 @@ struct MsmJob {
     bool active = false;
     size_t n = 0;
     WinLayout pl;
+    unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
     unsigned red_blocks = 0, log_m = 0, rb = 256;  // bucket stage: workgroups per window, log2 buckets per lane, lanes per workgroup
     int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
     // deferred bucket stage (msm_flush_tails): what it reads / writes, the stream the job ran on and its "partials ready" event

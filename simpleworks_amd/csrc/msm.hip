@@ -99,11 +99,15 @@ WinLayout msm_table_layout(unsigned c) {
     return L;
 }
 unsigned msm_table_width(size_t n_bases) {
-    if (const char* e = getenv("SWM_MSM_TABLE_C")) return (unsigned)std::min(22, std::max(12, atoi(e)));
-    if (n_bases < (1u << 17)) return 0;  // small base sets keep the per-window schedule
+    if (const char* e = getenv("SWM_MSM_TABLE_C")) return (unsigned)std::min(22, std::max(8, atoi(e)));
+    if (n_bases < 512) return 0;  // tiny base sets keep the per-window schedule
+    // measured r02 (prove() at 2^10 .. 2^20 constraints, base sets of 3 x that): two bits above the size of the base
+    // set up to 2^15 points — 4 .. 10 points per bucket for the MSMs of a proof, which keeps the accumulation chains
+    // short — one bit above it from there, up to 20 (21 and 22 lose at 2^20 and above: the bucket stage grows faster
+    // than the accumulation shrinks)
     unsigned lg = 0;
     while (((size_t)2 << lg) <= n_bases) lg++;
-    return std::min(20u, std::max(17u, lg));
+    return lg <= 15 ? lg + 2 : std::min(20u, lg + 1);
 }
 
 // ---------------------------------------------------------------------------------------------- digits
@@ -640,14 +644,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_mid(uint32_t* __restrict_
     }
 }
 
-// Also appends buckets with > BIG_NSEG segments to the big list.
+// Also appends buckets with > big_nseg segments to the big list.
 __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __restrict__ hist, uint32_t NB, uint32_t SEG,
                                                             const uint32_t* __restrict__ tot_cnt,
                                                             const uint32_t* __restrict__ tot_seg, uint32_t ntiles,
                                                             uint32_t* __restrict__ bucket_off,
                                                             uint32_t* __restrict__ seg_off,
                                                             uint32_t* __restrict__ big_count,
-                                                            uint32_t* __restrict__ big_list) {
+                                                            uint32_t* __restrict__ big_list, uint32_t big_nseg) {
     __shared__ uint32_t sa[SCAN_BLOCK], sb[SCAN_BLOCK];
     uint32_t lo = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t hi = min(lo + SCAN_ITEMS, NB);
@@ -665,7 +669,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) msm_scan_final(const uint32_t* __r
         seg_off[i] = rb;
         ra += h;
         rb += ns;
-        if (ns > BIG_NSEG) big_list[atomicAdd(big_count, 1u)] = i;
+        if (ns > big_nseg) big_list[atomicAdd(big_count, 1u)] = i;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         bucket_off[NB] = tot_cnt[ntiles];
@@ -966,23 +970,31 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
 __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restrict__ partial,
                                                                 const uint32_t* __restrict__ seg_off,
                                                                 const uint32_t* __restrict__ big_count,
-                                                                const uint32_t* __restrict__ big_list) {
+                                                                const uint32_t* __restrict__ big_list, unsigned log_g) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
     const uint32_t nbig = *big_count;
-    for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
-        uint32_t b = big_list[j];
-        uint32_t s = seg_off[b], e = seg_off[b + 1];
+    // 2^log_g lanes per listed bucket (a whole workgroup for the oversized buckets of structured scalars; 4 .. 64 lanes
+    // in the low-latency schedule of small MSMs, where EVERY bucket with more than two segments is folded here)
+    const uint32_t G = 1u << log_g, per = RED_BLOCK >> log_g, g = threadIdx.x & (G - 1);
+    for (uint32_t j0 = blockIdx.x * per; j0 < nbig; j0 += gridDim.x * per) {
+        const uint32_t j = j0 + (threadIdx.x >> log_g);
+        uint32_t s = 0, e = 0;
+        if (j < nbig) {
+            uint32_t b = big_list[j];
+            s = seg_off[b];
+            e = seg_off[b + 1];
+        }
         p28_store(sm[threadIdx.x], p28_identity());
 #pragma unroll 1
-        for (uint32_t k = s + threadIdx.x; k < e; k += RED_BLOCK) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &partial[k]);
+        for (uint32_t k = s + g; k < e; k += G) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &partial[k]);
         __syncthreads();
 #pragma unroll 1
-        for (uint32_t stride = RED_BLOCK / 2; stride > 0; stride >>= 1) {
-            if (threadIdx.x < stride) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &sm[threadIdx.x + stride]);
+        for (uint32_t stride = G / 2; stride > 0; stride >>= 1) {
+            if (g < stride) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &sm[threadIdx.x + stride]);
             __syncthreads();
         }
-        if (threadIdx.x == 0) partial[s] = sm[0];
+        if (g == 0 && j < nbig) partial[s] = sm[threadIdx.x];
         __syncthreads();
     }
 }
@@ -1011,7 +1023,7 @@ struct TailJob {
     const G1XYZZ* partial;
     const uint32_t* seg_off;
     G1XYZZ* out;
-    unsigned log_m, red_blocks;
+    unsigned log_m, red_blocks, big_nseg;
     WinLayout L;
 };
 struct TailBatch {
@@ -1048,7 +1060,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
         b--;
         s = seg_off[base + b];
         e = seg_off[base + b + 1];
-        if (e - s > BIG_NSEG) e = s + 1;  // already folded into the first partial
+        if (e - s > job.big_nseg) e = s + 1;  // already folded into the first partial
     }
     enum { WALK = 0, SCAN = 1, SHIFT = 2, FOLD = 3, TREE = 4 };
     int phase = WALK;
@@ -1079,7 +1091,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
                         b--;
                         s = seg_off[base + b];
                         e = seg_off[base + b + 1];
-                        if (e - s > BIG_NSEG) e = s + 1;
+                        if (e - s > job.big_nseg) e = s + 1;
                     }
                 }
             }
@@ -1236,7 +1248,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // flat schedule: the base set comes with its precomputed window multiples and the MSM is large enough to populate the
     // shared bucket set (below ~2^(c-4) points the per-window schedule with its small windows wins)
     static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
-    const bool flat = tab.t28 && !no_table && n >= ((size_t)1 << (tab.c - 4)) && (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+    const bool flat = tab.t28 && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
+                      (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+    // low-latency schedule (flat MSMs below ~2^18 points, where a proof is a chain of dependent additions rather than
+    // a throughput problem): short segments (8 points), every bucket with more than two segments folded by a lane
+    // group in msm_big_bucket_sum (a tree instead of the serial walk of the bucket stage), one bucket per lane in the
+    // bucket stage
+    static const size_t lat_below = getenv("SWM_MSM_LAT_BELOW") ? (size_t)atol(getenv("SWM_MSM_LAT_BELOW")) : 262144;
+    const bool lat = flat && n < lat_below;
     WinLayout pl = flat ? msm_table_layout(tab.c) : msm_plan(n);
     // rl: the layout the bucket stage and the host fold see — one window of 2^(c-1) buckets in the flat schedule
     WinLayout rl = pl;
@@ -1251,6 +1270,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // small windows: one bucket per lane shortens the serial walk of a lone MSM (r01 sweep); inside a round's batch the
     // workgroups of all jobs have to be resident together (one per CU: 96 KB of LDS each), which four buckets per lane allow
     unsigned log_m = pl.maxB <= 2048 ? (defer_tail ? 2 : 0) : 2;
+    if (lat) log_m = 0;
     if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     // (A, R) pairs per window that fit a result slot and that the host folds: 16 per window, or 256 for the single
     // window of the flat schedule (one workgroup per CU either way)
@@ -1260,7 +1280,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // 0.72 ms (1024 workgroup results to fold instead of 256) and a 2^20 proof 82.7 instead of 77.4 ms: not the default.
     static const unsigned flat_rb = getenv("SWM_RED_LANES") ? (unsigned)atoi(getenv("SWM_RED_LANES")) : 256u;
     const unsigned rb = flat ? (flat_rb == 64 ? 64u : 256u) : 256u;
-    const unsigned max_blocks = flat ? (rb == 64 ? 1024u : 256u) : 16u;
+    // (low-latency schedule: the bucket stages of a round's four MSMs run in one launch and have to be resident together)
+    const unsigned max_blocks = flat ? (rb == 64 ? 1024u : (lat && defer_tail ? 64u : 256u)) : 16u;
     while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
     if (red_blocks == 0) red_blocks = 1;
@@ -1342,7 +1363,19 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
     // 32 by 10 % at 2^20 and 2^22, loses at 2^16 where 45 k buckets cannot fill 196 k lane slots).
     uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;  // smaller bounds for small MSMs measured within run-to-run noise
+    if (lat) SEG = n < 65536 ? 8 : 16;
     if (const char* e = getenv("SWM_MSM_SEG")) SEG = std::min<uint32_t>(SEG_MAX, std::max(1, atoi(e)));
+    // segments per bucket above which a bucket is folded ahead of the bucket stage, and the lanes that fold one
+    uint32_t big_nseg = BIG_NSEG;
+    unsigned log_g = 8;
+    if (lat) {
+        big_nseg = 2;
+        const size_t per_bucket = total / ((size_t)pl.NB * SEG) + 1;  // expected segments per bucket
+        log_g = 2;
+        while (log_g < 6 && ((size_t)1 << log_g) < 2 * per_bucket) log_g++;
+    }
+    if (const char* e = getenv("SWM_MSM_LOGG")) log_g = std::min(8, std::max(0, atoi(e)));
+    job->big_nseg = big_nseg;
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
@@ -1390,8 +1423,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // as few bins as the LDS of msm_flat_bin_sort allows (FLAT_BIN_CAP entries): every (tile, bin) run of the partition
         // costs one global atomic, and with ~2 entries per run those atomics (27 M at 2^22 points) were the whole kernel
         static const size_t bin_target = getenv("SWM_FLAT_BIN_TARGET") ? (size_t)atol(getenv("SWM_FLAT_BIN_TARGET")) : 28000;
+        // (small MSMs: at least ~1024 bins as long as a bin keeps 1024 entries — 64 bins meant 64 workgroups in the bin
+        // sort and 1024 lanes contending for 64 LDS counters in the coarse histogram)
+        const size_t target = std::min(bin_target, std::max<size_t>(1024, total / 1024));
         uint32_t want = 64;
-        while (want < FLAT_MAX_BINS && (size_t)want * bin_target < total) want <<= 1;
+        while (want < FLAT_MAX_BINS && (size_t)want * target < total) want <<= 1;
         while ((pl.NB >> flat_fb) > want) flat_fb++;
         while ((1u << flat_fb) > FLAT_MAX_FINE) flat_fb--;  // keeps the fine-count arrays of msm_flat_bin_sort within LDS
         flat_bins = (pl.NB + (1u << flat_fb) - 1) >> flat_fb;
@@ -1435,7 +1471,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (flat) {
         // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the
         // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
-        const uint32_t ctile = 65536;
+        uint32_t ctile = 65536;  // digits per workgroup of the coarse histogram: at least ~256 workgroups
+        while (ctile > 4096 && (size_t)ctile * 256 > total) ctile >>= 1;
         SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, (size_t)PART_TILE * sizeof(uint2)));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
@@ -1450,7 +1487,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles_);
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
-                   scan_tiles_, bucket_off, seg_off, big_count, big_list);
+                   scan_tiles_, bucket_off, seg_off, big_count, big_list, big_nseg);
     } else {
         // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
         uint32_t SORT_TILE = SORT_TILE_MIN;
@@ -1463,7 +1500,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles);
         SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
-                   scan_tiles, bucket_off, seg_off, big_count, big_list);
+                   scan_tiles, bucket_off, seg_off, big_count, big_list, big_nseg);
         if (two_level) {
             SWM_TRY(allow_big_lds(ctx, 3, (const void*)msm_partition, (size_t)PART_TILE * sizeof(uint2)));
             SWM_TRY(allow_big_lds(ctx, 4, (const void*)msm_bin_sort, (size_t)BIN_CAP * 4));
@@ -1495,8 +1532,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3(acc_grid), dim3(256), 0,
                flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
                seg_off + pl.NB, partial);
-    SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum, dim3(std::min<unsigned>(pl.NB, 512)), dim3(RED_BLOCK),
-               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list);
+    SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum,
+               dim3(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512)), dim3(RED_BLOCK),
+               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, log_g);
     job->needs_acc_wait = st_tail != ctx->stream || defer_tail;  // the tail runs on another stream (or later, with others)
     job->d_partial = partial;
     job->d_wpart = wpart;
@@ -1539,6 +1577,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         batch.j[i].out = j->d_wpart;
         batch.j[i].log_m = j->log_m;
         batch.j[i].red_blocks = j->red_blocks;
+        batch.j[i].big_nseg = j->big_nseg;
         batch.j[i].L = j->pl;
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);

@@ -471,26 +471,51 @@ def test_batch_inverse_and_vec_mul(ctx, orc):
     assert np.array_equal(ctx.vec_mul_fr(x, y), ref)
 
 
-def test_msm_table_schedule_equals_window_schedule(ctx, orc):
-    """The same base set through both schedules (SWM_MSM_NO_TABLE is read once per process, so the comparison is between a
-    resident set large enough for the precomputed-window tables and its first 2^16 points re-uploaded as a small set):
-    MSMs at an offset, of uneven length, with structured scalars."""
+def test_msm_table_schedule_offsets_and_shapes(ctx, orc):
+    """A resident base set with precomputed-window tables: MSMs at an offset, of uneven length, with structured scalars,
+    through the flat schedule (60000 points: the low-latency variant with its lane-group fold of multi-segment buckets)
+    and — on the same set — through the per-window schedule that MSMs too small for the shared bucket set keep
+    (700 points, read from the first table row)."""
     from pyref.prng import fr_array
     n = 1 << 17
     G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
     bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
-    big = ctx.srs_upload(bases)                                     # table schedule (n >= 2^17)
-    off, m = 12345, 60000
-    small = ctx.srs_upload(np.ascontiguousarray(bases[off:off + m]))  # per-window schedule
-    for seed, shape in ((1, "uniform"), (2, "bits"), (3, "equal")):
-        sc = fr_array(m, 900 + seed)
+    big = ctx.srs_upload(bases)
+    for off, m in ((12345, 60000), (4321, 700)):
+        sub = np.ascontiguousarray(bases[off:off + m])
+        for seed, shape in ((1, "uniform"), (2, "bits"), (3, "equal")):
+            sc = fr_array(m, 900 + seed)
+            if shape == "bits":
+                sc[0::2] = 0
+                sc[0::4, 0] = 1
+            elif shape == "equal":
+                sc[:] = sc[7]
+            ref = orc.jac_to_affine_int(orc.msm(sub, sc, threads=8))
+            assert _affine_of(ctx, orc, ctx.msm_g1(big, sc, offset=off)) == ref, (shape, m)
+    big.free()
+
+
+@pytest.mark.parametrize("n", [512, 1000, 4096, 12288, 40000])
+def test_msm_small_sets_low_latency_schedule(ctx, orc, n):
+    """Base sets from 512 points carry tables too (c = lg n + 2): short segments, lane-group fold, one bucket per lane.
+    Uniform, bit-heavy, all-equal and sparse scalars against the oracle, full length and a ragged sub-range."""
+    from pyref.prng import fr_array
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    for seed, shape in ((1, "uniform"), (2, "bits"), (3, "equal"), (4, "sparse")):
+        sc = fr_array(n, 7000 + seed + n)
         if shape == "bits":
             sc[0::2] = 0
             sc[0::4, 0] = 1
         elif shape == "equal":
-            sc[:] = sc[7]
-        a = _affine_of(ctx, orc, ctx.msm_g1(big, sc, offset=off))
-        b = _affine_of(ctx, orc, ctx.msm_g1(small, sc))
-        assert a == b, shape
-    big.free()
-    small.free()
+            sc[:] = sc[3]
+        elif shape == "sparse":
+            sc[:] = 0
+            sc[5::97] = fr_array(len(sc[5::97]), 1)
+        ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref, shape
+        lo, m = n // 3, n - n // 3 - 5
+        ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[lo:lo + m]), np.ascontiguousarray(sc[:m]), threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, np.ascontiguousarray(sc[:m]), offset=lo)) == ref, shape
+    bh.free()
