@@ -46,7 +46,7 @@ void drain_streams(swm_ctx* ctx) {
         if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
     for (int i = 0; i < swm_ctx::MSM_SLOTS; i++) ctx->slot_busy[i] = false;
     ctx->pending_tails.clear();
-    ctx->set_acc_event[0] = ctx->set_acc_event[1] = nullptr;
+    for (auto& e : ctx->set_acc_event) e = nullptr;
 }
 
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {

@@ -56,7 +56,7 @@ struct swm_ctx {
     bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
     hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (stage A -> stage T, deferred bucket stages)
     hipEvent_t sort_event[MSM_SLOTS] = {nullptr};  // "sorted" per slot (stage S -> stage A)
-    hipEvent_t set_acc_event[2] = {nullptr, nullptr};  // accumulation that last read each per-lane scratch set (not owned)
+    hipEvent_t set_acc_event[4] = {nullptr, nullptr, nullptr, nullptr};  // accumulation that last read each per-lane scratch set (not owned)
     std::vector<swm::MsmJob*> pending_tails;      // jobs whose bucket stage waits for msm_flush_tails
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)

@@ -388,9 +388,10 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     const G1Affine *b = nullptr, *b28 = nullptr;
     MsmTable tab;
     if (n) pk.bases_at(offset, n, &b, &b28, &tab);
-    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 2;
+    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 0;  // 0: msm_enqueue picks (two pipelined lanes, four for small MSMs)
     size_t lo = 0, hi = n;
     out->have_result = false;
+    out->result = g1_xyzz_identity();  // an empty range (n = 0, or a rank's empty shard) contributes the identity
     const bool force_exchange = getenv("SWM_SHARD_FORCE") != nullptr;  // test hook: exchange with a world of one
     out->sharded = ctx->shard_world > 1 || (force_exchange && (ctx->rccl_comm || ctx->shard_allgather));
     if (out->sharded) {
@@ -406,7 +407,7 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
     const long batch_below = batch_env >= 0 ? batch_env : (tab.t28 ? 200000 : 32768);
     tab.offset += lo;
-    rc_check(ctx, msm_enqueue(ctx, (*lane)++ % nlanes, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
+    rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));
 }
 // every commitment of a round is enqueued: run their bucket stages together
@@ -420,6 +421,20 @@ static G1XYZZ fold_ranks(const G1XYZZ* all, unsigned world) {
 // All commitments of a round at once (sharded proving only): wait for every job, then ONE all-gather of k partial sums
 // per rank (k x 192 bytes) instead of one exchange per commitment; commit_wait then finds the folded results.
 void commit_gather(swm_ctx* ctx, std::initializer_list<AsyncMsm*> jobs) {
+    // every job of the round is awaited once and the host folds run side by side (msm_finish_many)
+    std::vector<AsyncMsm*> todo;
+    for (AsyncMsm* a : jobs)
+        if (a && !a->have_result && a->job.active) todo.push_back(a);
+    if (!todo.empty()) {
+        std::vector<MsmJob*> mj(todo.size());
+        std::vector<G1XYZZ> res(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) mj[i] = &todo[i]->job;
+        rc_check(ctx, msm_finish_many(ctx, mj.data(), (int)mj.size(), res.data()));
+        for (size_t i = 0; i < todo.size(); i++) {
+            todo[i]->result = res[i];
+            todo[i]->have_result = !todo[i]->sharded;  // a sharded job's sum is still this rank's part
+        }
+    }
     std::vector<AsyncMsm*> sh;
     for (AsyncMsm* a : jobs)
         if (a && a->sharded && !a->have_result) sh.push_back(a);
@@ -427,7 +442,10 @@ void commit_gather(swm_ctx* ctx, std::initializer_list<AsyncMsm*> jobs) {
     const unsigned world = ctx->shard_world;
     const size_t k = sh.size();
     std::vector<G1XYZZ> mine(k), all(k * world);
-    for (size_t i = 0; i < k; i++) rc_check(ctx, msm_finish(ctx, &sh[i]->job, &mine[i]));
+    for (size_t i = 0; i < k; i++) {
+        if (sh[i]->job.active) rc_check(ctx, msm_finish(ctx, &sh[i]->job, &mine[i]));
+        else mine[i] = sh[i]->result;
+    }
     rc_check(ctx, shard_exchange(ctx, mine.data(), k * sizeof(G1XYZZ), all.data()));
     for (size_t i = 0; i < k; i++) {
         std::vector<G1XYZZ> col(world);
@@ -461,6 +479,8 @@ struct PolyRand {
 struct CommitJob {
     AsyncMsm plain, shifted;
     bool has_bound = false, hiding = false;
+    bool blinded = false;  // pc_commit_blind has drawn the blinding polynomials and computed the hiding terms
+    G1XYZZ blind_plain, blind_shifted;
 };
 void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
                      bool hiding, CommitJob* job) {
@@ -469,23 +489,33 @@ void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs
     commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
     if (has_bound) commit_enqueue(ctx, lane, pk, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
 }
-Commitment pc_commit_end(swm_ctx* ctx, const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
-    Commitment c;
-    G1XYZZ plain = commit_wait(ctx, &job->plain);
+// The blinding half of pc_commit_end: the draws (plain first, then shifted) and the hiding terms sum_j r_j gamma^j G —
+// host work (~70 us per term) that depends on the generator only, not on the MSM: the prover calls it for the round's
+// polynomials in label order while their MSMs are still running.
+void pc_commit_blind(const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
     pr->rand.clear();
     pr->shifted_rand.clear();
     pr->has_shifted = job->has_bound;
+    job->blind_plain = job->blind_shifted = g1_xyzz_identity();
     if (job->hiding) {
         for (int i = 0; i < 3; i++) pr->rand.push_back(rng->rand_fr());  // DensePolynomial::rand(hiding_bound + 1)
-        g1_add(plain, gamma_msm(pk, pr->rand));
+        job->blind_plain = gamma_msm(pk, pr->rand);
+        if (job->has_bound) {
+            for (int i = 0; i < 3; i++) pr->shifted_rand.push_back(rng->rand_fr());
+            job->blind_shifted = gamma_msm(pk, pr->shifted_rand);
+        }
     }
+    job->blinded = true;
+}
+Commitment pc_commit_end(swm_ctx* ctx, const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
+    Commitment c;
+    if (!job->blinded) pc_commit_blind(pk, job, rng, pr);
+    G1XYZZ plain = commit_wait(ctx, &job->plain);
+    if (job->hiding) g1_add(plain, job->blind_plain);
     c.comm = g1_to_affine(plain);
     if (job->has_bound) {
         G1XYZZ sh = commit_wait(ctx, &job->shifted);
-        if (job->hiding) {
-            for (int i = 0; i < 3; i++) pr->shifted_rand.push_back(rng->rand_fr());
-            g1_add(sh, gamma_msm(pk, pr->shifted_rand));
-        }
+        if (job->hiding) g1_add(sh, job->blind_shifted);
         c.has_shifted = true;
         c.shifted = g1_to_affine(sh);
     }
@@ -1023,8 +1053,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
         e_z = on_mul_domain(z_poly.p, H + 1);
     }
-    commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
     tr.tick("r1: pre-work enqueued");
+    // blinding draws and hiding terms (label order: w, z_a, z_b, mask) while the MSMs run
+    pc_commit_blind(pk, &j1[0], &zk, &P_w.rand);
+    pc_commit_blind(pk, &j1[1], &zk, &P_za.rand);
+    pc_commit_blind(pk, &j1[2], &zk, &P_zb.rand);
+    pc_commit_blind(pk, &j1[3], nullptr, &P_mask.rand);
+    commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
     comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
     tr.tick("r1: w done");
     comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
@@ -1117,6 +1152,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         // the sumcheck remainder check needs a download; do it while the MSMs run
         Fr rem0 = g1x.download(0, 1)[0];
         bool unsat = !fp_is_zero(rem0);
+        pc_commit_blind(pk, &j2[0], nullptr, &P_t.rand);
+        pc_commit_blind(pk, &j2[1], &zk, &P_g1.rand);
+        pc_commit_blind(pk, &j2[2], nullptr, &P_h1.rand);
         commit_gather(ctx, {&j2[0].plain, &j2[1].plain, &j2[1].shifted, &j2[2].plain});
         comms2[0] = pc_commit_end(ctx, pk, &j2[0], nullptr, &P_t.rand);
         comms2[1] = pc_commit_end(ctx, pk, &j2[1], &zk, &P_g1.rand);
@@ -1364,24 +1402,32 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         }
     }
     commit_flush(ctx);  // both opening points: up to four bucket stages, one launch
+    // hiding terms of the two witnesses and the random evaluations: host work that does not depend on the MSMs in flight
+    G1XYZZ hide[2];
+    PcProof pps[2];
+    for (int pi = 0; pi < 2; pi++) {
+        PointOpen& o = po[pi];
+        hide[pi] = g1_xyzz_identity();
+        if (!hp_is_zero(o.r_comb)) {
+            g1_add(hide[pi], gamma_msm(pk, hp_div_linear(o.r_comb, o.point)));
+            pps[pi].has_random_v = true;
+            pps[pi].random_v = host_poly_eval(o.r_comb, o.point);
+        }
+        if (!o.shifted_terms.empty()) {
+            if (!hp_is_zero(o.shifted_r_witness)) g1_add(hide[pi], gamma_msm(pk, o.shifted_r_witness));
+            if (!hp_is_zero(o.shifted_r) && pps[pi].has_random_v)
+                pps[pi].random_v = fp_add(pps[pi].random_v, host_poly_eval(o.shifted_r, o.point));
+        }
+    }
     commit_gather(ctx, {&po[0].wjob, po[0].sjobs.empty() ? nullptr : &po[0].sjobs[0], &po[1].wjob,
                         po[1].sjobs.empty() ? nullptr : &po[1].sjobs[0]});
     for (int pi = 0; pi < 2; pi++) {
         PointOpen& o = po[pi];
         G1XYZZ w = commit_wait(ctx, &o.wjob);
-        PcProof pp;
-        if (!hp_is_zero(o.r_comb)) {
-            g1_add(w, gamma_msm(pk, hp_div_linear(o.r_comb, o.point)));
-            pp.has_random_v = true;
-            pp.random_v = host_poly_eval(o.r_comb, o.point);
-        }
         for (size_t i = 0; i < o.shifted_terms.size(); i++) g1_add(w, commit_wait(ctx, &o.sjobs[i]));
-        if (!o.shifted_terms.empty()) {
-            if (!hp_is_zero(o.shifted_r_witness)) g1_add(w, gamma_msm(pk, o.shifted_r_witness));
-            if (!hp_is_zero(o.shifted_r) && pp.has_random_v) pp.random_v = fp_add(pp.random_v, host_poly_eval(o.shifted_r, o.point));
-        }
-        pp.w = g1_to_affine(w);
-        proof.pc_proof.push_back(pp);
+        g1_add(w, hide[pi]);
+        pps[pi].w = g1_to_affine(w);
+        proof.pc_proof.push_back(pps[pi]);
     }
     tr.mark("openings");
     proof.commitments = {comms1, comms2, comms3};

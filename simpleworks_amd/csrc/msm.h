@@ -71,6 +71,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
 int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k);
 int msm_flush_tails(swm_ctx* ctx);
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
+int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results);  // a round's jobs: one wait, folds side by side
 int msm_run(swm_ctx* ctx, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n, int mont,
             G1XYZZ* result, MsmInfMask inf = MsmInfMask(), MsmTable tab = MsmTable());
 

@@ -1303,11 +1303,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     static const size_t pipe_min = getenv("SWM_MSM_PIPE_MIN") ? (size_t)atol(getenv("SWM_MSM_PIPE_MIN")) : 131072;
     const bool one_stream = pipe_mode == 0 || n < pipe_min;
     if (lane >= 0) {
-        lane %= 2;
+        // small MSMs: four single-stream lanes (scratch sets 0 .. 3 on the streams 1, 2, 3, 0), so that the launch chains of
+        // all four commitments of a prover round proceed side by side; sets 0 and 1 are shared with the pipelined form,
+        // whose accumulations run on the same streams 1 and 2 (stream order covers the reuse)
+        static const int small_lanes = getenv("SWM_MSM_SMALL_LANES") ? std::min(4, std::max(1, atoi(getenv("SWM_MSM_SMALL_LANES")))) : 4;
+        lane %= one_stream ? small_lanes : 2;
         for (int i = 0; i < 4; i++)
             if (!ctx->aux_stream[i]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
         if (one_stream) {
-            st_sort = st_acc = st_tail = ctx->aux_stream[1 + lane];
+            st_sort = st_acc = st_tail = ctx->aux_stream[(1 + lane) % 4];
         } else {
             st_sort = ctx->aux_stream[0];
             st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + lane];
@@ -1617,30 +1621,22 @@ int msm_flush_tails(swm_ctx* ctx) {
     return SWM_OK;
 }
 
-int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
-    *result = g1_xyzz_identity();
-    if (!job->active) return SWM_OK;
+// Waits for a job's download, releases its slot and checks the status words.
+static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     if (job->tail_pending) SWM_TRY(msm_flush_tails(ctx));  // awaited before its round was flushed
-    static const bool trace = getenv("SWM_TRACE") != nullptr;
-    auto tw0 = std::chrono::steady_clock::now();
     SWM_HIP(ctx, hipEventSynchronize(job->done));
-    auto tw1 = std::chrono::steady_clock::now();
-    struct FoldTimer {
-        bool on;
-        std::chrono::steady_clock::time_point t0, t1;
-        size_t n;
-        ~FoldTimer() {
-            if (on)
-                fprintf(stderr, "[swm trace]   msm_finish n=%zu: waited %.3f ms, host fold %.3f ms\n", n,
-                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
-        }
-    } fold_timer{trace, tw0, tw1, job->n};
     job->active = false;
     ctx->slot_busy[job->slot] = false;
     ctx->stat_msm_adds += job->host_flags[1];  // entries the sort placed = non-zero digits
     if (job->host_flags[0])
         return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: a scalar is not a canonical field element (>= r)");
+    return SWM_OK;
+}
+
+// Host fold of a job's downloaded workgroup results.  `pool`: the context's host workers for the independent parts of
+// ONE job (null: serial — the caller is already folding several jobs side by side).  Returns false on an inconsistent
+// window layout (internal error).
+static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result) {
     // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per
     // workgroup; W_w by suffix sums over the <= 16 workgroups).  The windows are independent: they are folded on the
     // context's host workers.  Then Horner over the windows (high -> low, c_w doublings each), with the 2^shift of W_w
@@ -1666,19 +1662,18 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
         G1XYZZ sr;
         fold_range(job->host + (size_t)w * nb * 2, 0, nb, &sum_a[w], &sr, &weighted[w]);
     };
-    if (!ctx->host_pool && nb > 1) {
-        unsigned hw = std::thread::hardware_concurrency();
-        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
-    }
-    if (pl.nwin == 1 && nb > 16) {
+    auto run = [&](int n, const std::function<void(int)>& fn) {
+        if (pool) pool->parallel_for(n, fn);
+        else
+            for (int i = 0; i < n; i++) fn(i);
+    };
+    if (pl.nwin == 1 && nb > 16 && pool) {
         // flat schedule: one window, up to 256 workgroups.  Groups of 16 consecutive workgroups are folded in parallel;
         // with g0 = 16 g the first workgroup of group g:  sum blk R_blk = sum_g [W_g + 16 g SR_g], and sum_g g SR_g comes
         // from suffix sums over the groups, times 16 by four doublings.
         const unsigned G = (nb + 15) / 16;
         std::vector<G1XYZZ> ga(G), gr(G), gw(G);
-        ctx->host_pool->parallel_for((int)G, [&](int g) {
-            fold_range(job->host, 16u * g, std::min(nb, 16u * (g + 1)), &ga[g], &gr[g], &gw[g]);
-        });
+        run((int)G, [&](int g) { fold_range(job->host, 16u * g, std::min(nb, 16u * (g + 1)), &ga[g], &gr[g], &gw[g]); });
         G1XYZZ sa = g1_xyzz_identity(), wsum = g1_xyzz_identity(), suffix = g1_xyzz_identity(), gsum = g1_xyzz_identity();
         for (unsigned g = G; g-- > 0;) {
             g1_add(sa, ga[g]);
@@ -1691,7 +1686,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
         sum_a[0] = sa;
         weighted[0] = wsum;
     } else if (nb > 1 && pl.nwin > 1) {
-        ctx->host_pool->parallel_for((int)pl.nwin, fold_window);
+        run((int)pl.nwin, fold_window);
     } else {
         for (unsigned w = 0; w < pl.nwin; w++) fold_window((int)w);
     }
@@ -1704,13 +1699,65 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
                 g1_add(total_pt, weighted[w]);
                 cw = shift;
             } else {  // a window narrower than one workgroup's span cannot have content beyond workgroup 0
-                return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
+                return false;
             }
         }
         for (unsigned k = 0; k < cw; k++) total_pt = g1_dbl(total_pt);
         g1_add(total_pt, sum_a[w]);
     }
     *result = total_pt;
+    return true;
+}
+
+static HostPool* host_pool_of(swm_ctx* ctx) {
+    if (!ctx->host_pool) {
+        unsigned hw = std::thread::hardware_concurrency();
+        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
+    }
+    return ctx->host_pool;
+}
+
+int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
+    *result = g1_xyzz_identity();
+    if (!job->active) return SWM_OK;
+    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    auto tw0 = std::chrono::steady_clock::now();
+    SWM_TRY(msm_finish_wait(ctx, job));
+    auto tw1 = std::chrono::steady_clock::now();
+    if (!msm_fold(job, host_pool_of(ctx), result)) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
+    if (trace)
+        fprintf(stderr, "[swm trace]   msm_finish n=%zu: waited %.3f ms, host fold %.3f ms\n", job->n,
+                std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
+    return SWM_OK;
+}
+
+// Several jobs at once (the commitments of a prover round): wait for all of them, then fold them side by side, one job
+// per host worker (a fold is a serial chain of ~3 additions per workgroup result: four of them back to back were
+// ~0.25 ms between the last kernel of a round and its Fiat-Shamir challenge).
+int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
+    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    auto tw0 = std::chrono::steady_clock::now();
+    std::vector<int> live;
+    for (int i = 0; i < k; i++) {
+        results[i] = g1_xyzz_identity();
+        if (jobs[i] && jobs[i]->active) live.push_back(i);
+    }
+    int rc = SWM_OK;
+    for (int i : live) {  // every job is waited for and released even if one reports an error
+        int r = msm_finish_wait(ctx, jobs[i]);
+        if (rc == SWM_OK) rc = r;
+    }
+    if (rc != SWM_OK) return rc;
+    auto tw1 = std::chrono::steady_clock::now();
+    std::vector<char> ok(live.size(), 1);
+    host_pool_of(ctx)->parallel_for((int)live.size(), [&](int t) { ok[t] = msm_fold(jobs[live[t]], nullptr, &results[live[t]]); });
+    for (char c : ok)
+        if (!c) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
+    if (trace)
+        fprintf(stderr, "[swm trace]   msm_finish_many k=%zu: waited %.3f ms, host folds %.3f ms\n", live.size(),
+                std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
     return SWM_OK;
 }
 
