@@ -507,19 +507,57 @@ void pc_commit_blind(const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand*
     }
     job->blinded = true;
 }
-Commitment pc_commit_end(swm_ctx* ctx, const swm_pk& pk, CommitJob* job, ChaChaRng* rng, PolyRand* pr) {
-    Commitment c;
-    if (!job->blinded) pc_commit_blind(pk, job, rng, pr);
-    G1XYZZ plain = commit_wait(ctx, &job->plain);
-    if (job->hiding) g1_add(plain, job->blind_plain);
-    c.comm = g1_to_affine(plain);
-    if (job->has_bound) {
-        G1XYZZ sh = commit_wait(ctx, &job->shifted);
-        if (job->hiding) g1_add(sh, job->blind_shifted);
-        c.has_shifted = true;
-        c.shifted = g1_to_affine(sh);
+// XYZZ -> affine for several points with ONE field inversion (Montgomery's trick over the products ZZ * ZZZ): the
+// commitments of a round are normalised together, between its last kernel and the Fiat-Shamir challenge.
+void g1_to_affine_batch(const G1XYZZ* in, int k, G1Affine* out) {
+    std::vector<Fq> pref((size_t)k + 1);
+    pref[0] = fp_one<Fq>();
+    for (int i = 0; i < k; i++) pref[i + 1] = g1_is_inf(in[i]) ? pref[i] : fp_mul(pref[i], fp_mul(in[i].zz, in[i].zzz));
+    Fq inv = fp_inv(pref[k]);
+    for (int i = k; i-- > 0;) {
+        if (g1_is_inf(in[i])) {
+            out[i] = g1_affine_identity();
+            continue;
+        }
+        Fq zi = fp_mul(inv, pref[i]);  // 1 / (ZZ_i ZZZ_i)
+        inv = fp_mul(inv, fp_mul(in[i].zz, in[i].zzz));
+        out[i].x = fp_mul(in[i].x, fp_mul(zi, in[i].zzz));
+        out[i].y = fp_mul(in[i].y, fp_mul(zi, in[i].zz));
     }
-    return c;
+}
+// Waits for the commitments of a round (label order; pc_commit_blind already called or called here) and normalises them
+// together.
+void pc_commit_end_round(swm_ctx* ctx, const swm_pk& pk, std::initializer_list<CommitJob*> jobs,
+                         std::initializer_list<ChaChaRng*> rngs, std::initializer_list<PolyRand*> prs, Commitment* out) {
+    std::vector<G1XYZZ> pts;
+    std::vector<std::pair<int, bool>> where;  // (commitment index, shifted?)
+    auto rng = rngs.begin();
+    auto pr = prs.begin();
+    int idx = 0;
+    for (CommitJob* job : jobs) {
+        if (!job->blinded) pc_commit_blind(pk, job, *rng, *pr);
+        G1XYZZ plain = commit_wait(ctx, &job->plain);
+        if (job->hiding) g1_add(plain, job->blind_plain);
+        pts.push_back(plain);
+        where.push_back({idx, false});
+        out[idx] = Commitment();
+        if (job->has_bound) {
+            G1XYZZ sh = commit_wait(ctx, &job->shifted);
+            if (job->hiding) g1_add(sh, job->blind_shifted);
+            pts.push_back(sh);
+            where.push_back({idx, true});
+            out[idx].has_shifted = true;
+        }
+        ++rng;
+        ++pr;
+        ++idx;
+    }
+    std::vector<G1Affine> aff(pts.size());
+    g1_to_affine_batch(pts.data(), (int)pts.size(), aff.data());
+    for (size_t i = 0; i < pts.size(); i++) {
+        if (where[i].second) out[where[i].first].shifted = aff[i];
+        else out[where[i].first].comm = aff[i];
+    }
 }
 
 // ================================================================================================ setup
@@ -1060,14 +1098,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     pc_commit_blind(pk, &j1[2], &zk, &P_zb.rand);
     pc_commit_blind(pk, &j1[3], nullptr, &P_mask.rand);
     commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
-    comms1[0] = pc_commit_end(ctx, pk, &j1[0], &zk, &P_w.rand);
-    tr.tick("r1: w done");
-    comms1[1] = pc_commit_end(ctx, pk, &j1[1], &zk, &P_za.rand);
-    tr.tick("r1: z_a done");
-    comms1[2] = pc_commit_end(ctx, pk, &j1[2], &zk, &P_zb.rand);
-    tr.tick("r1: z_b done");
-    comms1[3] = pc_commit_end(ctx, pk, &j1[3], nullptr, &P_mask.rand);
-    tr.tick("r1: mask done");
+    pc_commit_end_round(ctx, pk, {&j1[0], &j1[1], &j1[2], &j1[3]}, {&zk, &zk, &zk, nullptr},
+                        {&P_w.rand, &P_za.rand, &P_zb.rand, &P_mask.rand}, comms1.data());
     tr.mark("round 1 commitments");
     fs_absorb_commitments(fs, comms1);
     VerifierState st;
@@ -1156,9 +1188,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         pc_commit_blind(pk, &j2[1], &zk, &P_g1.rand);
         pc_commit_blind(pk, &j2[2], nullptr, &P_h1.rand);
         commit_gather(ctx, {&j2[0].plain, &j2[1].plain, &j2[1].shifted, &j2[2].plain});
-        comms2[0] = pc_commit_end(ctx, pk, &j2[0], nullptr, &P_t.rand);
-        comms2[1] = pc_commit_end(ctx, pk, &j2[1], &zk, &P_g1.rand);
-        comms2[2] = pc_commit_end(ctx, pk, &j2[2], nullptr, &P_h1.rand);
+        pc_commit_end_round(ctx, pk, {&j2[0], &j2[1], &j2[2]}, {nullptr, &zk, nullptr}, {&P_t.rand, &P_g1.rand, &P_h1.rand},
+                            comms2.data());
         if (unsat) throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
     }
     tr.mark("round 2 commitments");
@@ -1260,8 +1291,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             poly_eval_async(ctx, lp->p, lp->n, ep_beta, slots.p + i);
         }
         commit_gather(ctx, {&j3[0].plain, &j3[0].shifted, &j3[1].plain});
-        comms3[0] = pc_commit_end(ctx, pk, &j3[0], nullptr, &P_g2.rand);
-        comms3[1] = pc_commit_end(ctx, pk, &j3[1], nullptr, &P_h2.rand);
+        pc_commit_end_round(ctx, pk, {&j3[0], &j3[1]}, {nullptr, nullptr}, {&P_g2.rand, &P_h2.rand}, comms3.data());
         tr.mark("round 3 commitments");
         fs_absorb_commitments(fs, comms3);
         st.gamma = fs.rand_fr();
@@ -1421,12 +1451,17 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     commit_gather(ctx, {&po[0].wjob, po[0].sjobs.empty() ? nullptr : &po[0].sjobs[0], &po[1].wjob,
                         po[1].sjobs.empty() ? nullptr : &po[1].sjobs[0]});
+    G1XYZZ wit[2];
+    G1Affine wit_aff[2];
     for (int pi = 0; pi < 2; pi++) {
         PointOpen& o = po[pi];
-        G1XYZZ w = commit_wait(ctx, &o.wjob);
-        for (size_t i = 0; i < o.shifted_terms.size(); i++) g1_add(w, commit_wait(ctx, &o.sjobs[i]));
-        g1_add(w, hide[pi]);
-        pps[pi].w = g1_to_affine(w);
+        wit[pi] = commit_wait(ctx, &o.wjob);
+        for (size_t i = 0; i < o.shifted_terms.size(); i++) g1_add(wit[pi], commit_wait(ctx, &o.sjobs[i]));
+        g1_add(wit[pi], hide[pi]);
+    }
+    g1_to_affine_batch(wit, 2, wit_aff);
+    for (int pi = 0; pi < 2; pi++) {
+        pps[pi].w = wit_aff[pi];
         proof.pc_proof.push_back(pps[pi]);
     }
     tr.mark("openings");

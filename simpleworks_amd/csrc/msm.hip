@@ -1633,10 +1633,42 @@ static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     return SWM_OK;
 }
 
+// over the workgroups blk in [lo, hi): sum of A, sum of R, and sum of (blk - lo) R_blk by suffix sums
+static void fold_range(const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out, G1XYZZ* sr_out, G1XYZZ* wt_out) {
+    G1XYZZ sa = g1_xyzz_identity(), suffix = g1_xyzz_identity(), wt = g1_xyzz_identity();
+    for (unsigned blk = hi; blk-- > lo;) {
+        g1_add(sa, h[2 * blk]);
+        g1_add(suffix, h[2 * blk + 1]);                // Suffix_blk = sum_{u >= blk} R_u
+        if (blk > lo) g1_add(wt, suffix);              // sum_{blk > lo} Suffix_blk = sum (blk - lo) R_blk
+    }
+    *sa_out = sa;
+    *sr_out = suffix;
+    *wt_out = wt;
+}
+// flat schedule: one window, up to 256 workgroups, folded in groups of 16 consecutive workgroups (independent: host
+// workers); with g0 = 16 g the first workgroup of group g:  sum blk R_blk = sum_g [W_g + 16 g SR_g], and sum_g g SR_g
+// comes from suffix sums over the groups, times 16 by four doublings.
+static constexpr unsigned FOLD_GROUP = 16;
+static void fold_groups_combine(const G1XYZZ* ga, const G1XYZZ* gr, const G1XYZZ* gw, unsigned G, G1XYZZ* sum_a, G1XYZZ* weighted) {
+    G1XYZZ sa = g1_xyzz_identity(), wsum = g1_xyzz_identity(), suffix = g1_xyzz_identity(), gsum = g1_xyzz_identity();
+    for (unsigned g = G; g-- > 0;) {
+        g1_add(sa, ga[g]);
+        g1_add(wsum, gw[g]);
+        g1_add(suffix, gr[g]);
+        if (g > 0) g1_add(gsum, suffix);  // sum_g g SR_g
+    }
+    for (int k = 0; k < 4; k++) gsum = g1_dbl(gsum);
+    static_assert(FOLD_GROUP == 16, "four doublings");
+    g1_add(wsum, gsum);
+    *sum_a = sa;
+    *weighted = wsum;
+}
+
 // Host fold of a job's downloaded workgroup results.  `pool`: the context's host workers for the independent parts of
 // ONE job (null: serial — the caller is already folding several jobs side by side).  Returns false on an inconsistent
 // window layout (internal error).
-static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result) {
+// `groups` (flat schedule, more than one group): the group sums (ga | gr | gw, G each) were already computed by the caller.
+static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1XYZZ* groups = nullptr) {
     // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per
     // workgroup; W_w by suffix sums over the <= 16 workgroups).  The windows are independent: they are folded on the
     // context's host workers.  Then Horner over the windows (high -> low, c_w doublings each), with the 2^shift of W_w
@@ -1646,18 +1678,6 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result) {
     unsigned shift = job->log_m;
     for (unsigned v = job->rb; v > 1; v >>= 1) shift++;
     G1XYZZ sum_a[MAX_WIN], weighted[MAX_WIN];
-    auto fold_range = [&](const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out, G1XYZZ* sr_out, G1XYZZ* wt_out) {
-        // over the workgroups blk in [lo, hi): sum of A, sum of R, and sum of (blk - lo) R_blk by suffix sums
-        G1XYZZ sa = g1_xyzz_identity(), suffix = g1_xyzz_identity(), wt = g1_xyzz_identity();
-        for (unsigned blk = hi; blk-- > lo;) {
-            g1_add(sa, h[2 * blk]);
-            g1_add(suffix, h[2 * blk + 1]);                // Suffix_blk = sum_{u >= blk} R_u
-            if (blk > lo) g1_add(wt, suffix);              // sum_{blk > lo} Suffix_blk = sum (blk - lo) R_blk
-        }
-        *sa_out = sa;
-        *sr_out = suffix;
-        *wt_out = wt;
-    };
     auto fold_window = [&](int w) {
         G1XYZZ sr;
         fold_range(job->host + (size_t)w * nb * 2, 0, nb, &sum_a[w], &sr, &weighted[w]);
@@ -1667,24 +1687,18 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result) {
         else
             for (int i = 0; i < n; i++) fn(i);
     };
-    if (pl.nwin == 1 && nb > 16 && pool) {
-        // flat schedule: one window, up to 256 workgroups.  Groups of 16 consecutive workgroups are folded in parallel;
-        // with g0 = 16 g the first workgroup of group g:  sum blk R_blk = sum_g [W_g + 16 g SR_g], and sum_g g SR_g comes
-        // from suffix sums over the groups, times 16 by four doublings.
-        const unsigned G = (nb + 15) / 16;
-        std::vector<G1XYZZ> ga(G), gr(G), gw(G);
-        run((int)G, [&](int g) { fold_range(job->host, 16u * g, std::min(nb, 16u * (g + 1)), &ga[g], &gr[g], &gw[g]); });
-        G1XYZZ sa = g1_xyzz_identity(), wsum = g1_xyzz_identity(), suffix = g1_xyzz_identity(), gsum = g1_xyzz_identity();
-        for (unsigned g = G; g-- > 0;) {
-            g1_add(sa, ga[g]);
-            g1_add(wsum, gw[g]);
-            g1_add(suffix, gr[g]);
-            if (g > 0) g1_add(gsum, suffix);  // sum_g g SR_g
+    if (pl.nwin == 1 && nb > FOLD_GROUP && (pool || groups)) {
+        const unsigned G = (nb + FOLD_GROUP - 1) / FOLD_GROUP;
+        std::vector<G1XYZZ> own;
+        if (!groups) {
+            own.resize(3 * (size_t)G);
+            G1XYZZ* o = own.data();
+            run((int)G, [&](int g) {
+                fold_range(job->host, FOLD_GROUP * g, std::min(nb, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
+            });
+            groups = o;
         }
-        for (int k = 0; k < 4; k++) gsum = g1_dbl(gsum);
-        g1_add(wsum, gsum);
-        sum_a[0] = sa;
-        weighted[0] = wsum;
+        fold_groups_combine(groups, groups + G, groups + 2 * G, G, &sum_a[0], &weighted[0]);
     } else if (nb > 1 && pl.nwin > 1) {
         run((int)pl.nwin, fold_window);
     } else {
@@ -1750,8 +1764,38 @@ int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
     }
     if (rc != SWM_OK) return rc;
     auto tw1 = std::chrono::steady_clock::now();
+    // tasks: one per group of 16 workgroup results of a flat job, one per job otherwise
+    struct Task {
+        int job;
+        int group;  // -1: the whole job
+    };
+    std::vector<Task> tasks;
+    std::vector<std::vector<G1XYZZ>> groups(live.size());
+    for (size_t t = 0; t < live.size(); t++) {
+        const MsmJob* j = jobs[live[t]];
+        if (j->pl.nwin == 1 && j->red_blocks > FOLD_GROUP) {
+            const unsigned G = (j->red_blocks + FOLD_GROUP - 1) / FOLD_GROUP;
+            groups[t].resize(3 * (size_t)G);
+            for (unsigned g = 0; g < G; g++) tasks.push_back({(int)t, (int)g});
+        } else {
+            tasks.push_back({(int)t, -1});
+        }
+    }
     std::vector<char> ok(live.size(), 1);
-    host_pool_of(ctx)->parallel_for((int)live.size(), [&](int t) { ok[t] = msm_fold(jobs[live[t]], nullptr, &results[live[t]]); });
+    host_pool_of(ctx)->parallel_for((int)tasks.size(), [&](int i) {
+        const Task& tk = tasks[i];
+        const MsmJob* j = jobs[live[tk.job]];
+        if (tk.group < 0) {
+            ok[tk.job] = msm_fold(j, nullptr, &results[live[tk.job]]);
+        } else {
+            const unsigned G = (j->red_blocks + FOLD_GROUP - 1) / FOLD_GROUP, g = (unsigned)tk.group;
+            G1XYZZ* o = groups[tk.job].data();
+            fold_range(j->host, FOLD_GROUP * g, std::min(j->red_blocks, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
+        }
+    });
+    host_pool_of(ctx)->parallel_for((int)live.size(), [&](int t) {  // per job: the combine of its group sums
+        if (!groups[t].empty()) ok[t] = msm_fold(jobs[live[t]], nullptr, &results[live[t]], groups[t].data());
+    });
     for (char c : ok)
         if (!c) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
     if (trace)
