@@ -445,6 +445,87 @@ inline void poly_eval_async(swm_ctx* ctx, const Fr* p, size_t n, const EvalPoint
         len = ntiles;
     }
 }
+// Several polynomials at the SAME point in one launch per level (the evaluation phase of a proof reads ~20 polynomials
+// at beta and ~6 at gamma: one launch each was 70 launches of ~25 us for a small proof).  Same tiles, same arithmetic
+// and the same order of additions as eval_chunks, so the values are bit-identical to poly_eval_async's.
+static constexpr int EVAL_MANY = 32;
+struct EvalBatch {
+    const Fr* c[EVAL_MANY];
+    size_t n[EVAL_MANY];
+    Fr* out[EVAL_MANY];
+};
+static __global__ void __launch_bounds__(256) eval_chunks_many(EvalBatch b, Fr x256, const Fr* __restrict__ xpow) {
+    __shared__ Fr sm[256];
+    const Fr* __restrict__ c = b.c[blockIdx.y];
+    const size_t n = b.n[blockIdx.y];
+    const size_t base = (size_t)blockIdx.x * EVAL_TILE;
+    if (base >= n) return;  // this polynomial has fewer tiles than the longest of the batch (uniform per workgroup)
+    const unsigned t = threadIdx.x;
+    Fr acc = fp_zero<Fr>();
+#pragma unroll 1
+    for (int j = EVAL_PER - 1; j >= 0; j--) {
+        size_t k = base + (size_t)j * 256 + t;
+        acc = fp_mul(acc, x256);
+        if (k < n) acc = fp_add(acc, c[k]);
+    }
+    sm[t] = fp_mul(acc, xpow[t]);
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fp_add(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) b.out[blockIdx.y][blockIdx.x] = sm[0];
+}
+struct EvalItem {
+    const Fr* p;
+    size_t n;
+    Fr* d_result;
+};
+inline void poly_eval_many(swm_ctx* ctx, const std::vector<EvalItem>& items, const EvalPoint& ep) {
+    std::vector<EvalItem> cur;
+    for (const EvalItem& it : items) {
+        if (it.n == 0) hip_check(ctx, hipMemsetAsync(it.d_result, 0, sizeof(Fr), ctx->stream), "memset");
+        else cur.push_back(it);
+    }
+    std::vector<DVec> keep;  // intermediate tile sums stay alive until the last level has been enqueued
+    for (int level = 0; !cur.empty(); level++) {
+        if (level >= 3) throw MarlinError(SWM_ERR_INTERNAL, "poly_eval: polynomial too long");
+        size_t total_tiles = 0;
+        for (const EvalItem& it : cur)
+            if (it.n > (size_t)EVAL_TILE) total_tiles += (it.n + EVAL_TILE - 1) / EVAL_TILE;
+        DVec tmp;
+        if (total_tiles) tmp = DVec(ctx, total_tiles);
+        size_t used = 0;
+        std::vector<EvalItem> next;
+        for (size_t lo = 0; lo < cur.size(); lo += EVAL_MANY) {
+            const size_t k = std::min<size_t>(EVAL_MANY, cur.size() - lo);
+            EvalBatch b;
+            memset(&b, 0, sizeof(b));
+            size_t max_tiles = 1;
+            for (size_t j = 0; j < k; j++) {
+                const EvalItem& it = cur[lo + j];
+                const size_t ntiles = (it.n + EVAL_TILE - 1) / EVAL_TILE;
+                b.c[j] = it.p;
+                b.n[j] = it.n;
+                if (ntiles > 1) {
+                    b.out[j] = tmp.p + used;
+                    next.push_back({tmp.p + used, ntiles, it.d_result});
+                    used += ntiles;
+                } else {
+                    b.out[j] = it.d_result;
+                }
+                max_tiles = std::max(max_tiles, ntiles);
+            }
+            prof_begin(ctx, "poly_eval");
+            hipLaunchKernelGGL(eval_chunks_many, dim3((unsigned)max_tiles, (unsigned)k), dim3(256), 0, ctx->stream, b,
+                               ep.y256[level], ep.pw[level].p);
+            prof_end(ctx);
+            hip_check(ctx, hipGetLastError(), "poly_eval");
+        }
+        if (total_tiles) keep.push_back(std::move(tmp));
+        cur.swap(next);
+    }
+}
 // returns p(x) on the host (synchronises)
 inline Fr poly_eval(swm_ctx* ctx, const Fr* p, size_t n, Fr x) {
     EvalPoint ep = eval_point(ctx, x);

@@ -1285,11 +1285,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         want.push_back({"h_2", true});
         DVec slots(ctx, want.size());
         EvalPoint ep_beta = eval_point(ctx, beta);
+        std::vector<EvalItem> at_beta;
         for (size_t i = 0; i < want.size(); i++) {
             if (want[i].second) continue;
             LPoly* lp = polys.at(want[i].first);
-            poly_eval_async(ctx, lp->p, lp->n, ep_beta, slots.p + i);
+            at_beta.push_back({lp->p, lp->n, slots.p + i});
         }
+        poly_eval_many(ctx, at_beta, ep_beta);
         commit_gather(ctx, {&j3[0].plain, &j3[0].shifted, &j3[1].plain});
         pc_commit_end_round(ctx, pk, {&j3[0], &j3[1]}, {nullptr, nullptr}, {&P_g2.rand, &P_h2.rand}, comms3.data());
         tr.mark("round 3 commitments");
@@ -1297,11 +1299,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         st.gamma = fs.rand_fr();
         // part 2: the evaluations at gamma
         EvalPoint ep_gamma = eval_point(ctx, st.gamma);
+        std::vector<EvalItem> at_gamma;
         for (size_t i = 0; i < want.size(); i++) {
             if (!want[i].second) continue;
             LPoly* lp = polys.at(want[i].first);
-            poly_eval_async(ctx, lp->p, lp->n, ep_gamma, slots.p + i);
+            at_gamma.push_back({lp->p, lp->n, slots.p + i});
         }
+        poly_eval_many(ctx, at_gamma, ep_gamma);
         std::vector<Fr> vals = slots.download(0, want.size());
         for (size_t i = 0; i < want.size(); i++) eval_cache[want[i]] = vals[i];
     }
