@@ -52,6 +52,7 @@ struct swm_ctx {
     hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
+    void* pinned_dev = nullptr;  // device address of `pinned`
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
     bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
     hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (stage A -> stage T, deferred bucket stages)

@@ -50,6 +50,9 @@ struct MsmJob {
     G1XYZZ *d_partial = nullptr, *d_wpart = nullptr;
     const uint32_t *d_seg_off = nullptr, *d_status = nullptr, *d_entries = nullptr;
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
+    G1XYZZ* host_dev = nullptr;          // the same slot as the device addresses it (the bucket stage writes there)
+    uint32_t* host_flags_dev = nullptr;
+    bool zero_copy = false;              // results written by the bucket stage into the pinned slot (no copies)
     const uint32_t* host_flags = nullptr;  // tail of the slot: [0] != 0 when a scalar was not a canonical field element
     hipEvent_t done = nullptr;
 };

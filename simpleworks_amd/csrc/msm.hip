@@ -1024,6 +1024,8 @@ struct TailJob {
     const uint32_t* seg_off;
     G1XYZZ* out;
     unsigned log_m, red_blocks, big_nseg;
+    const uint32_t *status, *entries;  // device status words of the job, forwarded to ...
+    uint32_t* host_flags;              // ... the tail of its pinned result slot
     WinLayout L;
 };
 struct TailBatch {
@@ -1141,9 +1143,15 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
         }
     }
     if (t == 0) {
+        // `out` is the job's PINNED host slot (zero-copy: 384 B per workgroup over the fabric instead of three
+        // stream-ordered copies per job after the kernel — ~25 us per job between a round's last kernel and its challenge)
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
         p28_store_384(out[o], p28_load(sm_acc[0]));
         p28_store_384(out[o + 1], p28_load(sm_r[0]));
+        if (blockIdx.x == 0 && w == 0 && job.host_flags) {
+            job.host_flags[0] = *job.status;
+            job.host_flags[1] = *job.entries;
+        }
     }
 }
 
@@ -1327,7 +1335,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const size_t slot_bytes = (size_t)MAX_WIN * 32 * sizeof(G1XYZZ) + 64;  // up to 1024 (A, R) pairs + status words
     const size_t flags_off = slot_bytes - 16;  // the last 16 bytes of a slot carry the status words of the job
     if ((size_t)rl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
-    if (!ctx->pinned) SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocDefault));
+    if (!ctx->pinned) {  // coherent + mapped: the bucket stage writes its results straight into the slots
+        SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocCoherent | hipHostMallocMapped));
+        SWM_HIP(ctx, hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0));
+    }
     int slot = ctx->next_slot;
     if (ctx->slot_busy[slot])  // its previous job has not been collected: the download would overwrite live results
         return set_err(ctx, SWM_ERR_INTERNAL, "msm: more than %d jobs in flight", swm_ctx::MSM_SLOTS);
@@ -1336,6 +1347,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->slot = slot;
     job->host = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned + slot_bytes * slot);
     job->host_flags = reinterpret_cast<const uint32_t*>((char*)job->host + flags_off);
+    job->host_dev = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned_dev + slot_bytes * slot);
+    job->host_flags_dev = reinterpret_cast<uint32_t*>((char*)job->host_dev + flags_off);
+    // the bucket stage writes its results straight into the pinned slot (see msm_bucket_reduce; SWM_MSM_ZERO_COPY=0: the
+    // stream-ordered copies — measured r02 on one box: 2^16 proofs 11.8 vs 11.4 ms, 2^20 75.7 vs 75.1 ms)
+    static const int zc_env = getenv("SWM_MSM_ZERO_COPY") ? atoi(getenv("SWM_MSM_ZERO_COPY")) : -1;
+    job->zero_copy = zc_env != 0;
     job->done = ctx->slot_event[slot];
     if (!ctx->acc_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->acc_event[slot], hipEventDisableTiming));
     job->acc_done = ctx->acc_event[slot];
@@ -1578,7 +1595,10 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         if (j->acc_done && j->stream != nullptr && j->needs_acc_wait) SWM_HIP(ctx, hipStreamWaitEvent(st, j->acc_done, 0));
         batch.j[i].partial = j->d_partial;
         batch.j[i].seg_off = j->d_seg_off;
-        batch.j[i].out = j->d_wpart;
+        batch.j[i].out = j->zero_copy ? j->host_dev : j->d_wpart;
+        batch.j[i].status = j->d_status;
+        batch.j[i].entries = j->d_entries;
+        batch.j[i].host_flags = j->zero_copy ? j->host_flags_dev : nullptr;
         batch.j[i].log_m = j->log_m;
         batch.j[i].red_blocks = j->red_blocks;
         batch.j[i].big_nseg = j->big_nseg;
@@ -1596,6 +1616,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
     }
     for (int i = 0; i < k; i++) {
         MsmJob* j = jobs[i];
+        if (j->zero_copy) continue;
         SWM_HIP(ctx, hipMemcpyAsync(j->host, j->d_wpart, (size_t)j->pl.nwin * j->red_blocks * 2 * sizeof(G1XYZZ),
                                     hipMemcpyDeviceToHost, st));
         SWM_HIP(ctx, hipMemcpyAsync((void*)j->host_flags, j->d_status, 4, hipMemcpyDeviceToHost, st));
