@@ -950,6 +950,50 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     FiatShamirRng fs;
     fs_init(fs, pk.vk, public_input);
 
+    // ---- the zero-knowledge draws of round 1 do not depend on the witness: rho_w, rho_a, rho_b, then the mask polynomial
+    // (arkworks' order).  The mask is sampled and its commitment — the largest MSM of the round, 3|H| points — enqueued
+    // BEFORE the witness upload: a pageable host buffer of 32 MB per 2^20 variables takes ~5 ms to reach HBM, during
+    // which the GPU had nothing to do (r02 timeline).
+    const Fr rho_w = zk.rand_fr(), rho_a = zk.rand_fr(), rho_b = zk.rand_fr();
+    LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
+    int lane = 0;
+    // Every commitment MSM is enqueued as soon as its polynomial exists.  SWM_COMMIT_LATE=1 (experiment, r02): enqueue the
+    // commitments of a round together once ALL its polynomials are built.  The idea: an accumulation in flight holds every
+    // SIMD's register file (3 waves x 168 VGPRs) for ~1.5 ms per wave, so transforms issued beside it wait for retiring
+    // waves and run 3-5x slower than alone (25 ms of ntt_pass event time per 2^20 proof against 5 ms stand-alone).
+    // Measured: no gain (2^20: 77.6 vs 76.1 ms early, 2^18: 33.3 vs 32.2) — the early MSMs cover more than the slowed
+    // transforms cost.
+    static const bool commit_early = getenv("SWM_COMMIT_LATE") == nullptr;
+    std::vector<std::function<void()>> late;
+    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job) {
+        if (commit_early) {
+            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
+        } else {
+            late.push_back([&, coeffs, n, has_bound, bound, hiding, job] {
+                pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
+            });
+        }
+    };
+    auto flush_commits = [&] {
+        for (auto& f : late) f();
+        late.clear();
+        commit_flush(ctx);
+    };
+    CommitJob j1[4];
+    // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
+    const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
+    DVec mask(ctx, mask_len);
+    sample_fr_bulk(ctx, zk, mask.p, mask_len);
+    {
+        Fr* mp = mask.p;
+        ew(ctx, "mask_fix", 1, [=] __device__(size_t) {
+            // remainder mod v_H at coefficient 0 = c[0] + c[H] + c[2H]; subtracting it from c[0] leaves -(c[H] + c[2H])
+            mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
+        });
+    }
+    P_mask.p = mask.p; P_mask.n = mask_len;
+    begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+
     // ---- z on the device, z_A = A z, z_B = B z  (K3)
     DVec z(ctx, nvars);
     hip_check(ctx, hipMemcpyAsync(z.p, pr.inst.data(), ninst * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
@@ -1000,40 +1044,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             poly[H] = fp_add(poly[H], rho);
         });
     };
-    Fr rho_w = zk.rand_fr();
     add_rho_vh(w_poly.p, rho_w);
     // divide by v_X (exact): quotient = strided suffix sums, w_poly <- quotient (degree <= H - X)
     suffix_recurrence(ctx, w_poly.p, H + 1, X, fr_one());
     const Fr* w_coeffs = w_poly.p + X;  // quotient[j] = s[j + X]
     const size_t w_len = H + 1 - X;
-    LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
-    int lane = 0;
-    // Every commitment MSM is enqueued as soon as its polynomial exists.  SWM_COMMIT_LATE=1 (experiment, r02): enqueue the
-    // commitments of a round together once ALL its polynomials are built.  The idea: an accumulation in flight holds every
-    // SIMD's register file (3 waves x 168 VGPRs) for ~1.5 ms per wave, so transforms issued beside it wait for retiring
-    // waves and run 3-5x slower than alone (25 ms of ntt_pass event time per 2^20 proof against 5 ms stand-alone).
-    // Measured: no gain (2^20: 77.6 vs 76.1 ms early, 2^18: 33.3 vs 32.2) — the early MSMs cover more than the slowed
-    // transforms cost.
-    static const bool commit_early = getenv("SWM_COMMIT_LATE") == nullptr;
-    std::vector<std::function<void()>> late;
-    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job) {
-        if (commit_early) {
-            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
-        } else {
-            late.push_back([&, coeffs, n, has_bound, bound, hiding, job] {
-                pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
-            });
-        }
-    };
-    auto flush_commits = [&] {
-        for (auto& f : late) f();
-        late.clear();
-        commit_flush(ctx);
-    };
-    CommitJob j1[4];
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
     begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0]);
-    Fr rho_a = zk.rand_fr();
     DVec za_poly = dv_zeros(ctx, H + 1);
     {
         dv_ntt(ctx, za_evals, pk.logH, true);
@@ -1042,7 +1059,6 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
     begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
-    Fr rho_b = zk.rand_fr();
     DVec zb_poly = dv_zeros(ctx, H + 1);
     {
         dv_ntt(ctx, zb_evals, pk.logH, true);
@@ -1051,21 +1067,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
     begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
-    // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
-    const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
-    DVec mask(ctx, mask_len);
-    sample_fr_bulk(ctx, zk, mask.p, mask_len);
-    {
-        Fr* mp = mask.p;
-        ew(ctx, "mask_fix", 1, [=] __device__(size_t) {
-            // remainder mod v_H at coefficient 0 = c[0] + c[H] + c[2H]; subtracting it from c[0] leaves -(c[H] + c[2H])
-            mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
-        });
-    }
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
-    P_mask.p = mask.p; P_mask.n = mask_len;
-    begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
     flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
