@@ -1390,12 +1390,16 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     uint32_t big_nseg = BIG_NSEG;
     unsigned log_g = 8;
     if (lat) {
-        big_nseg = 2;
+        // every bucket with more than two segments below 2^16 points; from there (16-point segments, 1 - 2 per bucket) only
+        // the rare long ones: listing ~2 % of the buckets cost a ~120-us launch per MSM for a two-step shorter walk
+        // (r02: 2^16 proofs 11.5 -> 10.8 ms)
+        big_nseg = n < 65536 ? 2 : 6;
         const size_t per_bucket = total / ((size_t)pl.NB * SEG) + 1;  // expected segments per bucket
         log_g = 2;
         while (log_g < 6 && ((size_t)1 << log_g) < 2 * per_bucket) log_g++;
     }
     if (const char* e = getenv("SWM_MSM_LOGG")) log_g = std::min(8, std::max(0, atoi(e)));
+    if (const char* e = getenv("SWM_MSM_BIG_NSEG")) big_nseg = (uint32_t)std::max(1, atoi(e));
     job->big_nseg = big_nseg;
     const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
