@@ -18,6 +18,7 @@ all ranks: every commitment MSM split by point range, partial sums all-gathered,
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -375,7 +376,8 @@ def main():
         # MI355X_MICROARCH.md); taken from the newest committed PMC summary under profiles/ and scaled per point.
         traffic, traffic_source = None, None
         try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_msm_accumulate.json"))
+            pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc_msm_accumulate\.json", f)),
+                          key=lambda f: int(f[1:f.index("_")]))
             if pmcs:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
                 traffic = pmc["hbm_bytes_per_point"] * (alg_bytes / 128.0)

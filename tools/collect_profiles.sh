@@ -18,5 +18,5 @@ rocprofv3 --kernel-trace --stats -d $out/prof_msm -o run --output-format csv -- 
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_fetch -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_write -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
 python3 tools/ubench/ntt_time.py > $out/ntt_time.log 2>&1
-python3 tools/small_proofs.py 12 14 16 18 > $out/small_proofs.log 2>&1
+python3 tools/small_proofs.py 10 12 14 16 18 > $out/small_proofs.log 2>&1
 ls -R $out | head -40

@@ -47,9 +47,10 @@ json.dump({"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "kernel
                       "python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline   (tools/collect_profiles.sh)",
            "points_per_launch": n, "hbm_bytes_per_launch": (f + w) * 1024, "hbm_bytes_per_point": (f + w) * 1024 / n,
            "note": "FETCH_SIZE taken at face value (KB): the access pattern is 6 x 16-B loads per lane into random 96-B "
-                   "records, i.e. two 64-B requests per record; 16.8M records x 128 B = 2.1 GB matches the counter, so the x2 "
-                   "correction the guide gives for wide coalesced streams does not apply. Re-reading every base once per "
-                   "window (16 windows at c = 16) is inherent to the bucket method; the 100 MB base table is Infinity-Cache "
-                   "resident, so most of this is fabric (MALL) traffic, not DRAM. Writes: one 192-B partial sum per bucket "
-                   "(524 k buckets)."}, open(os.path.join(p, pre + "_pmc_msm_accumulate.json"), "w"), indent=1)
+                   "records, i.e. two 64-B requests per record; 13 windows x 2^20 records x 128 B = 1.7 GB matches the counter, so "
+                   "the x2 correction the guide gives for wide coalesced streams does not apply. One table row per (point, window) "
+                   "is inherent to the precomputed-window schedule (13 windows at c = 20): the table of a 2^20-point base set is "
+                   "13 x 100 MB, larger than the Infinity Cache, so this is DRAM traffic (0.9 TB/s at 2.0 ms per launch: 11 % of "
+                   "the HBM peak; the kernel is bound by integer issue, see DESIGN.md section 3). Writes: one 192-B partial sum "
+                   "per segment."}, open(os.path.join(p, pre + "_pmc_msm_accumulate.json"), "w"), indent=1)
 print("traffic B/point", (f + w) * 1024 / n)
