@@ -420,8 +420,14 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
                                                            uint32_t toff, unsigned fb, uint32_t nbins,
                                                            const uint32_t* __restrict__ bin_off, uint32_t* __restrict__ bin_cursor,
                                                            uint2* __restrict__ tmp) {
-    __shared__ uint32_t cnt[FLAT_MAX_BINS], start[FLAT_MAX_BINS], gpos[FLAT_MAX_BINS], scan[1024];
+    // LDS: PART_TILE pairs | cnt, start, gpos (nbins words each, rounded up to a multiple of 4) | 1024 scan words: sized by
+    // the bin count of the call (74 KB at 512 bins: two workgroups per CU; the fixed 4096-bin arrays allowed one)
     extern __shared__ uint2 stage[];  // PART_TILE pairs
+    const uint32_t nb4 = (nbins + 3) & ~3u;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PART_TILE);
+    uint32_t* start = cnt + nb4;
+    uint32_t* gpos = start + nb4;
+    uint32_t* scan = gpos + nb4;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
     const size_t lo = (size_t)blockIdx.x * PART_TILE;
     for (uint32_t b = t; b < nbins; b += 1024) cnt[b] = 0;
@@ -1498,14 +1504,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
         uint32_t ctile = 65536;  // digits per workgroup of the coarse histogram: at least ~256 workgroups
         while (ctile > 4096 && (size_t)ctile * 256 > total) ctile >>= 1;
-        SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, (size_t)PART_TILE * sizeof(uint2)));
+        const size_t lds_part = (size_t)PART_TILE * sizeof(uint2) + (3 * (size_t)((flat_bins + 3) & ~3u) + 1024) * 4;
+        SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, lds_part));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((total + ctile - 1) / ctile)), dim3(SORT_THREADS), 0,
                    digits, total, flat_fb, flat_bins, ctile, flat_cnt);
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off);
         SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
-                   dim3(1024), (size_t)PART_TILE * sizeof(uint2), digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, flat_fb,
+                   dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, flat_fb,
                    flat_bins, flat_off, flat_cur, pairs);
         SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
                    (const uint2*)pairs, flat_fb, pl.NB, flat_off, hist, sorted);
