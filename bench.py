@@ -427,7 +427,8 @@ def main():
                          # explanatory figure: the kernel is bound by integer issue, not by HBM —
                          # mixed additions per second against the ceiling its instruction mix allows
                          # (3423 v_mad_u64_u32 + 677 64-bit shift/adds at 4.2 cycles, ~870 32-bit ops at 2.3, per
-                         # wave-addition; 1024 SIMDs at 2.4 GHz)
+                         # wave-addition; 1024 SIMDs at 2.4 GHz; the mix is the hot block `tools/isa_mix.py
+                         # simpleworks_amd/csrc/msm.hip msm_accumulate` prints)
                          # msm_adds = NON-ZERO digits (bucket entries), counted by the sort on the device
                          "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
                          "issue_ceiling_mixed_adds_per_s": 8.2e9},
