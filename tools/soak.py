@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 from simpleworks_amd import marlin as M, workloads as W
 rng = M.generate_rand()
 keys = []
-for lg in (12, 16, 18, 20):
+for lg in (10, 12, 14, 16, 17, 18, 20):
     n = 1 << lg
     srs = M.generate_universal_srs(n, n, n, rng)
     cs, public = W.synthetic_r1cs(n, 0x99 + lg, 0x1234)
