@@ -1322,8 +1322,19 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // whose accumulations run on the same streams 1 and 2 (stream order covers the reuse)
         static const int small_lanes = getenv("SWM_MSM_SMALL_LANES") ? std::min(4, std::max(1, atoi(getenv("SWM_MSM_SMALL_LANES")))) : 4;
         lane %= one_stream ? small_lanes : 2;
-        for (int i = 0; i < 4; i++)
-            if (!ctx->aux_stream[i]) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
+        if (!ctx->aux_stream[0]) {
+            // Hardware-queue placement.  ROCm 7 hands its hardware queues (four by default) to streams in creation order,
+            // bouncing: 1, 2, 3, 4, 4, 3, 2, 1, ... (rocprofv3 Queue_Id, r02).  With the context's stream and the null stream
+            // first, four auxiliary streams created in a row put the sort and the tail stream on ONE queue: tail(k) and
+            // sort(k+1) — the two phases that run between consecutive accumulations — executed one after the other.  A
+            // placeholder stream created before the tail stream moves the tail to the queue of the (idle) null stream;
+            // the two accumulation streams share a queue either way (accumulations cannot overlap: each fills the register
+            // files).  SWM_MSM_QUEUE_ORDER=0 keeps the plain creation order.
+            static const bool steer = !(getenv("SWM_MSM_QUEUE_ORDER") && atoi(getenv("SWM_MSM_QUEUE_ORDER")) == 0);
+            for (int i = 0; i < 3; i++) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
+            if (steer) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->placeholder_stream, hipStreamNonBlocking));
+            SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[3], hipStreamNonBlocking));
+        }
         if (one_stream) {
             st_sort = st_acc = st_tail = ctx->aux_stream[(1 + lane) % 4];
         } else {
