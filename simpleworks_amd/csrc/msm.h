@@ -52,6 +52,7 @@ struct MsmJob {
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
     G1XYZZ* host_dev = nullptr;          // the same slot as the device addresses it (the bucket stage writes there)
     uint32_t* host_flags_dev = nullptr;
+    bool joint_tail = false;             // bucket stage launched together with the other jobs of its round
     bool zero_copy = false;              // results written by the bucket stage into the pinned slot (no copies)
     const uint32_t* host_flags = nullptr;  // tail of the slot: [0] != 0 when a scalar was not a canonical field element
     hipEvent_t done = nullptr;

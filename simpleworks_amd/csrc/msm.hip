@@ -1591,6 +1591,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_HIP(ctx, hipEventRecord(job->acc_done, ctx->stream));
         if (lane >= 0) ctx->set_acc_event[lane] = job->acc_done;
     }
+    job->joint_tail = defer_tail;
     if (defer_tail) {  // the bucket stage runs with the other jobs of the round (msm_flush_tails)
         ctx->pending_tails.push_back(job);
         return SWM_OK;
@@ -1801,6 +1802,25 @@ int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
         if (jobs[i] && jobs[i]->active) live.push_back(i);
     }
     int rc = SWM_OK;
+    // Jobs with their own tail finish one after the other (the tail stream runs them in order): each is folded as soon as
+    // its results are there, while the GPU is still busy with the tails of the later ones — only the last fold is exposed.
+    // Jobs of one joint tail launch finish together: those are folded side by side below.
+    bool pipelined = false;
+    for (int i : live) pipelined = pipelined || !jobs[i]->joint_tail;
+    if (pipelined && live.size() > 1) {
+        bool ok_all = true;
+        for (int i : live) {
+            int r = msm_finish_wait(ctx, jobs[i]);
+            if (rc == SWM_OK) rc = r;
+            if (r == SWM_OK && !msm_fold(jobs[i], host_pool_of(ctx), &results[i])) ok_all = false;
+        }
+        if (rc != SWM_OK) return rc;
+        if (!ok_all) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
+        if (trace)
+            fprintf(stderr, "[swm trace]   msm_finish_many k=%zu: waits and folds interleaved, %.3f ms\n", live.size(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+        return SWM_OK;
+    }
     for (int i : live) {  // every job is waited for and released even if one reports an error
         int r = msm_finish_wait(ctx, jobs[i]);
         if (rc == SWM_OK) rc = r;
