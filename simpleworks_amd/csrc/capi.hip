@@ -276,7 +276,7 @@ void swm_destroy(swm_ctx* ctx) {
             (void)hipStreamSynchronize(ctx->aux_stream[i]);
             (void)hipStreamDestroy(ctx->aux_stream[i]);
         }
-    if (ctx->placeholder_stream) (void)hipStreamDestroy(ctx->placeholder_stream);
+    for (hipStream_t sp : ctx->spare_streams) (void)hipStreamDestroy(sp);
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     for (auto e : ctx->slot_event)
         if (e) (void)hipEventDestroy(e);

@@ -50,7 +50,7 @@ struct swm_ctx {
     static constexpr int MSM_SLOTS = 8;
     static constexpr int MSM_LANES = 4;
     hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t placeholder_stream = nullptr;  // never used: occupies a slot in the hardware-queue assignment order (msm_enqueue)
+    std::vector<hipStream_t> spare_streams;  // never used: placeholders / rejected candidates of the hardware-queue placement (msm_enqueue)
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
     void* pinned_dev = nullptr;  // device address of `pinned`
