@@ -1391,7 +1391,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             }
         }
         if (one_stream) {
-            st_sort = st_acc = st_tail = ctx->aux_stream[(1 + lane) % 4];
+            // lanes 0, 1, 2 on three different hardware queues (accumulation 0, tail, sort); lane 3 shares the
+            // second accumulation stream's queue
+            static const int lane_stream[4] = {1, 3, 0, 2};
+            st_sort = st_acc = st_tail = ctx->aux_stream[lane_stream[lane]];
         } else {
             st_sort = ctx->aux_stream[0];
             st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + lane];
@@ -1401,7 +1404,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
         SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->fork_event, 0));  // the scalars are ready
         // the scratch set of this lane was last read by the accumulation of the job two back
-        if (!one_stream && ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
+        // (single-stream jobs too: their stream is not necessarily the one the set's previous reader ran on)
+        if (ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
     }
     hipStream_t st = st_sort;
     const size_t slot_bytes = (size_t)MAX_WIN * 32 * sizeof(G1XYZZ) + 64;  // up to 1024 (A, R) pairs + status words
