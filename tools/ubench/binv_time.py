@@ -6,8 +6,8 @@ import simpleworks_amd as swm
 from pyref.prng import fr_array
 ctx = swm.Context(0)
 base = fr_array(1 << 20, 5)
-for n in (1 << 16, 1 << 20, 3 << 20):
-    x = np.tile(base, ((n + (1 << 20) - 1) >> 20, 1))[:n]
+for n in (16, 4096, 1 << 16, 1 << 20, 3 << 20):
+    x = np.ascontiguousarray(np.tile(base, ((n + (1 << 20) - 1) >> 20, 1))[:n])
     d = ctx.to_device(x)
     for _ in range(3): ctx.batch_inverse_fr_dev(d, n)
     ctx.synchronize()
