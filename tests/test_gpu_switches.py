@@ -1,0 +1,52 @@
+"""The experiment switches DESIGN.md quotes A/B numbers for select alternative code paths (per-window schedule, stream-
+ordered result copies, plain stream order, 64-lane bucket stage, single stage stream ...).  Each must still produce the
+golden proof bytes and accepted proofs: one subprocess per setting (the switches are read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from simpleworks_amd import marlin as M, workloads as W, serialization as S
+case = json.load(open(os.path.join(%r, "tests", "golden", "marlin.json")))["synthetic_32"]
+rng = M.generate_rand()
+srs = M.generate_universal_srs(*case["srs"], rng)
+cs = W.synthetic_circuit(case["num_constraints"], int(case["a"], 16), int(case["b"], 16))
+pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+proof = M.generate_proof(cs, pk, rng)
+assert S.serialize_proof(proof).hex() == case["proof"], "golden proof bytes"
+for lg in (12, 17):
+    n = 1 << lg
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 3 + lg, 5)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    a = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
+    b = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
+    assert a == b, "same rng, same proof"
+    assert M.verify_proof(vk, public, S.deserialize_proof(a), M.generate_rand())
+    print("sha", lg, __import__("hashlib").sha256(a).hexdigest())
+"""
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("sha ")]
+
+
+@pytest.mark.gpu
+def test_switches_select_equivalent_paths():
+    ref = _run({})
+    assert len(ref) == 2
+    for env in ({"SWM_MSM_NO_TABLE": "1"}, {"SWM_MSM_ZERO_COPY": "0"}, {"SWM_MSM_QUEUE_ORDER": "0"},
+                {"SWM_RED_LANES": "64"}, {"SWM_MSM_PIPE": "0"}, {"SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
+                {"SWM_MSM_SMALL_LANES": "1", "SWM_COMMIT_LATE": "1"}):
+        assert _run(env) == ref, env
