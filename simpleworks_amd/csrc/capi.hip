@@ -416,8 +416,6 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
     }
     e = hipMemcpyAsync(b->d_points, xy, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    b->table_c = msm_table_width(n);
-    if (e == hipSuccess && !b->table_c) e = hipMalloc(&b->d_points28, n * sizeof(G1Affine));
     if (e != hipSuccess) {
         (void)hipFree(b->d_points);
         delete b;
@@ -430,20 +428,23 @@ int swm_srs_upload(swm_ctx* ctx, const uint64_t* xy, size_t n, swm_bases** out) 
     if (hipMalloc((void**)&b->d_inf_mask, mask_words * 4) != hipSuccess ||
         hipMemsetAsync(b->d_inf_mask, 0, mask_words * 4, ctx->stream) != hipSuccess)
         rc = set_err(ctx, SWM_ERR_OOM, "srs_upload: infinity mask");
-    if (rc == SWM_OK && b->table_c) {  // large resident sets get the window-multiple tables (row 0 = the scaled copy)
-        G1Affine* tab = nullptr;
-        rc = msm_table_build(ctx, (const G1Affine*)b->d_points, n, b->table_c, &tab);
-        b->d_points28 = tab;
+    // scaled copy + window-multiple table for large sets: twisted Edwards rows when every point lies in the prime-order
+    // subgroup (checked here: the caller's points are arbitrary), XYZZ rows otherwise, none when nothing fits
+    if (rc == SWM_OK) {
+        G1Affine* d28 = nullptr;
+        G1TE* te = nullptr;
+        rc = msm_install_bases(ctx, (const G1Affine*)b->d_points, n, false, &d28, &te, &b->table_c, b->d_inf_mask);
+        b->d_points28 = d28;
+        b->d_te = te;
     }
-    // (with a table the scaled copy exists already; the call below then only fills the infinity mask)
-    if (rc == SWM_OK) rc = msm_scale_bases_run(ctx, (const G1Affine*)b->d_points, n, (G1Affine*)b->d_points28, b->d_inf_mask);
     std::vector<uint32_t> hmask(mask_words);
     if (rc == SWM_OK && (hipMemcpyAsync(hmask.data(), b->d_inf_mask, mask_words * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                          hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = set_err(ctx, SWM_ERR_HIP, "srs_upload: infinity mask download");
     if (rc != SWM_OK) {
         (void)hipFree(b->d_points);
-        (void)hipFree(b->d_points28);
+        if (b->d_points28) (void)hipFree(b->d_points28);
+        if (b->d_te) (void)hipFree(b->d_te);
         if (b->d_inf_mask) (void)hipFree(b->d_inf_mask);
         delete b;
         return rc;
@@ -463,6 +464,7 @@ int swm_srs_free(swm_ctx* ctx, swm_bases* bases) {
     SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SWM_HIP(ctx, hipFree(bases->d_points));
     SWM_HIP(ctx, hipFree(bases->d_points28));
+    if (bases->d_te) SWM_HIP(ctx, hipFree(bases->d_te));
     if (bases->d_inf_mask) SWM_HIP(ctx, hipFree(bases->d_inf_mask));
     delete bases;
     return SWM_OK;
@@ -484,7 +486,8 @@ int swm_msm_g1_dev(swm_ctx* ctx, const swm_bases* bases, size_t offset, const vo
     SWM_TRY(msm_run(ctx, reinterpret_cast<const G1Affine*>(bases->d_points) + offset,
                     reinterpret_cast<const G1Affine*>(bases->d_points28) + offset, d_scalars, n, scalars_montgomery, &r,
                     MsmInfMask{bases->d_inf_mask, offset},
-                    bases->table_c ? MsmTable{reinterpret_cast<const G1Affine*>(bases->d_points28), bases->n, bases->table_c, offset}
+                    bases->table_c ? MsmTable{bases->d_te ? nullptr : reinterpret_cast<const G1Affine*>(bases->d_points28), bases->n,
+                                              bases->table_c, offset, reinterpret_cast<const G1TE*>(bases->d_te)}
                                    : MsmTable()));
     write_jac(r, out_jac);
     return SWM_OK;

@@ -99,7 +99,8 @@ struct swm_bases {
     void* d_points = nullptr;    // n x G1Affine (96 B, Montgomery radix 2^384)
     void* d_points28 = nullptr;  // same points, coordinates x 2^8 (radix 2^392) for the MSM inner loop
     uint32_t* d_inf_mask = nullptr;  // n bits, allocated only when some base is the point at infinity
-    unsigned table_c = 0;            // != 0: d_points28 is the table of window multiples (msm_table_build), row 0 = the scaled copy
+    unsigned table_c = 0;            // != 0: the set has a table of window multiples — d_te when that is set, else d_points28 (row 0 = the scaled copy)
+    void* d_te = nullptr;            // twisted Edwards form of the table (msm_table_build_te); d_points28 is then the n-point scaled copy
     size_t n = 0;
 };
 

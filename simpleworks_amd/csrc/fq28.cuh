@@ -17,6 +17,7 @@
 // limb goes negative; the value grows by k*p, which the next multiplication absorbs.
 #pragma once
 #include "ff.cuh"
+#include "g1.cuh"
 
 namespace swm {
 
@@ -29,6 +30,7 @@ struct Fq28Consts {
     static constexpr uint32_t P[14] = SWM_FQ28_P;
     static constexpr uint32_t ONE[14] = SWM_FQ28_ONE;
     static constexpr uint32_t TO384[14] = SWM_FQ28_TO384;
+    static constexpr uint32_t SPREAD2[14] = SWM_FQ28_SPREAD2_1;
     static constexpr uint32_t SPREAD4[14] = SWM_FQ28_SPREAD4_1;
     static constexpr uint32_t SPREAD8[14] = SWM_FQ28_SPREAD8_1;
     static constexpr uint32_t SPREAD16_3[14] = SWM_FQ28_SPREAD16_3;
@@ -372,6 +374,119 @@ __device__ __forceinline__ void p28_store_384(XYZZ& m, const P28& p) {
     m.y = fq28_pack(fq28_canonical(fq28_mul(p.y, k)));
     m.zz = fq28_pack(fq28_canonical(fq28_mul(p.zz, k)));
     m.zzz = fq28_pack(fq28_canonical(fq28_mul(p.zzz, k)));
+}
+
+// ------------------------------------------------------------------------------------------------ twisted Edwards points in the 28-bit domain
+// (the curve form, its constants and the reason for it: g1.cuh, "twisted Edwards form").  Coordinates are field elements
+// times 2^392; every coordinate of a point at rest is N (what fq28_mul returns).  In memory a point is a G1XYZZ whose
+// slots hold X, Y, T, Z (x, y, zz, zzz).  The law is unified: no identity / doubling / cancellation cases anywhere.
+struct Fq28TeConsts {
+    static constexpr uint32_t TWO[14] = SWM_FQ28_TWO;
+    static constexpr uint32_t K2D[14] = SWM_FQ28_TE_2D;
+    static constexpr uint32_t INVD[14] = SWM_FQ28_TE_INVD;
+};
+struct T28 {
+    Fq28 x, y, t, z;
+};
+// acc += +-P for the table row (m2, s2, k2) = (y2 - x2, y2 + x2, 2 d x2 y2) of P: EFD madd-2008-hwcd-3 with the row
+// precomputed, 7 multiplications.  A NEGATIVE digit is taken on the accumulator side, -(P1) + P2 = -(P1 - P2): negating P1
+// swaps Y1 - X1 with Y1 + X1 and the sign of C, negating the sum swaps the sign of E — so the row is consumed as loaded
+// (each coordinate unpacked right before the multiplication that reads it) and the sign costs 6 x 14 selects.
+// Bounds (N: limbs < 2^28, value < 2p; the row: canonical):
+//   Y1 - X1 + 4p: limbs < 2^30, < 6p  |  Y1 + X1 < 4p  |  A, B, C = products: N  |  D = 2 Z1: limbs < 2^29, < 4p
+//   +-(B - A) + 4p, D - C + 4p: limbs < 2^30, < 8p  |  D + C: limbs < 3 2^28, < 6p  |  H = B + A: limbs < 2^29, < 4p
+//   X3 = E F, Y3 = G H, T3 = E H, Z3 = F G: operands within what fq28_mul accepts (limbs < 2^30, value < 128p) -> N.
+// The same bounds hold for the first point of a segment (te28_from_row: X1 normalised, in (p, 3p); a SPREADk subtraction
+// needs the top limb of what it subtracts below the top limb of k p: 13.8 k for an N value, 27.5 k for 4p).
+// The empty asm statements at the end pin the new coordinates as 32-bit values: without them the compiler carries the
+// unmasked 64-bit column sums of the last multiplications around the loop and spills ~100 registers.
+template <class M = MulFenced>
+__device__ __forceinline__ void te28_madd_row(T28& a, const G1TE* __restrict__ rp, bool neg) {
+    Fq28 a1, b1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t d = a.y.l[i] + Fq28Consts::SPREAD4[i] - a.x.l[i], s = a.y.l[i] + a.x.l[i];
+        a1.l[i] = neg ? s : d;
+        b1.l[i] = neg ? d : s;
+    }
+    Fq28 A = M::mul(a1, fq28_unpack(rp->ymx));
+    Fq28 B = M::mul(b1, fq28_unpack(rp->ypx));
+    Fq28 C = M::mul(a.t, fq28_unpack(rp->kt));
+    Fq28 E, H, F, G;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t sp = Fq28Consts::SPREAD4[i];
+        E.l[i] = neg ? A.l[i] + sp - B.l[i] : B.l[i] + sp - A.l[i];
+        H.l[i] = A.l[i] + B.l[i];
+        const uint32_t D = a.z.l[i] + a.z.l[i];
+        const uint32_t dm = D + sp - C.l[i], dp = D + C.l[i];
+        F.l[i] = neg ? dp : dm;
+        G.l[i] = neg ? dm : dp;
+    }
+    a.x = M::mul(E, F);
+    a.y = M::mul(G, H);
+    a.t = M::mul(E, H);
+    a.z = M::mul(F, G);
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        asm volatile("" : "+v"(a.x.l[i]));
+        asm volatile("" : "+v"(a.y.l[i]));
+        asm volatile("" : "+v"(a.t.l[i]));
+        asm volatile("" : "+v"(a.z.l[i]));
+    }
+}
+// the point a row stands for, as an accumulator: (X : Y : T : Z) = (2x : 2y : 2xy : 2) — one multiplication (by 1/d)
+// instead of an addition to the identity.  neg: the row of -P is (s2, m2, -k2).
+__device__ __forceinline__ T28 te28_from_row(const Fq28& m2, const Fq28& s2, const Fq28& k2, bool neg) {
+    T28 r;
+    Fq28 d;  // +-(s2 - m2) + 2p = +-2x: in (p, 3p), top limb below SPREAD4's (what the next Y1 - X1 + 4p needs)
+#pragma unroll
+    for (int i = 0; i < 14; i++) d.l[i] = Fq28Consts::SPREAD2[i] + (neg ? m2.l[i] - s2.l[i] : s2.l[i] - m2.l[i]);
+    r.x = fq28_normalize(d);
+    r.y = fq28_normalize(fq28_add(s2, m2));    // 2y < 2p
+    Fq28 ks;
+#pragma unroll
+    for (int i = 0; i < 14; i++) ks.l[i] = neg ? Fq28Consts::SPREAD4[i] - k2.l[i] : k2.l[i];
+    r.t = fq28_mul(ks, fq28_const(Fq28TeConsts::INVD));  // 2 d x y / d
+    r.z = fq28_const(Fq28TeConsts::TWO);
+    return r;
+}
+__device__ __forceinline__ void te28_store_identity(G1XYZZ& m) {
+    Fq28 z, one = fq28_const(Fq28Consts::ONE);
+#pragma unroll
+    for (int i = 0; i < 14; i++) z.l[i] = 0;
+    m.x = fq28_pack(z);
+    m.y = fq28_pack(one);
+    m.zz = fq28_pack(z);
+    m.zzz = fq28_pack(one);
+}
+// *dst = *pa + *pq, operands in memory (LDS slots or HBM), streamed like p28_slot_add: 9 multiplications, four field
+// elements live at the peak.  dst may be pa or pq: every load precedes the first store.
+template <class M = MulFenced>
+__device__ __forceinline__ void te28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) {
+    Fq28 A, B;
+    {
+        Fq28 ax = fq28_unpack(pa->x), ay = fq28_unpack(pa->y), qx = fq28_unpack(pq->x), qy = fq28_unpack(pq->y);
+        A = M::mul(FQ28_SUB(ay, ax, SPREAD4), FQ28_SUB(qy, qx, SPREAD4));
+        B = M::mul(fq28_add(ay, ax), fq28_add(qy, qx));
+    }
+    Fq28 C = M::mul(M::mul(fq28_unpack(pa->zz), fq28_unpack(pq->zz)), fq28_const(Fq28TeConsts::K2D));
+    Fq28 D = M::mul(fq28_unpack(pa->zzz), fq28_unpack(pq->zzz));
+    D = fq28_add(D, D);
+    Fq28 E = FQ28_SUB(B, A, SPREAD4), H = fq28_add(B, A);
+    Fq28 F = FQ28_SUB(D, C, SPREAD4), G = fq28_add(D, C);
+    dst->x = fq28_pack(M::mul(E, F));
+    dst->zz = fq28_pack(M::mul(E, H));
+    dst->y = fq28_pack(M::mul(G, H));
+    dst->zzz = fq28_pack(M::mul(F, G));
+}
+// 28-bit domain (x 2^392) -> radix 2^384, canonical; still a twisted Edwards point (the host folds in that form)
+__device__ __forceinline__ void te28_store_384(G1XYZZ& m, const G1XYZZ& slot) {
+    Fq28 k = fq28_const(Fq28Consts::TO384);
+    m.x = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(slot.x), k)));
+    m.y = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(slot.y), k)));
+    m.zz = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(slot.zz), k)));
+    m.zzz = fq28_pack(fq28_canonical(fq28_mul(fq28_unpack(slot.zzz), k)));
 }
 
 }  // namespace swm

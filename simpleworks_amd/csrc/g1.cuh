@@ -191,6 +191,70 @@ SWM_HD bool g1_is_on_curve(const G1Affine& p) {
     return fp_eq(lhs, rhs);
 }
 
+// ------------------------------------------------------------------------------------------------ twisted Edwards form
+// G1 is also the a = -1 twisted Edwards curve  -x^2 + y^2 = 1 + d x^2 y^2  (constants and the map: tools/gen_constants.py):
+//     x = f (x_w + 1) / y_w,   y = (s (x_w + 1) - 1) / (s (x_w + 1) + 1),   s = 1/sqrt(3), f = sqrt(-(A + 2)/B).
+// In extended coordinates (X : Y : T : Z), T Z = X Y, the UNIFIED addition of Hisil-Wong-Carter-Dawson (EFD
+// add-2008-hwcd-3) costs 9 multiplications (8 + the constant 2d) and — with the second operand kept as the affine
+// triple (y - x, y + x, 2 d x y) — 7: against 8M + 2S for the XYZZ mixed addition.  The law has no exceptional cases
+// among points of odd order (doubling, cancellation and the identity (0, 1) go through the same formulas), so it is used
+// only for base sets known to lie in the prime-order subgroup (msm_table_build_te); it is what the precomputed-table
+// MSM accumulates and reduces in.  A TE point travels in a G1XYZZ-sized slot: x -> X, y -> Y, zz -> T, zzz -> Z.
+struct alignas(16) G1TE {  // one table row: affine, already in the form the mixed addition consumes
+    Fq ymx, ypx, kt;       // y - x, y + x, 2 d x y
+};
+struct TeParams {
+    static constexpr uint32_t S[12] = SWM_TE_S_MONT;
+    static constexpr uint32_t F[12] = SWM_TE_F_MONT;
+    static constexpr uint32_t K2D[12] = SWM_TE_2D_MONT;
+    static constexpr uint32_t RT3[12] = SWM_TE_RT3_MONT;
+    static constexpr uint32_t F_RT3[12] = SWM_TE_F_RT3_MONT;
+};
+SWM_HD Fq fq_const(const uint32_t (&c)[12]) {
+    Fq r;
+    for (int i = 0; i < 12; i++) r.v[i] = c[i];
+    return r;
+}
+SWM_HD G1XYZZ g1te_identity() {
+    G1XYZZ r;
+    r.x = fp_zero<Fq>();
+    r.y = fp_one<Fq>();
+    r.zz = fp_zero<Fq>();
+    r.zzz = fp_one<Fq>();
+    return r;
+}
+// acc += q, both extended (unified: also doubles)
+SWM_HD void g1te_add(G1XYZZ& acc, const G1XYZZ& q) {
+    Fq a = fp_mul(fp_sub(acc.y, acc.x), fp_sub(q.y, q.x));
+    Fq b = fp_mul(fp_add(acc.y, acc.x), fp_add(q.y, q.x));
+    Fq c = fp_mul(fp_mul(acc.zz, q.zz), fq_const(TeParams::K2D));
+    Fq d = fp_dbl(fp_mul(acc.zzz, q.zzz));
+    Fq e = fp_sub(b, a), f = fp_sub(d, c), g = fp_add(d, c), h = fp_add(b, a);
+    acc.x = fp_mul(e, f);
+    acc.y = fp_mul(g, h);
+    acc.zz = fp_mul(e, h);
+    acc.zzz = fp_mul(f, g);
+}
+SWM_HD G1XYZZ g1te_dbl(const G1XYZZ& p) {
+    G1XYZZ r = p;
+    g1te_add(r, p);
+    return r;
+}
+// extended twisted Edwards -> XYZZ on y^2 = x^3 + 1 (no inversion):
+//   u = (Z + Y)/(Z - Y),  x_w = u/s - 1,  y_w = f u Z / (s X);  with z = (Z - Y) X:  zz = z^2, zzz = z^3,
+//   X_w = (rt3 (Z + Y) - (Z - Y)) (Z - Y) X^2,   Y_w = (f rt3) (Z + Y) Z zz.        The identity (X = 0) gives zz = 0.
+SWM_HD G1XYZZ g1te_to_xyzz(const G1XYZZ& p) {
+    Fq n1 = fp_add(p.zzz, p.y), a = fp_sub(p.zzz, p.y);
+    Fq z = fp_mul(a, p.x);
+    if (fp_is_zero(z)) return g1_xyzz_identity();
+    G1XYZZ r;
+    r.zz = fp_sqr(z);
+    r.zzz = fp_mul(r.zz, z);
+    r.x = fp_mul(fp_sub(fp_mul(fq_const(TeParams::RT3), n1), a), fp_mul(z, p.x));
+    r.y = fp_mul(fp_mul(fq_const(TeParams::F_RT3), fp_mul(n1, p.zzz)), r.zz);
+    return r;
+}
+
 // k * p for a small multiplier (window offsets in the bucket reduction; k < 2^31)
 SWM_HD G1XYZZ g1_mul_small(const G1XYZZ& p, uint32_t k) {
     G1XYZZ acc = g1_xyzz_identity();

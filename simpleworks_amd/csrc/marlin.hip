@@ -38,6 +38,9 @@ struct swm_srs {
         if (d_powers) (void)hipFree(d_powers);
     }
     size_t max_degree = 0;
+    // every power lies in the prime-order subgroup: true by construction for universal_setup, established by a check for an
+    // imported SRS (the twisted Edwards MSM tables of the keys derived from it rely on it)
+    bool in_subgroup = false;
     G1Affine* d_powers = nullptr;  // [beta^i] g, i <= max_degree (device)
     std::vector<G1Affine> gamma_powers;  // [beta^i] gamma_g, i < 3 (host)
     G2Affine h, beta_h;
@@ -80,6 +83,8 @@ struct swm_pk {
         if (d_powers28) (void)hipFree(d_powers28);   // the whole table when tab_c != 0
         if (d_shifted) (void)hipFree(d_shifted);
         if (d_shifted28) (void)hipFree(d_shifted28);
+        if (d_powers_te) (void)hipFree(d_powers_te);
+        if (d_shifted_te) (void)hipFree(d_shifted_te);
     }
     IndexInfo info;
     uint64_t H = 0, K = 0, X = 0, B = 0;
@@ -99,17 +104,21 @@ struct swm_pk {
     // precomputed window multiples of both ranges (msm_table_build; width 0: none, the key is small).  Row 0 of a table IS
     // the scaled copy, so d_powers28 / d_shifted28 then point into the tables.
     unsigned tab_c = 0, shtab_c = 0;
+    // the tables in twisted Edwards form (msm_table_build_te; the SRS powers lie in the prime-order subgroup): when set, the
+    // flat schedule runs on them and d_*28 are the n-point scaled copies only
+    G1TE* d_powers_te = nullptr;
+    G1TE* d_shifted_te = nullptr;
     // bases for an MSM of n points starting at SRS power `offset`
     void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28, MsmTable* tab) const {
         *tab = MsmTable();
         if (offset + n <= n_powers) {
             *b = d_powers + offset;
             *b28 = d_powers28 + offset;
-            if (tab_c) *tab = MsmTable{d_powers28, n_powers, tab_c, offset};
+            if (tab_c) *tab = MsmTable{d_powers_te ? nullptr : d_powers28, n_powers, tab_c, offset, d_powers_te};
         } else if (offset >= shift_base && offset + n <= shift_base + n_shifted) {
             *b = d_shifted + (offset - shift_base);
             *b28 = d_shifted28 + (offset - shift_base);
-            if (shtab_c) *tab = MsmTable{d_shifted28, n_shifted, shtab_c, offset - shift_base};
+            if (shtab_c) *tab = MsmTable{d_shifted_te ? nullptr : d_shifted28, n_shifted, shtab_c, offset - shift_base, d_shifted_te};
         } else {
             throw MarlinError(SWM_ERR_INDEX_TOO_LARGE, "polynomial does not fit the committer key");
         }
@@ -405,7 +414,7 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // launch only queues them behind one another (2^16: 16.5 -> 20.3 ms) — those keep their own tail, as do large MSMs,
     // whose tail overlaps the next commitment's accumulation.
     static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
-    const long batch_below = batch_env >= 0 ? batch_env : (tab.t28 ? 200000 : 32768);
+    const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? 200000 : 32768);
     tab.offset += lo;
     rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));
@@ -670,6 +679,7 @@ swm_srs* universal_setup(swm_ctx* ctx, size_t nc, size_t nv, size_t nnz, ChaChaR
     G2Affine h = g2_rand(rng);
     std::unique_ptr<swm_srs> srs(new swm_srs());
     srs->max_degree = max_degree;
+    srs->in_subgroup = true;  // multiples of g, which g1_rand returns with the cofactor cleared
     srs->h = h;
     srs->beta_h = g2_mul_fr(h, beta);
     Fr bp = fp_one<Fr>();
@@ -784,7 +794,7 @@ void arithmetize(swm_ctx* ctx, swm_pk& pk, const HostCsr& m, MatrixArith& ar) {
 
 // Copies the two power ranges of a trimmed committer key into the key (device or host source) and derives the scaled twins.
 void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, size_t n_powers, const G1Affine* shifted,
-                           size_t n_shifted, bool device_src) {
+                           size_t n_shifted, bool device_src, bool in_subgroup) {
     const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     pk.n_powers = n_powers;
     pk.n_shifted = n_shifted;
@@ -793,20 +803,14 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     hip_check(ctx, hipMalloc((void**)&pk.d_shifted, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted)");
     hip_check(ctx, hipMemcpyAsync(pk.d_powers, powers, n_powers * sizeof(G1Affine), kind, ctx->stream), "copy powers");
     if (n_shifted) hip_check(ctx, hipMemcpyAsync(pk.d_shifted, shifted, n_shifted * sizeof(G1Affine), kind, ctx->stream), "copy shifted");
-    // scaled twins, or — for keys large enough to profit — the tables of window multiples whose first row they are
-    pk.tab_c = msm_table_width(n_powers);
-    pk.shtab_c = n_shifted ? msm_table_width(n_shifted) : 0;
-    if (pk.tab_c) {
-        rc_check(ctx, msm_table_build(ctx, pk.d_powers, n_powers, pk.tab_c, &pk.d_powers28));
+    // scaled twins and — for keys large enough to profit — the tables of window multiples (twisted Edwards rows when the
+    // points are known to lie in the prime-order subgroup: SRS powers generated here are multiples of the generator,
+    // deserialised keys went through the checks of their codec, an imported SRS is checked at import)
+    rc_check(ctx, msm_install_bases(ctx, pk.d_powers, n_powers, in_subgroup, &pk.d_powers28, &pk.d_powers_te, &pk.tab_c));
+    if (n_shifted) {
+        rc_check(ctx, msm_install_bases(ctx, pk.d_shifted, n_shifted, in_subgroup, &pk.d_shifted28, &pk.d_shifted_te, &pk.shtab_c));
     } else {
-        hip_check(ctx, hipMalloc((void**)&pk.d_powers28, n_powers * sizeof(G1Affine)), "hipMalloc(pk powers28)");
-        rc_check(ctx, msm_scale_bases_run(ctx, pk.d_powers, n_powers, pk.d_powers28));
-    }
-    if (pk.shtab_c) {
-        rc_check(ctx, msm_table_build(ctx, pk.d_shifted, n_shifted, pk.shtab_c, &pk.d_shifted28));
-    } else {
-        hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, std::max<size_t>(n_shifted, 1) * sizeof(G1Affine)), "hipMalloc(pk shifted28)");
-        rc_check(ctx, msm_scale_bases_run(ctx, pk.d_shifted, n_shifted, pk.d_shifted28));
+        hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, sizeof(G1Affine)), "hipMalloc(pk shifted28)");
     }
     hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
 }
@@ -833,7 +837,7 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     // committer key = MarlinKZG10::trim(srs, supported_degree = max_deg, hiding bound 1, bounds {|H| - 2, |K| - 2})
     pk->srs_max_degree = srs->max_degree;
     install_committer_key(ctx, *pk, srs->d_powers, max_deg + 1, srs->d_powers + (srs->max_degree - (std::max(pk->H, pk->K) - 2)),
-                          std::max(pk->H, pk->K) - 2 + 1, /*device_src=*/true);
+                          std::max(pk->H, pk->K) - 2 + 1, /*device_src=*/true, srs->in_subgroup);
     pk->gamma_powers = srs->gamma_powers;
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->ha = p.a; pk->hb = p.b; pk->hc = p.c;
@@ -1803,7 +1807,8 @@ swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
         powers.size() > pk->srs_max_degree + 1 || shifted.size() != max_bound + 1 || pk->gamma_powers.size() < 3 ||
         pk->srs_max_degree != pk->vk.vk.max_degree)
         throw MarlinError(SWM_ERR_SERIALIZATION, "committer key does not fit the index");
-    install_committer_key(ctx, *pk, powers.data(), powers.size(), shifted.data(), shifted.size(), /*device_src=*/false);
+    install_committer_key(ctx, *pk, powers.data(), powers.size(), shifted.data(), shifted.size(), /*device_src=*/false,
+                          /*in_subgroup=*/true);  // g1_decompress_kernel checked [r]P = O for every point
     pk->gtab = build_gamma_table(pk->gamma_powers);
     pk->a = upload_csr(ctx, pk->ha);
     pk->b = upload_csr(ctx, pk->hb);
@@ -1976,6 +1981,7 @@ int swm_srs_import(swm_ctx* ctx, const uint64_t* powers_xy, size_t n_powers, con
         hip_check(ctx, hipMalloc((void**)&srs->d_powers, n_powers * sizeof(G1Affine)), "hipMalloc(srs)");
         hip_check(ctx, hipMemcpyAsync(srs->d_powers, powers_xy, n_powers * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream), "h2d");
         hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        rc_check(ctx, msm_subgroup_check(ctx, srs->d_powers, n_powers, &srs->in_subgroup));
         *out = srs.release();
     });
 }

@@ -26,6 +26,10 @@ struct MsmTable {
     size_t stride = 0;
     unsigned c = 0;
     size_t offset = 0;
+    // the same multiples as twisted Edwards rows (msm_table_build_te; g1.cuh): when set, the flat schedule accumulates and
+    // reduces in that form (7 multiplications per mixed addition instead of 8M + 2S) and t28 is not needed
+    const G1TE* te = nullptr;
+    bool any() const { return t28 != nullptr || te != nullptr; }
 };
 unsigned msm_table_windows(unsigned c);
 WinLayout msm_table_layout(unsigned c);
@@ -34,6 +38,20 @@ unsigned msm_table_width(size_t n_bases);
 // builds the table of d_points[0 .. n) (affine, radix 2^384) for width c into *out (hipMalloc'd, windows * n points);
 // row 0 is the plain scaled copy of the set (what msm_scale_bases_run produces)
 int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c, G1Affine** out);
+// The twisted Edwards form of the same table (144-B rows).  The points must lie in the prime-order subgroup (the unified
+// addition law has exceptional pairs among points of even order): the prover's committer keys do by construction or by
+// their checked deserialisation; msm_subgroup_check establishes it for caller-supplied sets.  *out stays null (and the
+// call returns SWM_OK) when a point has no image under the map — the caller then keeps the XYZZ table.
+int msm_table_build_te(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c, G1TE** out);
+// *ok = every point is the identity (0, 0) or lies on the curve and in the prime-order subgroup ([r]P = O)
+int msm_subgroup_check(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool* ok);
+// scaled copy + the best table that fits for a resident base set (see msm.hip); frees nothing of the caller's
+int msm_install_bases(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool in_subgroup, G1Affine** d28, G1TE** te, unsigned* c,
+                      uint32_t* d_inf_mask = nullptr);
+// SWM_MSM_TE=0 keeps the XYZZ tables everywhere (A/B measurements)
+bool msm_te_enabled();
+// HBM left for a table of `bytes` bytes? (hipMemGetInfo, keeping a quarter of the free memory for the prover's temporaries)
+bool msm_table_fits(size_t bytes);
 
 struct MsmJob {
     bool active = false;
@@ -41,6 +59,7 @@ struct MsmJob {
     WinLayout pl;
     unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
     unsigned red_blocks = 0, log_m = 0, rb = 256;  // bucket stage: workgroups per window, log2 buckets per lane, lanes per workgroup
+    bool te = false;         // partial sums and workgroup results are twisted Edwards points (the host fold converts the total)
     int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
     // deferred bucket stage (msm_flush_tails): what it reads / writes, the stream the job ran on and its "partials ready" event
     bool tail_pending = false;

@@ -581,6 +581,75 @@ __global__ void __launch_bounds__(256) msm_table_normalize(const G1XYZZ* __restr
     }
 }
 
+// affine points on y^2 = x^3 + 1 (plain form, radix 2^384) -> twisted Edwards table rows (y - x, y + x, 2 d x y), each
+// coordinate x 2^8 like the XYZZ table.  x = f (x_w + 1)/y_w, y = (u - 1)/(u + 1), u = s (x_w + 1): one inversion per
+// TAB_NORM_CHUNK points (of the product of their y_w (u + 1)).  The identity (0, 0) becomes the row (1, 1, 0) of (0, 1).
+// A point with y_w (u + 1) = 0 (order 2, or mapped to infinity: never in the prime-order subgroup) raises *bad.
+__global__ void __launch_bounds__(256) msm_te_convert(const G1Affine* __restrict__ in, size_t n, Fq* __restrict__ pref,
+                                                      G1TE* __restrict__ out, uint32_t* __restrict__ bad) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t lo = t * TAB_NORM_CHUNK;
+    if (lo >= n) return;
+    size_t hi = lo + TAB_NORM_CHUNK < n ? lo + TAB_NORM_CHUNK : n;
+    const Fq one = fp_one<Fq>(), cs = fq_const(TeParams::S);
+    Fq acc = one;
+    for (size_t i = lo; i < hi; i++) {
+        G1Affine p = in[i];
+        pref[i] = acc;
+        if (g1_is_inf(p)) continue;
+        Fq den = fp_mul(p.y, fp_add(fp_mul(cs, fp_add(p.x, one)), one));
+        if (fp_is_zero(den)) atomicOr(bad, 1u);
+        else acc = fp_mul(acc, den);
+    }
+    Fq inv = fp_inv(acc);
+    const uint32_t k256[12] = SWM_FQ_SCALE256_MONT;
+    Fq c256, one256;
+#pragma unroll
+    for (int j = 0; j < 12; j++) c256.v[j] = k256[j];
+    one256 = fp_mul(one, c256);
+    for (size_t i = hi; i-- > lo;) {
+        G1Affine p = in[i];
+        G1TE r;
+        Fq x1 = fp_add(p.x, one), u = fp_mul(cs, x1), up1 = fp_add(u, one), den = fp_mul(p.y, up1);
+        if (g1_is_inf(p) || fp_is_zero(den)) {
+            r.ymx = one256;
+            r.ypx = one256;
+            r.kt = fp_zero<Fq>();
+        } else {
+            Fq di = fp_mul(inv, pref[i]);
+            inv = fp_mul(inv, den);
+            Fq xt = fp_mul(fp_mul(fq_const(TeParams::F), x1), fp_mul(di, up1));  // f (x_w + 1) / y_w
+            Fq yt = fp_mul(fp_sub(u, one), fp_mul(di, p.y));                       // (u - 1) / (u + 1)
+            r.ymx = fp_mul(fp_sub(yt, xt), c256);
+            r.ypx = fp_mul(fp_add(yt, xt), c256);
+            r.kt = fp_mul(fp_mul(fq_const(TeParams::K2D), fp_mul(xt, yt)), c256);
+        }
+        out[i] = r;
+    }
+}
+// [r]P = O and P on the curve, for every point that is not the identity (0, 0): double-and-add over the 253 bits of r
+__global__ void __launch_bounds__(256) msm_subgroup_kernel(const G1Affine* __restrict__ in, size_t n, uint32_t* __restrict__ bad) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = in[i];
+    if (g1_is_inf(p)) return;
+    if (!g1_is_on_curve(p)) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    G1XYZZ acc = g1_xyzz_identity();
+    bool started = false;
+#pragma unroll 1
+    for (int b = 252; b >= 0; b--) {
+        if (started) acc = g1_dbl(acc);
+        if ((FrParams::P[b >> 5] >> (b & 31)) & 1) {
+            g1_add_mixed(acc, p);
+            started = true;
+        }
+    }
+    if (!g1_is_inf(acc)) atomicOr(bad, 2u);
+}
+
 __device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
 
 // Exclusive scans of the bucket counts and of the per-bucket segment counts, in three launches:
@@ -878,6 +947,43 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
     }
 }
 
+// The same kernel over a twisted Edwards table (msm_table_build_te): rows are the affine triples (y - x, y + x, 2 d x y),
+// the accumulator is an extended point and every addition is the UNIFIED 7-multiplication law of te28_madd — no doubling /
+// cancellation test, no cold path, 2 646 instead of 3 598 multiply-adds per addition (3 890 instead of 4 817 instructions in
+// the loop, 148 VGPRs, no scratch).  Partial sums leave as extended points (X, Y, T, Z in the four slots of a G1XYZZ).
+// Algorithmic bytes per point are unchanged (96 B base + 32 B scalar); a table row is 144 B instead of 96 B.
+__global__ void __launch_bounds__(256, 3) msm_accumulate_te(const G1TE* __restrict__ rows,
+                                                           const uint32_t* __restrict__ sorted,
+                                                           const uint32_t* __restrict__ seg_start,
+                                                           const uint32_t* __restrict__ seg_len,
+                                                           const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ nseg_ptr,
+                                                           G1XYZZ* __restrict__ partial) {
+    const uint32_t nseg_total = *nseg_ptr;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nseg_total; t += gridDim.x * blockDim.x) {
+        const uint32_t seg = order[t];
+        const uint32_t k0 = seg_start[seg], e = k0 + seg_len[seg];
+        if (k0 >= e) {
+            te28_store_identity(partial[seg]);
+            continue;
+        }
+        T28 acc;
+        {
+            const uint32_t ent = sorted[k0];
+            const G1TE row = rows[ent & 0x7fffffffu];
+            acc = te28_from_row(fq28_unpack(row.ymx), fq28_unpack(row.ypx), fq28_unpack(row.kt), (ent >> 31) != 0);
+        }
+        for (uint32_t k = k0 + 1; k < e; k++) {
+            const uint32_t ent = sorted[k];
+            te28_madd_row(acc, rows + (ent & 0x7fffffffu), (ent >> 31) != 0);
+        }
+        partial[seg].x = fq28_pack(acc.x);
+        partial[seg].y = fq28_pack(acc.y);
+        partial[seg].zz = fq28_pack(acc.t);
+        partial[seg].zzz = fq28_pack(acc.z);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- bucket stage (28-bit domain)
 // Register budget of the bucket stage: a general addition keeps two points (2 x 56 VGPRs) plus ~8 temporaries
 // (112 VGPRs) live; a third live point spills to scratch, i.e. to HBM-backed private memory with nothing to hide the
@@ -971,8 +1077,24 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
     dst->y = fq28_pack(M::mul2(r, FQ28_SUB(qq, x3, SPREAD32), ns1, ppp));  // R (Q - X3) - S1 PPP, one reduction
 }
 
+// The two point forms of the bucket stage: XYZZ on the Weierstrass curve (per-window schedule, XYZZ tables) and extended
+// twisted Edwards (TE tables).  Each kernel below is instantiated once per form; a launch handles jobs of one form.
+struct FormXYZZ {
+    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) { p28_slot_add(dst, pa, pq); }
+    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa) { p28_slot_dbl(dst, pa); }
+    static __device__ __forceinline__ void store_identity(G1XYZZ& m) { p28_store(m, p28_identity()); }
+    static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { p28_store_384(m, p28_load(slot)); }
+};
+struct FormTE {
+    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) { te28_slot_add(dst, pa, pq); }
+    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa) { te28_slot_add(dst, pa, pa); }  // unified law
+    static __device__ __forceinline__ void store_identity(G1XYZZ& m) { te28_store_identity(m); }
+    static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { te28_store_384(m, slot); }
+};
+
 // Oversized buckets (> BIG_NSEG segments: structured scalars) are folded first, one workgroup each: strided partial
 // sums + LDS tree; the result replaces the bucket's first partial.
+template <class Form>
 __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restrict__ partial,
                                                                 const uint32_t* __restrict__ seg_off,
                                                                 const uint32_t* __restrict__ big_count,
@@ -991,13 +1113,13 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
             s = seg_off[b];
             e = seg_off[b + 1];
         }
-        p28_store(sm[threadIdx.x], p28_identity());
+        Form::store_identity(sm[threadIdx.x]);
 #pragma unroll 1
-        for (uint32_t k = s + g; k < e; k += G) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &partial[k]);
+        for (uint32_t k = s + g; k < e; k += G) Form::slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &partial[k]);
         __syncthreads();
 #pragma unroll 1
         for (uint32_t stride = G / 2; stride > 0; stride >>= 1) {
-            if (g < stride) p28_slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &sm[threadIdx.x + stride]);
+            if (g < stride) Form::slot_add(&sm[threadIdx.x], &sm[threadIdx.x], &sm[threadIdx.x + stride]);
             __syncthreads();
         }
         if (g == 0 && j < nbig) partial[s] = sm[threadIdx.x];
@@ -1037,7 +1159,7 @@ struct TailJob {
 struct TailBatch {
     TailJob j[TAIL_MAX];
 };
-template <int RB>
+template <int RB, class Form>
 __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
@@ -1058,8 +1180,8 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
-    p28_store(sm_run[t], p28_identity());
-    p28_store(sm_acc[t], p28_identity());
+    Form::store_identity(sm_run[t]);
+    Form::store_identity(sm_acc[t]);
     // phase-1 sequencer of this lane: buckets b = hi-1 .. lo; per bucket "run += partial[s]" for its segments, then
     // "acc += run"
     uint32_t b = min(lo + m, B), s = 0, e = 0;
@@ -1115,10 +1237,10 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
             d <<= 1;
         } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1} (into the other copy); R_blk = Suffix_0 is parked
             if (t + 1 < RB) sm_alt[t] = sm_run[t + 1];
-            else p28_store(sm_alt[t], p28_identity());
+            else Form::store_identity(sm_alt[t]);
             if (t == 0) sm_r[0] = sm_run[0];
 #pragma unroll 1
-            for (unsigned i = 0; i < log_m; i++) p28_slot_dbl(&sm_alt[t], &sm_alt[t]);
+            for (unsigned i = 0; i < log_m; i++) Form::slot_dbl(&sm_alt[t], &sm_alt[t]);
             __syncthreads();
             G1XYZZ* x = sm_run;
             sm_run = sm_alt;
@@ -1139,7 +1261,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
             if (act) pq = &sm_acc[t + d];  // the lanes t + d .. are idle in this step: nobody rewrites what is read
             d >>= 1;
         }
-        if (act) p28_slot_add(dst, pa, pq);
+        if (act) Form::slot_add(dst, pa, pq);
         else if (copy) *dst = *pa;
         __syncthreads();
         if (dst == &sm_alt[t]) {  // a scan step went from one copy of the running sums to the other (uniform per step)
@@ -1152,8 +1274,8 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
         // `out` is the job's PINNED host slot (zero-copy: 384 B per workgroup over the fabric instead of three
         // stream-ordered copies per job after the kernel — ~25 us per job between a round's last kernel and its challenge)
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
-        p28_store_384(out[o], p28_load(sm_acc[0]));
-        p28_store_384(out[o + 1], p28_load(sm_r[0]));
+        Form::store_384(out[o], sm_acc[0]);
+        Form::store_384(out[o + 1], sm_r[0]);
         if (blockIdx.x == 0 && w == 0 && job.host_flags) {
             job.host_flags[0] = *job.status;
             job.host_flags[1] = *job.entries;
@@ -1208,6 +1330,7 @@ int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c
     const unsigned W = L.nwin;
     G1Affine* tab = nullptr;
     hipError_t e = hipMalloc((void**)&tab, (size_t)W * n * sizeof(G1Affine));
+    if (e != hipSuccess) (void)hipGetLastError();  // not sticky: the caller falls back to a smaller form
     if (e != hipSuccess) return set_err(ctx, SWM_ERR_OOM, "msm table (%u windows x %zu points): %s", W, n, hipGetErrorString(e));
     G1XYZZ* x = nullptr;
     Fq* pref = nullptr;
@@ -1239,6 +1362,126 @@ int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c
     }
     *out = tab;
     return SWM_OK;
+}
+
+bool msm_te_enabled() {
+    static const bool on = !(getenv("SWM_MSM_TE") && atoi(getenv("SWM_MSM_TE")) == 0);
+    return on;
+}
+bool msm_table_fits(size_t bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;  // cannot tell: let the allocation decide
+    return bytes <= free_b - free_b / 4;
+}
+int msm_subgroup_check(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool* ok) {
+    *ok = true;
+    if (n == 0) return SWM_OK;
+    uint32_t* d_bad = nullptr;
+    SWM_TRY(scratch(ctx, "tab.bad", 64, (void**)&d_bad));
+    SWM_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    SWM_LAUNCH(ctx, "msm_subgroup_check", msm_subgroup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_points, n, d_bad);
+    uint32_t h = 0;
+    SWM_HIP(ctx, hipMemcpyAsync(&h, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *ok = h == 0;
+    return SWM_OK;
+}
+int msm_table_build_te(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c, G1TE** out) {
+    *out = nullptr;
+    if (n == 0 || c < 2) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm table: bad arguments");
+    const WinLayout L = msm_table_layout(c);
+    const unsigned W = L.nwin;
+    G1TE* tab = nullptr;
+    hipError_t e = hipMalloc((void**)&tab, (size_t)W * n * sizeof(G1TE));
+    if (e != hipSuccess) (void)hipGetLastError();  // not sticky: the caller falls back to a smaller form
+    if (e != hipSuccess) return set_err(ctx, SWM_ERR_OOM, "msm table (%u windows x %zu points): %s", W, n, hipGetErrorString(e));
+    G1XYZZ* x = nullptr;
+    Fq* pref = nullptr;
+    G1Affine* cur = nullptr;  // 2^(bit_w) P in the plain form, input of the next shift
+    uint32_t* d_bad = nullptr;
+    uint32_t bad = 0;
+    int rc = SWM_OK;
+    do {
+        if ((rc = scratch(ctx, "tab.xyzz", n * sizeof(G1XYZZ), (void**)&x)) != SWM_OK) break;
+        if ((rc = scratch(ctx, "tab.pref", n * sizeof(Fq), (void**)&pref)) != SWM_OK) break;
+        if ((rc = scratch(ctx, "tab.cur", n * sizeof(G1Affine), (void**)&cur)) != SWM_OK) break;
+        if ((rc = scratch(ctx, "tab.bad", 64, (void**)&d_bad)) != SWM_OK) break;
+        if (hipMemsetAsync(d_bad, 0, 4, ctx->stream) != hipSuccess) {
+            rc = set_err(ctx, SWM_ERR_HIP, "msm table: memset failed");
+            break;
+        }
+        const G1Affine* src = d_points;
+        const unsigned grid = (unsigned)((n + 255) / 256), gridn = (unsigned)(((n + TAB_NORM_CHUNK - 1) / TAB_NORM_CHUNK + 255) / 256);
+        for (unsigned w = 0; w < W && rc == SWM_OK; w++) {
+            if (w > 0) {
+                hipLaunchKernelGGL(msm_table_shift, dim3(grid), dim3(256), 0, ctx->stream, src, n, (unsigned)L.c[w - 1], x);
+                hipLaunchKernelGGL(msm_table_normalize, dim3(gridn), dim3(256), 0, ctx->stream, (const G1XYZZ*)x, n, pref, cur);
+                src = cur;
+            }
+            hipLaunchKernelGGL(msm_te_convert, dim3(gridn), dim3(256), 0, ctx->stream, src, n, pref, tab + (size_t)w * n, d_bad);
+            if (hipGetLastError() != hipSuccess) rc = set_err(ctx, SWM_ERR_HIP, "msm table: launch failed");
+        }
+        if (rc == SWM_OK && (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                             hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = set_err(ctx, SWM_ERR_HIP, "msm table: sync failed");
+    } while (0);
+    scratch_release(ctx, "tab.xyzz");
+    scratch_release(ctx, "tab.pref");
+    scratch_release(ctx, "tab.cur");
+    if (rc != SWM_OK || bad) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tab);
+        return rc;  // bad: SWM_OK with *out == nullptr — a point without an image; the caller keeps the XYZZ form
+    }
+    *out = tab;
+    return SWM_OK;
+}
+
+// Everything a resident base set needs for its MSMs, in one place (swm_srs_upload, the prover's committer keys):
+//   *c    table width (0: the set is too small, its table would not fit, or n * windows >= 2^31 — per-window schedule only)
+//   *te   twisted Edwards table when the set qualifies (subgroup established, SWM_MSM_TE != 0, it fits): the flat schedule
+//         then runs in that form and *d28 is just the scaled copy of the set (n points) for the per-window schedule
+//   *d28  otherwise the XYZZ table (row 0 = the scaled copy) when *c != 0, else the scaled copy
+// A table that cannot be allocated is not an error: the next cheaper form is used (TE -> XYZZ table -> no table).
+int msm_install_bases(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool in_subgroup, G1Affine** d28, G1TE** te, unsigned* c,
+                      uint32_t* d_inf_mask) {
+    *d28 = nullptr;
+    *te = nullptr;
+    *c = msm_table_width(n);
+    if (*c && (uint64_t)n * msm_table_windows(*c) >= (1ull << 31)) *c = 0;  // the sort addresses table rows with 31 bits
+    const unsigned W = *c ? msm_table_windows(*c) : 0;
+    if (*c && msm_te_enabled()) {
+        bool ok = in_subgroup;
+        if (!ok) SWM_TRY(msm_subgroup_check(ctx, d_points, n, &ok));
+        if (ok && msm_table_fits((size_t)W * n * sizeof(G1TE) + n * sizeof(G1Affine))) {
+            int rc = msm_table_build_te(ctx, d_points, n, *c, te);
+            if (rc != SWM_OK && rc != SWM_ERR_OOM) return rc;
+        }
+    }
+    if (*c && !*te) {
+        int rc = SWM_ERR_OOM;
+        if (msm_table_fits((size_t)W * n * sizeof(G1Affine))) rc = msm_table_build(ctx, d_points, n, *c, d28);
+        if (rc == SWM_ERR_OOM) *c = 0;  // no room for a table: the per-window schedule needs 1x the set
+        else if (rc != SWM_OK) return rc;
+    }
+    if (!*d28) {
+        hipError_t e = hipMalloc((void**)d28, std::max<size_t>(n, 1) * sizeof(G1Affine));
+        if (e != hipSuccess) {
+            if (*te) (void)hipFree(*te);
+            *te = nullptr;
+            return set_err(ctx, SWM_ERR_OOM, "msm bases (%zu points): %s", n, hipGetErrorString(e));
+        }
+    }
+    // the scaled copy (row 0 of an XYZZ table is written again: same bytes) and, when asked for, the infinity mask
+    int rc = msm_scale_bases_run(ctx, d_points, n, *d28, d_inf_mask);
+    if (rc == SWM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, SWM_ERR_HIP, "msm bases: sync failed");
+    if (rc != SWM_OK) {
+        (void)hipFree(*d28);
+        if (*te) (void)hipFree(*te);
+        *d28 = nullptr;
+        *te = nullptr;
+    }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------- hardware-queue probe
@@ -1287,8 +1530,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // flat schedule: the base set comes with its precomputed window multiples and the MSM is large enough to populate the
     // shared bucket set (below ~2^(c-4) points the per-window schedule with its small windows wins)
     static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
-    const bool flat = tab.t28 && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
+    const bool flat = tab.any() && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
                       (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+    const bool te = flat && tab.te != nullptr;  // twisted Edwards rows: accumulation and bucket stage run in that form
+    job->te = te;
     // low-latency schedule (flat MSMs below ~2^18 points, where a proof is a chain of dependent additions rather than
     // a throughput problem): short segments (8 points), every bucket with more than two segments folded by a lane
     // group in msm_big_bucket_sum (a tree instead of the serial walk of the bucket stage), one bucket per lane in the
@@ -1631,12 +1876,19 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
     static const unsigned acc_cap = getenv("SWM_ACC_WGS") ? (unsigned)atoi(getenv("SWM_ACC_WGS")) : 0u;
     if (acc_cap && lane >= 0) acc_grid = std::min(acc_grid, acc_cap);
-    SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3(acc_grid), dim3(256), 0,
-               flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
-               seg_off + pl.NB, partial);
-    SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum,
-               dim3(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512)), dim3(RED_BLOCK),
-               RED_BLOCK * sizeof(G1XYZZ), partial, seg_off, big_count, big_list, log_g);
+    const dim3 big_grid(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512));
+    if (te) {
+        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), 0, tab.te, sorted, seg_start, seg_len,
+                   order, seg_off + pl.NB, partial);
+        SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormTE>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
+                   partial, seg_off, big_count, big_list, log_g);
+    } else {
+        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3(acc_grid), dim3(256), 0,
+                   flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
+                   seg_off + pl.NB, partial);
+        SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormXYZZ>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
+                   partial, seg_off, big_count, big_list, log_g);
+    }
     job->needs_acc_wait = st_tail != ctx->stream || defer_tail;  // the tail runs on another stream (or later, with others)
     job->d_partial = partial;
     job->d_wpart = wpart;
@@ -1688,12 +1940,21 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);
     }
+    const bool te = jobs[0]->te;  // every job of a launch has the same point form (msm_flush_tails groups them)
     if (jobs[0]->rb == 64) {
-        SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce<64>, dim3(max_red, max_win, (unsigned)k), dim3(64),
-                   (3 * 64 + 1) * sizeof(G1XYZZ), batch);
+        if (te)
+            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(64),
+                       (3 * 64 + 1) * sizeof(G1XYZZ), batch);
+        else
+            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormXYZZ>), dim3(max_red, max_win, (unsigned)k), dim3(64),
+                       (3 * 64 + 1) * sizeof(G1XYZZ), batch);
+    } else if (te) {
+        SWM_TRY(allow_big_lds(ctx, 7, (const void*)msm_bucket_reduce<256, FormTE>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+        SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
+                   (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
     } else {
-        SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce<256>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
-        SWM_LAUNCH(ctx, "msm_bucket_reduce", msm_bucket_reduce<256>, dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
+        SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce<256, FormXYZZ>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+        SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormXYZZ>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
                    (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
     }
     for (int i = 0; i < k; i++) {
@@ -1717,7 +1978,7 @@ int msm_flush_tails(swm_ctx* ctx) {
     jobs.swap(ctx->pending_tails);
     for (size_t i = 0; i < jobs.size();) {  // one launch per run of up to TAIL_MAX jobs of the same workgroup width
         size_t k = 1;
-        while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb) k++;
+        while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb && jobs[i + k]->te == jobs[i]->te) k++;
         SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)k));
         i += k;
     }
@@ -1736,13 +1997,29 @@ static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     return SWM_OK;
 }
 
+// point form of a job's workgroup results on the host: XYZZ, or extended twisted Edwards (job->te; g1.cuh)
+struct HostXYZZ {
+    static G1XYZZ identity() { return g1_xyzz_identity(); }
+    static void add(G1XYZZ& a, const G1XYZZ& q) { g1_add(a, q); }
+    static G1XYZZ dbl(const G1XYZZ& p) { return g1_dbl(p); }
+    static bool is_inf(const G1XYZZ& p) { return g1_is_inf(p); }
+    static G1XYZZ to_xyzz(const G1XYZZ& p) { return p; }
+};
+struct HostTE {
+    static G1XYZZ identity() { return g1te_identity(); }
+    static void add(G1XYZZ& a, const G1XYZZ& q) { g1te_add(a, q); }
+    static G1XYZZ dbl(const G1XYZZ& p) { return g1te_dbl(p); }
+    static bool is_inf(const G1XYZZ& p) { return fp_is_zero(p.x) && fp_eq(p.y, p.zzz); }  // (0 : z : 0 : z)
+    static G1XYZZ to_xyzz(const G1XYZZ& p) { return g1te_to_xyzz(p); }
+};
 // over the workgroups blk in [lo, hi): sum of A, sum of R, and sum of (blk - lo) R_blk by suffix sums
+template <class HF>
 static void fold_range(const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out, G1XYZZ* sr_out, G1XYZZ* wt_out) {
-    G1XYZZ sa = g1_xyzz_identity(), suffix = g1_xyzz_identity(), wt = g1_xyzz_identity();
+    G1XYZZ sa = HF::identity(), suffix = HF::identity(), wt = HF::identity();
     for (unsigned blk = hi; blk-- > lo;) {
-        g1_add(sa, h[2 * blk]);
-        g1_add(suffix, h[2 * blk + 1]);                // Suffix_blk = sum_{u >= blk} R_u
-        if (blk > lo) g1_add(wt, suffix);              // sum_{blk > lo} Suffix_blk = sum (blk - lo) R_blk
+        HF::add(sa, h[2 * blk]);
+        HF::add(suffix, h[2 * blk + 1]);                // Suffix_blk = sum_{u >= blk} R_u
+        if (blk > lo) HF::add(wt, suffix);              // sum_{blk > lo} Suffix_blk = sum (blk - lo) R_blk
     }
     *sa_out = sa;
     *sr_out = suffix;
@@ -1752,17 +2029,18 @@ static void fold_range(const G1XYZZ* h, unsigned lo, unsigned hi, G1XYZZ* sa_out
 // workers); with g0 = 16 g the first workgroup of group g:  sum blk R_blk = sum_g [W_g + 16 g SR_g], and sum_g g SR_g
 // comes from suffix sums over the groups, times 16 by four doublings.
 static constexpr unsigned FOLD_GROUP = 16;
+template <class HF>
 static void fold_groups_combine(const G1XYZZ* ga, const G1XYZZ* gr, const G1XYZZ* gw, unsigned G, G1XYZZ* sum_a, G1XYZZ* weighted) {
-    G1XYZZ sa = g1_xyzz_identity(), wsum = g1_xyzz_identity(), suffix = g1_xyzz_identity(), gsum = g1_xyzz_identity();
+    G1XYZZ sa = HF::identity(), wsum = HF::identity(), suffix = HF::identity(), gsum = HF::identity();
     for (unsigned g = G; g-- > 0;) {
-        g1_add(sa, ga[g]);
-        g1_add(wsum, gw[g]);
-        g1_add(suffix, gr[g]);
-        if (g > 0) g1_add(gsum, suffix);  // sum_g g SR_g
+        HF::add(sa, ga[g]);
+        HF::add(wsum, gw[g]);
+        HF::add(suffix, gr[g]);
+        if (g > 0) HF::add(gsum, suffix);  // sum_g g SR_g
     }
-    for (int k = 0; k < 4; k++) gsum = g1_dbl(gsum);
+    for (int k = 0; k < 4; k++) gsum = HF::dbl(gsum);
     static_assert(FOLD_GROUP == 16, "four doublings");
-    g1_add(wsum, gsum);
+    HF::add(wsum, gsum);
     *sum_a = sa;
     *weighted = wsum;
 }
@@ -1771,7 +2049,8 @@ static void fold_groups_combine(const G1XYZZ* ga, const G1XYZZ* gr, const G1XYZZ
 // ONE job (null: serial — the caller is already folding several jobs side by side).  Returns false on an inconsistent
 // window layout (internal error).
 // `groups` (flat schedule, more than one group): the group sums (ga | gr | gw, G each) were already computed by the caller.
-static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1XYZZ* groups = nullptr) {
+template <class HF>
+static bool msm_fold_form(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1XYZZ* groups) {
     // host: per window  X_w = sum_blk A_blk + 2^shift * W_w,  W_w = sum_blk blk R_blk  (2^shift = RED_BLOCK * m buckets per
     // workgroup; W_w by suffix sums over the <= 16 workgroups).  The windows are independent: they are folded on the
     // context's host workers.  Then Horner over the windows (high -> low, c_w doublings each), with the 2^shift of W_w
@@ -1783,7 +2062,7 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1
     G1XYZZ sum_a[MAX_WIN], weighted[MAX_WIN];
     auto fold_window = [&](int w) {
         G1XYZZ sr;
-        fold_range(job->host + (size_t)w * nb * 2, 0, nb, &sum_a[w], &sr, &weighted[w]);
+        fold_range<HF>(job->host + (size_t)w * nb * 2, 0, nb, &sum_a[w], &sr, &weighted[w]);
     };
     auto run = [&](int n, const std::function<void(int)>& fn) {
         if (pool) pool->parallel_for(n, fn);
@@ -1797,33 +2076,36 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1
             own.resize(3 * (size_t)G);
             G1XYZZ* o = own.data();
             run((int)G, [&](int g) {
-                fold_range(job->host, FOLD_GROUP * g, std::min(nb, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
+                fold_range<HF>(job->host, FOLD_GROUP * g, std::min(nb, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
             });
             groups = o;
         }
-        fold_groups_combine(groups, groups + G, groups + 2 * G, G, &sum_a[0], &weighted[0]);
+        fold_groups_combine<HF>(groups, groups + G, groups + 2 * G, G, &sum_a[0], &weighted[0]);
     } else if (nb > 1 && pl.nwin > 1) {
         run((int)pl.nwin, fold_window);
     } else {
         for (unsigned w = 0; w < pl.nwin; w++) fold_window((int)w);
     }
-    G1XYZZ total_pt = g1_xyzz_identity();
+    G1XYZZ total_pt = HF::identity();
     for (unsigned w = pl.nwin; w-- > 0;) {
         unsigned cw = pl.c[w];
-        if (!g1_is_inf(weighted[w])) {
+        if (!HF::is_inf(weighted[w])) {
             if (cw >= shift) {
-                for (unsigned k = shift; k < cw; k++) total_pt = g1_dbl(total_pt);
-                g1_add(total_pt, weighted[w]);
+                for (unsigned k = shift; k < cw; k++) total_pt = HF::dbl(total_pt);
+                HF::add(total_pt, weighted[w]);
                 cw = shift;
             } else {  // a window narrower than one workgroup's span cannot have content beyond workgroup 0
                 return false;
             }
         }
-        for (unsigned k = 0; k < cw; k++) total_pt = g1_dbl(total_pt);
-        g1_add(total_pt, sum_a[w]);
+        for (unsigned k = 0; k < cw; k++) total_pt = HF::dbl(total_pt);
+        HF::add(total_pt, sum_a[w]);
     }
-    *result = total_pt;
+    *result = HF::to_xyzz(total_pt);
     return true;
+}
+static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1XYZZ* groups = nullptr) {
+    return job->te ? msm_fold_form<HostTE>(job, pool, result, groups) : msm_fold_form<HostXYZZ>(job, pool, result, groups);
 }
 
 static HostPool* host_pool_of(swm_ctx* ctx) {
@@ -1912,7 +2194,8 @@ int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
         } else {
             const unsigned G = (j->red_blocks + FOLD_GROUP - 1) / FOLD_GROUP, g = (unsigned)tk.group;
             G1XYZZ* o = groups[tk.job].data();
-            fold_range(j->host, FOLD_GROUP * g, std::min(j->red_blocks, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
+            if (j->te) fold_range<HostTE>(j->host, FOLD_GROUP * g, std::min(j->red_blocks, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
+            else fold_range<HostXYZZ>(j->host, FOLD_GROUP * g, std::min(j->red_blocks, FOLD_GROUP * (g + 1)), &o[g], &o[G + g], &o[2 * G + g]);
         }
     });
     host_pool_of(ctx)->parallel_for((int)live.size(), [&](int t) {  // per job: the combine of its group sums
