@@ -339,3 +339,43 @@ def verify_proof(verifying_key, public_inputs, proof, rng):
     _check(lib.swm_verify_proof(verifying_key.h, _p64(pi) if len(pi) else None, len(pi), data, len(proof.data), rng.h,
                                 ctypes.byref(ok)), "swm_verify_proof")
     return bool(ok.value)
+
+
+class MarlinInst:
+    """`MarlinInst` (= ark_marlin::Marlin<Fr, MultiPC, FS>, src/marlin/mod.rs:14) as the reference's in-tree callers use
+    it: associated functions that take a ConstraintSynthesizer — SimpleMerkleTree::{new, prove, verify}
+    (src/merkle_tree/simple_merkle_tree.rs:39,83,119,148), examples/manual-constraints.rs:89-99,
+    examples/merkle-tree/main.rs:212-257, examples/simple-payments/transaction.rs:96-125.  A synthesizer here is any
+    object with generate_constraints(cs) (ark_relations::r1cs::ConstraintSynthesizer); index / prove run it into a fresh
+    ConstraintSystem, as ark-marlin does, and forward to the five functions below.  Mirrors swmarlin-sys'
+    `pub struct MarlinInst` (swmarlin-sys/src/marlin.rs) method for method."""
+
+    @staticmethod
+    def universal_setup(num_constraints, num_variables, num_non_zero, rng, ctx=None):
+        return generate_universal_srs(num_constraints, num_variables, num_non_zero, rng, ctx)
+
+    @staticmethod
+    def _synthesize(circuit):
+        cs = ConstraintSystem()
+        circuit.generate_constraints(cs)
+        return cs
+
+    @staticmethod
+    def index(universal_srs, circuit):
+        return generate_proving_and_verifying_keys(universal_srs, MarlinInst._synthesize(circuit))
+
+    @staticmethod
+    def index_from_constraint_system(universal_srs, constraint_system):
+        return generate_proving_and_verifying_keys(universal_srs, constraint_system)
+
+    @staticmethod
+    def prove(index_pk, circuit, zk_rng):
+        return generate_proof(MarlinInst._synthesize(circuit), index_pk, zk_rng)
+
+    @staticmethod
+    def prove_from_constraint_system(index_pk, constraint_system, zk_rng):
+        return generate_proof(constraint_system, index_pk, zk_rng)
+
+    @staticmethod
+    def verify(index_vk, public_input, proof, rng):
+        return verify_proof(index_vk, public_input, proof, rng)

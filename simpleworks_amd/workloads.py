@@ -432,3 +432,75 @@ def merkle_membership_circuit(height=19, leaf_u8=0xA7, leaf_index=None, seed=7, 
     cs = ConstraintSystem()
     public = build_merkle_membership(cs, params, leaf_u8, leaf_index, siblings, gadget_byte_ops, root)
     return cs, public, params
+
+
+# ===================================================================================================================
+# The reference's driver of that circuit: SimpleMerkleTree (src/merkle_tree/simple_merkle_tree.rs:35-153), call for call
+# ===================================================================================================================
+class MerkleTreeVerificationU8:
+    """The ConstraintSynthesizer the driver hands to MarlinInst (src/merkle_tree/merkle_tree_verification_u8.rs:25-58):
+    constants = hash parameters, public = root + leaf, witness = authentication path."""
+
+    def __init__(self, params, root, leaf, leaf_index, authentication_path, gadget_byte_ops=0):
+        self.params, self.root, self.leaf, self.leaf_index = params, root, leaf, leaf_index
+        self.authentication_path, self.gadget_byte_ops = list(authentication_path), gadget_byte_ops
+
+    def generate_constraints(self, cs):
+        build_merkle_membership(cs, self.params, self.leaf, self.leaf_index, self.authentication_path,
+                                self.gadget_byte_ops, root=self.root)
+
+
+def merkle_tree_height(leaves_length):
+    """src/merkle_tree/simple_merkle_tree.rs:155-163."""
+    result = 0
+    while leaves_length:
+        result += 1
+        leaves_length >>= 1
+    return result
+
+
+class SimpleMerkleTree:
+    """SimpleMerkleTree::{new, get_merkle_path, prove, verify} with the same call sequence into MarlinInst: a fresh test_rng
+    and universal_setup(100_000, 25_000, 300_000) in new(), keys from a DUMMY circuit over a blank tree of the same height
+    (the circuit's shape depends on the height only), a fresh test_rng per prove / verify, proofs as serialised bytes,
+    verify(proof_bytes, leaf_u8) rebuilding the public input [root, 8 bits LSB-first].  Hash parameters: MerkleParams (the
+    reference samples them from the same rng; here they are derived from a seed — circuit constants either way)."""
+
+    def __init__(self, leaves_u8, params=None, srs_sizes=(100_000, 25_000, 300_000), gadget_byte_ops=0, ctx=None):
+        from . import marlin as M
+        from . import serialization as S
+        self._M, self._S = M, S
+        rng = M.generate_rand()                                                  # ark_std::test_rng()
+        universal_srs = M.MarlinInst.universal_setup(*srs_sizes, rng, ctx)       # simple_merkle_tree.rs:39
+        self.params = params or MerkleParams()
+        self.leaves = list(leaves_u8)
+        self.levels = self.params.build_tree(self.leaves)                        # MerkleTree::new, :47-49
+        height = merkle_tree_height(len(self.leaves))
+        blank_path = [0] * (height - 1)                                          # MerkleTree::blank(..).generate_proof(0)
+        blank_root = self.params.root_from_path(0, 0, blank_path)
+        dummy = MerkleTreeVerificationU8(self.params, blank_root, 0, 0, blank_path, gadget_byte_ops)
+        self.gadget_byte_ops = gadget_byte_ops
+        self.proving_key, self.verifying_key = M.MarlinInst.index(universal_srs, dummy)   # :83
+        universal_srs.free()
+
+    def root(self):
+        return self.levels[-1][0]
+
+    def get_merkle_path(self, leaf_index):
+        return leaf_index, MerkleParams.path_of(self.levels, leaf_index)
+
+    def prove(self, leaf, merkle_path):
+        leaf_index, siblings = merkle_path
+        circuit = MerkleTreeVerificationU8(self.params, self.root(), leaf, leaf_index, siblings, self.gadget_byte_ops)
+        rng = self._M.generate_rand()
+        proof = self._M.MarlinInst.prove(self.proving_key, circuit, rng)         # :119
+        return self._S.serialize_proof(proof)                                    # proof.serialize(&mut bytes)
+
+    def verify(self, proof_bytes, input_u8):
+        input_vec = [self.root()] + [(input_u8 >> i) & 1 for i in range(8)]      # :129-143
+        proof = self._S.deserialize_proof(proof_bytes)
+        rng = self._M.generate_rand()
+        return self._M.MarlinInst.verify(self.verifying_key, input_vec, proof, rng)   # :148
+
+    def free(self):
+        self.proving_key.free()

@@ -7,7 +7,11 @@
 //! pub mod serialization;            // unchanged: ark-serialize on arkworks types
 //! ```
 //! and every caller (`SimpleMerkleTree`, the examples, external VMs) compiles unchanged: the types are still the
-//! arkworks types, the rng is still the caller's `&mut StdRng`.
+//! arkworks types, the rng is still the caller's `&mut StdRng`, and `MarlinInst::{universal_setup, index, prove, verify}`
+//! — what those callers actually invoke, with a `ConstraintSynthesizer` — is a unit struct of this crate that forwards to
+//! the library (the reference's alias of arkworks' CPU prover is kept as `ArkMarlinInst`).
+//!
+//! EXPERIMENTAL: written without a Rust toolchain or the arkworks sources at hand; never compiled.  See INTEGRATION.md.
 pub mod ffi;
 pub mod marlin;
 mod convert;

@@ -9,8 +9,8 @@
 //! * `UniversalSRS`        -> `swm_srs_export` / `swm_srs_import` (the fields of kzg10::UniversalParams).
 //! * `ProvingKey`, `VerifyingKey`, `MarlinProof` -> their CanonicalSerialize bytes, which the library reads and writes
 //!                            (`swm_pk_*`, `swm_vk_*`, proof bytes) — the interchange format src/marlin/serialization.rs defines.
-//! Device-resident twins of keys and SRS are cached per thread, keyed by a digest of the verifying key (resp. of the first
-//! SRS powers), so `generate_proof(cs, proving_key, rng)` — which takes the key BY VALUE in the reference — pays the
+//! Device-resident twins of keys and SRS are cached per thread — keys by a digest of their verifying key and committer-key
+//! shape, at most four at a time (least recently used evicted), SRS by their first powers — so `generate_proof(cs, proving_key, rng)` — which takes the key BY VALUE in the reference — pays the
 //! import (serialise + upload + re-derive tables) once per key and thread, not once per proof.
 use crate::convert::*;
 use crate::ffi::*;
@@ -27,6 +27,7 @@ use digest::Digest;
 use rand::rngs::StdRng;
 use rand::RngCore;
 use rand_chacha::ChaChaRng;
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystem, OptimizationGoal, SynthesisMode};
 use std::cell::RefCell;
 use std::collections::{BTreeMap, HashMap};
 use std::ffi::CStr;
@@ -34,7 +35,11 @@ use std::os::raw::{c_int, c_void};
 
 pub type MultiPC = MarlinKZG10<Bls12_377, DensePolynomial<Fr>>;
 pub type FS = SimpleHashFiatShamirRng<Blake2s, ChaChaRng>;
-pub type MarlinInst = Marlin<Fr, MultiPC, FS>;
+/// arkworks' own CPU prover (`Marlin<Fr, MultiPC, FS>`): what the reference calls `MarlinInst`.  Kept under another name for
+/// A/B checks; the name `MarlinInst` below is the MI355X implementation with the same associated functions.
+pub type ArkMarlinInst = Marlin<Fr, MultiPC, FS>;
+/// The error type of `Marlin::{universal_setup, index, prove, verify}` for this instantiation.
+pub type MarlinError = ark_marlin::Error<ark_poly_commit::Error>;
 pub type UniversalSRS = ark_marlin::UniversalSRS<Fr, MultiPC>;
 pub type ConstraintSystemRef = ark_relations::r1cs::ConstraintSystemRef<Fr>;
 pub type VerifyingKey =
@@ -68,23 +73,45 @@ fn check(rc: c_int, what: &'static str, ctx: *mut swm_ctx) -> std::result::Resul
 
 // ------------------------------------------------------------------------------------------------ per-thread state
 // A ConstraintSystemRef is Rc<RefCell<..>> (!Send): one proof is driven by one thread, and so is one context.
+/// Device-resident keys of this thread, most recently used last; at most `PK_CACHE` of them (each holds its committer key
+/// and MSM tables in HBM: multi-GB at 2^20 constraints), the least recently used one is destroyed on overflow.
+const PK_CACHE: usize = 4;
 struct State {
     ctx: *mut swm_ctx,
     srs: HashMap<[u8; 32], *mut swm_srs>,
-    pks: HashMap<[u8; 32], *mut swm_pk>,
+    pks: Vec<([u8; 32], *mut swm_pk)>,
+}
+impl State {
+    fn pk_get(&mut self, key: &[u8; 32]) -> Option<*mut swm_pk> {
+        let i = self.pks.iter().position(|(k, _)| k == key)?;
+        let e = self.pks.remove(i);
+        self.pks.push(e);
+        Some(e.1)
+    }
+    fn pk_put(&mut self, key: [u8; 32], h: *mut swm_pk) {
+        if let Some(i) = self.pks.iter().position(|(k, _)| *k == key) {
+            let (_, old) = self.pks.remove(i);
+            unsafe { swm_pk_destroy(self.ctx, old) };
+        }
+        if self.pks.len() >= PK_CACHE {
+            let (_, old) = self.pks.remove(0);
+            unsafe { swm_pk_destroy(self.ctx, old) };
+        }
+        self.pks.push((key, h));
+    }
 }
 impl State {
     fn new() -> std::result::Result<Self, SwmError> {
         let device = std::env::var("SWM_DEVICE").ok().and_then(|s| s.parse::<c_int>().ok()).unwrap_or(0);
         let mut ctx = std::ptr::null_mut();
         check(unsafe { swm_init(device, &mut ctx) }, "swm_init", std::ptr::null_mut())?;
-        Ok(State { ctx, srs: HashMap::new(), pks: HashMap::new() })
+        Ok(State { ctx, srs: HashMap::new(), pks: Vec::new() })
     }
 }
 impl Drop for State {
     fn drop(&mut self) {
         unsafe {
-            for (_, pk) in self.pks.drain() {
+            for (_, pk) in self.pks.drain(..) {
                 swm_pk_destroy(self.ctx, pk);
             }
             for (_, srs) in self.srs.drain() {
@@ -108,15 +135,16 @@ fn with_state<T>(f: impl FnOnce(&mut State) -> std::result::Result<T, SwmError>)
 }
 
 // ------------------------------------------------------------------------------------------------ the caller's rng
-unsafe extern "C" fn fill_bytes_trampoline(user: *mut c_void, dest: *mut u8, len: usize) {
-    let rng = &mut *(user as *mut StdRng);
+unsafe extern "C" fn fill_bytes_trampoline<R: RngCore>(user: *mut c_void, dest: *mut u8, len: usize) {
+    let rng = &mut *(user as *mut R);
     rng.fill_bytes(std::slice::from_raw_parts_mut(dest, len));
 }
-/// Runs `f` with a library handle that draws from `rng`; the handle does not outlive the borrow.
-fn with_rng<T>(rng: &mut StdRng, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+/// Runs `f` with a library handle that draws from `rng` (any `RngCore`, as `Marlin`'s associated functions accept; the
+/// reference always passes its `StdRng`); the handle does not outlive the borrow.
+fn with_rng<R: RngCore, T>(rng: &mut R, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
     let mut h = std::ptr::null_mut();
     check(
-        unsafe { swm_rng_from_callback(fill_bytes_trampoline, rng as *mut StdRng as *mut c_void, &mut h) },
+        unsafe { swm_rng_from_callback(fill_bytes_trampoline::<R>, rng as *mut R as *mut c_void, &mut h) },
         "swm_rng_from_callback",
         std::ptr::null_mut(),
     )?;
@@ -143,6 +171,25 @@ fn srs_key(srs: &UniversalSRS) -> [u8; 32] {
     }
     digest32(&bytes)
 }
+/// Identity of a proving key for the resident-twin cache: its verifying key AND its committer key (a key with the same
+/// index under another SRS, or trimmed differently, is a different key).
+fn pk_key(pk: &ProvingKey, vk_bytes: &[u8]) -> [u8; 32] {
+    let ck = &pk.committer_key;
+    let mut bytes = Vec::with_capacity(vk_bytes.len() + 8 * (3 + 12 * 4));
+    bytes.extend_from_slice(vk_bytes);
+    let shifted: &[G1Affine] = ck.shifted_powers.as_deref().unwrap_or(&[]);
+    for v in [ck.powers.len() as u64, shifted.len() as u64, ck.max_degree as u64] {
+        bytes.extend_from_slice(&v.to_le_bytes());
+    }
+    let mut limbs = [0u64; 12];
+    for p in ck.powers.iter().take(2).chain(ck.powers.last()).chain(shifted.last()) {
+        g1_limbs(p, &mut limbs);
+        for w in limbs {
+            bytes.extend_from_slice(&w.to_le_bytes());
+        }
+    }
+    digest32(&bytes)
+}
 fn vk_key(vk: &VerifyingKey) -> std::result::Result<([u8; 32], Vec<u8>), SwmError> {
     let mut bytes = Vec::new();
     vk.serialize(&mut bytes).map_err(|e| SwmError { code: -7, what: "VerifyingKey::serialize", detail: format!("{:?}", e) })?;
@@ -165,7 +212,7 @@ pub fn generate_universal_srs(
     universal_setup(num_constraints, num_variables, num_non_zero, rng).map(Box::new).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn universal_setup(nc: usize, nv: usize, nnz: usize, rng: &mut StdRng) -> std::result::Result<UniversalSRS, SwmError> {
+fn universal_setup<R: RngCore>(nc: usize, nv: usize, nnz: usize, rng: &mut R) -> std::result::Result<UniversalSRS, SwmError> {
     with_state(|st| {
         let ctx = st.ctx;
         let handle = with_rng(rng, |r| {
@@ -268,9 +315,7 @@ fn index(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(Pr
         let pk = ProvingKey::deserialize(&mut pk_bytes.as_slice()).map_err(de);
         match (pk, vk) {
             (Ok(pk), Ok(vk)) => {
-                if let Some(old) = st.pks.insert(digest32(&vk_bytes), pk_h) {
-                    unsafe { swm_pk_destroy(ctx, old) };
-                }
+                st.pk_put(pk_key(&pk, &vk_bytes), pk_h);
                 Ok((pk, vk))
             }
             (Err(e), _) | (_, Err(e)) => {
@@ -282,16 +327,17 @@ fn index(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(Pr
 }
 
 fn resident_pk(st: &mut State, pk: &ProvingKey) -> std::result::Result<*mut swm_pk, SwmError> {
-    let (key, _) = vk_key(&pk.index_vk)?;
-    if let Some(h) = st.pks.get(&key) {
-        return Ok(*h);
+    let (_, vk_bytes) = vk_key(&pk.index_vk)?;
+    let key = pk_key(pk, &vk_bytes);
+    if let Some(h) = st.pk_get(&key) {
+        return Ok(h);
     }
     // a key this thread has not seen (deserialised from disk, built by arkworks): move it in through its bytes
     let mut bytes = Vec::new();
     pk.serialize(&mut bytes).map_err(|e| SwmError { code: -7, what: "ProvingKey::serialize", detail: format!("{:?}", e) })?;
     let mut h = std::ptr::null_mut();
     check(unsafe { swm_pk_deserialize(st.ctx, bytes.as_ptr(), bytes.len(), &mut h) }, "swm_pk_deserialize", st.ctx)?;
-    st.pks.insert(key, h);
+    st.pk_put(key, h);
     Ok(h)
 }
 
@@ -304,7 +350,7 @@ pub fn generate_proof(
     prove(&proving_key, constraint_system, rng).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn prove(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut StdRng) -> std::result::Result<MarlinProof, SwmError> {
+fn prove<R: RngCore>(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut R) -> std::result::Result<MarlinProof, SwmError> {
     let packed = PackedR1cs::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "to_matrices", detail: format!("{:?}", e) })?;
     with_state(|st| {
         let ctx = st.ctx;
@@ -327,7 +373,7 @@ pub fn verify_proof(
     verify(&verifying_key, public_inputs, proof, rng).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn verify(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mut StdRng) -> std::result::Result<bool, SwmError> {
+fn verify<R: RngCore>(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, SwmError> {
     let (_, vk_bytes) = vk_key(vk)?;
     let mut proof_bytes = Vec::new();
     proof.serialize(&mut proof_bytes).map_err(|e| SwmError { code: -7, what: "Proof::serialize", detail: format!("{:?}", e) })?;
@@ -349,12 +395,87 @@ fn verify(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mu
     out.map(|_| ok != 0)
 }
 
+// ------------------------------------------------------------------------------------------------ MarlinInst
+/// `MarlinInst` as every in-tree caller of the reference uses it — `SimpleMerkleTree::{new, prove, verify}`
+/// (/root/reference/src/merkle_tree/simple_merkle_tree.rs:39,83,119,148), `examples/manual-constraints.rs:89-99`,
+/// `examples/merkle-tree/main.rs:212-257`, `examples/simple-payments/transaction.rs:96-125`, `examples/test-circuit.rs:74-80`,
+/// `examples/schnorr-signature/main.rs:191-252` — is `ark_marlin::Marlin<Fr, MultiPC, FS>`: associated functions taking a
+/// `ConstraintSynthesizer`.  This unit struct has the same associated functions with the same argument and `Result` types
+/// (errors are `ark_marlin::Error<ark_poly_commit::Error>`, which those callers format with `{:?}` or `unwrap`), and sends
+/// the work to the MI355X library: after `pub use swmarlin_sys::marlin::*` those call sites compile unchanged and no longer
+/// run arkworks' CPU prover.
+///
+/// Synthesis follows ark-marlin 0.3 (`Marlin::index` / `Marlin::prove`): a fresh `ConstraintSystem`, optimisation goal
+/// `Weight`, mode `Setup` for the indexer and `Prove { construct_matrices: true }` for the prover, `generate_constraints`,
+/// then `finalize` + `to_matrices` (`PackedR1cs::from_cs`); padding to a square system happens inside the library.
+pub struct MarlinInst;
+
+/// Library status -> the variant arkworks would have returned where one exists, else a polynomial-commitment error that
+/// carries the library's message (callers only ever format the error).
+fn to_marlin_error(e: SwmError) -> MarlinError {
+    match e.code {
+        -6 => ark_marlin::Error::IndexTooLarge, // SWM_ERR_INDEX_TOO_LARGE
+        _ => ark_marlin::Error::PolynomialCommitmentError(ark_poly_commit::Error::IncorrectInputLength(format!(
+            "swmarlin {}: {} ({})",
+            e.what, e.detail, e.code
+        ))),
+    }
+}
+fn synthesize<C: ConstraintSynthesizer<Fr>>(c: C, mode: SynthesisMode) -> std::result::Result<ConstraintSystemRef, MarlinError> {
+    let cs = ConstraintSystem::<Fr>::new_ref();
+    cs.set_optimization_goal(OptimizationGoal::Weight);
+    cs.set_mode(mode);
+    c.generate_constraints(cs.clone()).map_err(ark_marlin::Error::R1CSError)?;
+    Ok(cs)
+}
+
+impl MarlinInst {
+    /// `Marlin::universal_setup` (simple_merkle_tree.rs:39).
+    pub fn universal_setup<R: RngCore>(
+        num_constraints: usize,
+        num_variables: usize,
+        num_non_zero: usize,
+        rng: &mut R,
+    ) -> std::result::Result<UniversalSRS, MarlinError> {
+        universal_setup(num_constraints, num_variables, num_non_zero, rng).map_err(to_marlin_error)
+    }
+
+    /// `Marlin::index` (simple_merkle_tree.rs:83): index the circuit `c` under `srs`.
+    pub fn index<C: ConstraintSynthesizer<Fr>>(srs: &UniversalSRS, c: C) -> std::result::Result<(ProvingKey, VerifyingKey), MarlinError> {
+        let cs = synthesize(c, SynthesisMode::Setup)?;
+        index(srs, cs).map_err(to_marlin_error)
+    }
+
+    /// The fork's entry point for an already synthesised system (/root/reference/src/marlin/mod.rs:92).
+    pub fn index_from_constraint_system(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(ProvingKey, VerifyingKey), MarlinError> {
+        index(srs, cs).map_err(to_marlin_error)
+    }
+
+    /// `Marlin::prove` (simple_merkle_tree.rs:119).  An unsatisfied witness is an `Err` here (ark-marlin panics on a
+    /// debug assertion, which the reference's `#[should_panic]` test reaches through `unwrap`: same outcome).
+    pub fn prove<C: ConstraintSynthesizer<Fr>, R: RngCore>(index_pk: &ProvingKey, c: C, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
+        let cs = synthesize(c, SynthesisMode::Prove { construct_matrices: true })?;
+        prove(index_pk, cs, zk_rng).map_err(to_marlin_error)
+    }
+
+    /// The fork's entry point for an already synthesised system (/root/reference/src/marlin/mod.rs:75).
+    pub fn prove_from_constraint_system<R: RngCore>(index_pk: &ProvingKey, cs: ConstraintSystemRef, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
+        prove(index_pk, cs, zk_rng).map_err(to_marlin_error)
+    }
+
+    /// `Marlin::verify` (simple_merkle_tree.rs:148).
+    pub fn verify<R: RngCore>(index_vk: &VerifyingKey, public_input: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, MarlinError> {
+        verify(index_vk, public_input, proof, rng).map_err(to_marlin_error)
+    }
+}
+
 #[cfg(test)]
 mod tests {
     //! The reference's own plumbing test (examples/manual-constraints.rs:86-100) against this module: needs an MI355X.
     use super::*;
     use ark_relations::{lc, r1cs::{ConstraintSynthesizer, ConstraintSystem, SynthesisError, Variable}};
 
+    #[derive(Clone)]
     struct ManualConstraints { a: Fr, b: Fr }
     impl ConstraintSynthesizer<Fr> for ManualConstraints {
         fn generate_constraints(self, cs: ark_relations::r1cs::ConstraintSystemRef<Fr>) -> std::result::Result<(), SynthesisError> {
@@ -362,6 +483,27 @@ mod tests {
             let b = cs.new_witness_variable(|| Ok(self.b))?;
             cs.enforce_constraint(lc!() + a - b, lc!() + Variable::One, lc!())
         }
+    }
+
+    /// examples/manual-constraints.rs:86-100 verbatim (MarlinInst with a ConstraintSynthesizer, `rng` reborrowed).
+    #[test]
+    fn manual_constraints_through_marlin_inst() {
+        let rng = &mut ark_std::test_rng();
+        let universal_srs = MarlinInst::universal_setup(100, 25, 300, rng).unwrap();
+        let number = Fr::from(1u64);
+        let circuit = ManualConstraints { a: number, b: number };
+        let (index_pk, index_vk) = MarlinInst::index(&universal_srs, circuit.clone()).unwrap();
+        let proof = MarlinInst::prove(&index_pk, circuit.clone(), rng).unwrap();
+        assert!(MarlinInst::verify(&index_vk, &[number], &proof, rng).unwrap());
+        // and the bytes are what arkworks' CPU prover emits for the same circuit, key and rng stream
+        let rng2 = &mut ark_std::test_rng();
+        let srs2 = ArkMarlinInst::universal_setup(100, 25, 300, rng2).unwrap();
+        let (pk2, _vk2) = ArkMarlinInst::index(&srs2, circuit.clone()).unwrap();
+        let proof2 = ArkMarlinInst::prove(&pk2, circuit, rng2).unwrap();
+        let (mut b1, mut b2) = (Vec::new(), Vec::new());
+        proof.serialize(&mut b1).unwrap();
+        proof2.serialize(&mut b2).unwrap();
+        assert_eq!(b1, b2);
     }
 
     #[test]

@@ -624,3 +624,44 @@ def test_proving_key_roundtrip_2p16_and_table_schedule(M, S, W):
     assert M.verify_proof(vk, public, p2, M.generate_rand())
     pk.free()
     pk2.free()
+
+
+# ---- proof bytes at real sizes (BASELINE config #2: "2^16 ... bit-exact vs CPU").  tests/golden/marlin_large.json comes
+# from the independent Python prover with the C restatement of the arkworks kernels plugged in (gen_golden_large.py).
+@pytest.mark.parametrize("name", ["synthetic_2p12", "synthetic_2p16"])
+def test_golden_proof_bytes_at_size(M, S, W, name):
+    case = golden("marlin_large.json")[name]
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*case["srs"], rng)
+    assert srs.max_degree == case["max_degree"]
+    n = case["num_constraints"]
+    cs, public = W.synthetic_r1cs(n, h2i(case["a"]), h2i(case["b"]))
+    assert [int(x) for x in public] == [h2i(x) for x in case["public_input"]]
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]
+    proof = M.generate_proof(cs, pk, rng)
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert M.verify_proof(vk, public, proof, rng)
+    pk.free()
+    srs.free()
+
+
+def test_golden_proof_bytes_merkle_height_5(M, S, W):
+    """The Pedersen-Merkle membership circuit with the reference's hash shape (144 / 128 windows of 4 bits, 256-bit
+    digests) at height 5: 15 427 constraints, |H| = 2^14, |K| = 2^15 — bytes of the Python model."""
+    case = golden("marlin_large.json")["merkle_h5"]
+    kw = case["circuit"]
+    cs, public, _ = W.merkle_membership_circuit(height=kw["height"], leaf_u8=kw["leaf_u8"], seed=kw["seed"],
+                                                gadget_byte_ops=kw["gadget_byte_ops"])
+    assert [int(x) for x in public] == [h2i(x) for x in case["public_input"]]
+    assert cs.num_constraints == case["num_constraints"]
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*case["srs"], rng)
+    assert srs.max_degree == case["max_degree"]
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]
+    proof = M.generate_proof(cs, pk, rng)
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert M.verify_proof(vk, public, proof, rng)
+    pk.free()
+    srs.free()

@@ -180,3 +180,58 @@ def test_merkle_full_prove_verify(M, S, W, full):
         M.generate_proof(bad, pk, rng)
     assert e.value.code == -5
     pk.free()
+
+
+# ---- the reference's own call sequences, through MarlinInst with a ConstraintSynthesizer (what its callers actually hit)
+def test_simple_merkle_tree_call_sequence_through_marlin_inst(M, W):
+    """SimpleMerkleTree::{new, get_merkle_path, prove, verify} (/root/reference/src/merkle_tree/simple_merkle_tree.rs:35-153),
+    call for call: universal_setup(100_000, 25_000, 300_000), keys indexed from a DUMMY circuit over a blank tree,
+    MarlinInst::prove with the real circuit, proofs as bytes, verify(bytes, leaf) over [root, 8 LSB-first bits] — and its
+    tests `:275-291` (a valid proof verifies) and `:224-273` (a wrong leaf does not)."""
+    leaves = [3, 200, 77, 9, 0, 255, 16, 42]
+    tree = W.SimpleMerkleTree(leaves)
+    assert W.merkle_tree_height(len(leaves)) == 4
+    path = tree.get_merkle_path(5)
+    proof = tree.prove(leaves[5], path)
+    assert isinstance(proof, bytes) and len(proof) > 900
+    assert tree.verify(proof, leaves[5])
+    assert not tree.verify(proof, leaves[5] ^ 1)          # another leaf value: rejected by the pairing check
+    proof2 = tree.prove(leaves[0], tree.get_merkle_path(0))
+    assert tree.verify(proof2, leaves[0]) and not tree.verify(proof2, leaves[5])
+    with pytest.raises(M.MarlinError) as e:               # a leaf that is not at that position: fails at prove time
+        tree.prove(leaves[5] ^ 0x10, path)
+    assert e.value.code == -5
+    tree.free()
+
+
+def test_marlin_inst_with_a_synthesizer_matches_golden_bytes(M, S):
+    """examples/manual-constraints.rs:86-100: MarlinInst::{universal_setup, index, prove, verify} with a circuit OBJECT
+    (generate_constraints), rng passed along — the bytes of tests/golden/marlin.json."""
+    case = golden("marlin.json")["manual_constraints"]
+
+    class ManualConstraints:  # examples/manual-constraints.rs:15-31
+        def __init__(self, a, b):
+            self.a, self.b = a, b
+
+        def generate_constraints(self, cs):
+            a = cs.new_input_variable(self.a)
+            b = cs.new_witness_variable(self.b)
+            cs.enforce_constraint([(1, a), (M.R_MODULUS - 1, b)], [(1, cs.one())], [])
+
+    rng = M.generate_rand()
+    universal_srs = M.MarlinInst.universal_setup(100, 25, 300, rng)
+    circuit = ManualConstraints(1, 1)
+    index_pk, index_vk = M.MarlinInst.index(universal_srs, circuit)
+    proof = M.MarlinInst.prove(index_pk, circuit, rng)
+    assert S.serialize_verifying_key(index_vk).hex() == case["vk"]
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert M.MarlinInst.verify(index_vk, [1], proof, rng)
+    # the fork's entry points on an already synthesised system give the same bytes
+    rng = M.generate_rand()
+    srs2 = M.MarlinInst.universal_setup(100, 25, 300, rng)
+    cs = M.ConstraintSystem()
+    circuit.generate_constraints(cs)
+    pk2, vk2 = M.MarlinInst.index_from_constraint_system(srs2, cs)
+    assert S.serialize_proof(M.MarlinInst.prove_from_constraint_system(pk2, cs, rng)).hex() == case["proof"]
+    for h in (index_pk, pk2, universal_srs, srs2):
+        h.free()
