@@ -153,6 +153,14 @@ def main():
                     help="prove workloads: `synthetic` = the 2^L-row a*b=c circuit of BASELINE configs[1-3] (default, the "
                          "headline); `merkle` = the Pedersen-hash Merkle-membership circuit of BASELINE configs[4] "
                          "(tree over 2^18 leaves, + the simpleworks UInt8 gadget block; --log-n is ignored)")
+    ap.add_argument("--rng", default="builtin", choices=["builtin", "callback", "adopt"],
+                    help="where the prover's randomness comes from in the TIMED loop: `builtin` = the library's ChaCha12 "
+                         "(ark_std::test_rng's stream; the headline), `callback` = a caller-owned generator behind "
+                         "swm_rng_from_callback (what a binding that keeps `&mut StdRng` gets; the caller here is a host "
+                         "ChaCha12 standing for StdRng), `adopt` = the caller's ChaCha state handed over with "
+                         "swm_rng_from_chacha and written back after every proof.  Whatever is chosen, the line carries a "
+                         "`drop_in_rng` object with the other modes measured over a few proofs.")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in_rng proofs after the timed loop (profiling runs)")
     ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true",
@@ -240,9 +248,22 @@ def main():
         pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
         srs.free()
         last = {}
+        caller = M.generate_rand()  # "the caller's StdRng" of the callback mode (host ChaCha12, AVX2, test_rng seed)
+        cb_rng = M.rng_behind_callback(caller)
+        adopt_pos = [0]             # "the caller's StdRng" of the adopt mode: (TEST_RNG_SEED, word position)
+
+        def prove_with(mode):
+            if mode == "callback":      # every draw goes through fill_bytes of the caller's generator
+                return M.generate_proof(cs, pk, cb_rng)
+            if mode == "adopt":         # get_seed / get_word_pos in, set_word_pos out: the caller's stream, drawn on the GPU
+                r = M.rng_from_chacha(M.TEST_RNG_SEED, adopt_pos[0], 12)
+                proof = M.generate_proof(cs, pk, r)
+                adopt_pos[0] = r.word_pos()   # what the binding writes back with rng.set_word_pos(..)
+                return proof
+            return M.generate_proof(cs, pk, rng)
 
         def step():
-            last["proof"] = M.generate_proof(cs, pk, rng)
+            last["proof"] = prove_with(args.rng)
         dominant, units, unit = "msm_accumulate", n, "constraints/s"
         alg_bytes = None
         if args.circuit == "merkle":
@@ -304,6 +325,23 @@ def main():
             ms = sum(v["total_ms"] for k, v in p3.items() if k.startswith("spmv_")) / 3
             b = 68.0 * int(rp[-1]) + 36.0 * (len(rp) - 1)
             standalone["spmv"] = {"rows": len(rp) - 1, "nnz": int(rp[-1]), "ms": ms, "achieved": b / (ms * 1e-3) / 1e9}
+    drop_in = None
+    if args.workload == "prove" and rank == 0 and not use_dist and not args.no_drop_in:
+        # what a source-compatible caller (its own `&mut StdRng`) sees, next to the headline: a few proofs per mode
+        drop_in = {}
+        for mode in ("builtin", "callback", "adopt"):
+            prove_with(mode)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                pr = prove_with(mode)
+            ctx.synchronize()
+            drop_in[mode] = {"ms_per_step": (time.perf_counter() - t1) / 3 * 1e3}
+            assert M.verify_proof(vk, public, pr, M.generate_rand()), "bench: %s-rng proof does not verify" % mode
+        drop_in["note"] = ("builtin = library ChaCha12 (the headline mode); callback = swm_rng_from_callback over a host ChaCha12 "
+                           "(AVX2, one thread) standing for the caller's StdRng: the 3|H| mask coefficients travel through "
+                           "fill_bytes while the GPU works on the rest of round 1; adopt = swm_rng_from_chacha with the caller's "
+                           "(seed, word position), position written back: the caller's stream word for word, drawn on the GPU")
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -367,10 +405,14 @@ def main():
         dom = prof[dominant]
         launches_per_step = dom["calls"] / args.steps
         work = work_timed
-        if alg_bytes is None:
-            # dominant kernel of prove(): the bucket accumulation behind the KZG commitments, one launch per MSM.
-            # Algorithmic bytes per launch = 128 B x (points the library logged) / (MSM launches)  (SURVEY §8d).
-            alg_bytes = 128.0 * work["msm_points"] / work["msm_calls"]
+        # dominant kernel: the bucket accumulation behind the KZG commitments, one launch per MSM.  Algorithmic bytes per
+        # launch: 128 B (96 B base + 32 B scalar) per point that reaches the kernel; a point with a ZERO scalar
+        # (or an identity base) is read as its 32-B scalar only and never reaches it — the synthetic witness of the headline
+        # circuit has 3 N such points per proof (z_B is constant) — so those are priced at 32 B.  `frac_all_points_128B` is
+        # the figure with every logged point at 128 B (what r01 / r02 reported).
+        zero_pts = work.get("msm_zero_points", 0)
+        alg_bytes_unpriced = 128.0 * work["msm_points"] / work["msm_calls"]
+        alg_bytes = (128.0 * (work["msm_points"] - zero_pts) + 32.0 * zero_pts) / work["msm_calls"]
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need their own rocprofv3 invocation,
         # MI355X_MICROARCH.md); taken from the newest committed PMC summary under profiles/ and scaled per point.
@@ -386,12 +428,27 @@ def main():
             traffic = None
         # the other two kernels of the path against the same roof: NTT 64 B per element per transform
         # (a transform is 2-3 ntt_pass launches), mat-vec 68 B per non-zero + 36 B per row
+        def newest_profile(stem):
+            try:
+                fs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_" + stem + r"\.json", f)),
+                            key=lambda f: int(f[1:f.index("_")]))
+                return (json.load(open(os.path.join(ROOT, "profiles", fs[-1]))), "profiles/" + fs[-1]) if fs else (None, None)
+            except Exception:
+                return None, None
+        # the issue ceiling of the dominant kernel, MEASURED: the newest committed SQ pass of the same kernel gives the share
+        # of its wave-cycles in which a VALU instruction issues; rate / share = the rate at which every cycle would issue
+        sq, sq_src = newest_profile("pmc_sq_msm_accumulate")
+        ceiling = sq["mixed_adds_per_s_of_the_pass"] / sq["valu_issue_share_of_wave_cycles"] if sq else None
+        ntt_pmc, ntt_src = newest_profile("pmc_ntt_pass")
+        spmv_pmc, spmv_src = newest_profile("pmc_spmv")
         secondary = []
         if "ntt_pass" in prof and work.get("ntt_elements"):
             b = 64.0 * work["ntt_elements"]
             a = b / (prof["ntt_pass"]["total_ms"] * 1e-3) / 1e9
             secondary.append({"bound": "hbm", "kernel": "ntt_pass", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": a / HBM_PEAK_GBS, "traffic": None,
+                              "frac": a / HBM_PEAK_GBS,
+                              "traffic": ntt_pmc["hbm_bytes_per_element_per_transform"] * work["ntt_elements"] / args.steps if ntt_pmc else None,
+                              "traffic_source": ntt_src and ntt_src + " (separate --pmc passes on the stand-alone transform, bytes per element scaled to this step)",
                               "algorithmic_bytes": "64 B x %d elements over %d transforms (%d launches)"
                                                    % (work["ntt_elements"] / args.steps, work["ntt_calls"] / args.steps,
                                                       prof["ntt_pass"]["calls"] / args.steps),
@@ -404,7 +461,9 @@ def main():
             ms = sum(prof[k]["total_ms"] for k in sp)
             a = b / (ms * 1e-3) / 1e9
             secondary.append({"bound": "hbm", "kernel": "+".join(sorted(sp)), "achieved": a, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                              "traffic": spmv_pmc["hbm_bytes_per_nnz"] * work["spmv_nnz"] / args.steps if spmv_pmc else None,
+                              "traffic_source": spmv_src and spmv_src + " (separate --pmc passes on the stand-alone mat-vec, bytes per non-zero scaled to this step)",
                               "algorithmic_bytes": "68 B x %d non-zeros + 36 B x %d rows over %d mat-vecs"
                                                    % (work["spmv_nnz"] / args.steps, work["spmv_rows"] / args.steps,
                                                       work["spmv_calls"] / args.steps),
@@ -424,16 +483,17 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         # explanatory figure: the kernel is bound by integer issue, not by HBM —
-                         # mixed additions per second against the ceiling its instruction mix allows
-                         # (3423 v_mad_u64_u32 + 677 64-bit shift/adds at 4.2 cycles, ~870 32-bit ops at 2.3, per
-                         # wave-addition; 1024 SIMDs at 2.4 GHz; the mix is the hot block `tools/isa_mix.py
-                         # simpleworks_amd/csrc/msm.hip msm_accumulate` prints)
-                         # msm_adds = NON-ZERO digits (bucket entries), counted by the sort on the device
+                         "zero_scalar_points_per_launch": zero_pts / work["msm_calls"],
+                         "frac_all_points_128B": alg_bytes_unpriced / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # explanatory figure: the kernel is bound by integer issue, not by HBM — mixed
+                         # additions per second (msm_adds = NON-ZERO digits = bucket entries, counted by the sort on the
+                         # device) against the rate at which every wave-cycle would issue a vector instruction, from the
+                         # committed SQ counters of the same kernel (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
                          "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
-                         "issue_ceiling_mixed_adds_per_s": 8.2e9},
+                         "issue_ceiling_mixed_adds_per_s": ceiling, "issue_ceiling_source": sq_src},
             "roofline_secondary": secondary,
             "sharded": sharded_info,
+            "rng": args.rng, "drop_in_rng": drop_in,
             "work_per_step": {k: v / args.steps for k, v in work.items()},
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(prof.items())},
         }
@@ -455,7 +515,12 @@ def main():
         json_out.flush()
     if use_dist:
         if sharded_info is not None and "error" in sharded_info:
-            os._exit(0)  # a watchdog-abandoned collective may never return: leave without the orderly teardown
+            # a watchdog-abandoned collective may never return: leave without the orderly teardown — the JSON line is out,
+            # but the failed leg must not look like success
+            sys.stdout.flush()
+            sys.stderr.write("bench: the sharded leg failed: %s\n" % sharded_info["error"])
+            sys.stderr.flush()
+            os._exit(3)
         dist.destroy_process_group()
 
 

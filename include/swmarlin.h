@@ -129,10 +129,25 @@ int swm_rng_from_seed(const uint8_t seed[32], swm_rng **out);
  * both little-endian, consecutive words).  The callback is invoked on the calling thread, only from inside
  * swm_generate_universal_srs / swm_generate_proof / swm_verify_proof / swm_rng_next_u64 / swm_rng_rand_fr, and must not
  * call back into the library.  `user` must stay valid until swm_rng_free.  Bulk draws (the 3|H| mask coefficients of a
- * proof) travel through the callback too (~170 MB at |H| = 2^20): slower than the built-in ChaCha12, which produces
- * them on the GPU. */
+ * proof) travel through the callback too (~170 MB at |H| = 2^20, requested while the GPU works on the rest of round 1):
+ * as fast as the caller's generator is.  A ChaCha generator is better handed over by state (swm_rng_from_chacha). */
 typedef void (*swm_fill_bytes_fn)(void *user, uint8_t *dest, size_t len);
 int swm_rng_from_callback(swm_fill_bytes_fn fill_bytes, void *user, swm_rng **out);
+/* The caller's generator by STATE instead of by callback, for callers whose generator is a ChaCha stream — rand 0.8's
+ * StdRng (= rand_chacha::ChaCha12Rng, the type of every `rng` parameter in src/marlin/mod.rs:49,73,83) is: `key` =
+ * get_seed(), `word_pos` = get_word_pos() (32-bit words of keystream consumed so far), `rounds` = 8, 12 or 20, stream
+ * id 0.  The library then draws exactly the words the caller's generator would have produced — bulk draws on the GPU,
+ * nothing through a callback — and swm_rng_word_pos returns where the stream stands afterwards, which the caller writes
+ * back with set_word_pos: caller-visible behaviour identical to swm_rng_from_callback at the cost of the built-in rng. */
+int swm_rng_from_chacha(const uint8_t key[32], uint64_t word_pos, int rounds, swm_rng **out);
+int swm_rng_word_pos(const swm_rng *rng, uint64_t *word_pos); /* SWM_ERR_INVALID_ARG for a callback generator */
+/* RngCore::fill_bytes on the handle (rand_core BlockRng: whole 32-bit words are consumed, little-endian; a tail of
+ * 1-3 bytes takes the low bytes of one more word) */
+int swm_rng_fill_bytes(swm_rng *rng, uint8_t *dest, size_t len);
+/* The same as a swm_fill_bytes_fn (user = a swm_rng* that is NOT the one it is installed in): lets a harness put one
+ * library generator behind the callback of another handle — a stand-in for "the caller's StdRng" whose stream is known
+ * (tests, `bench.py --rng callback`).  Pure host code, no context: the one callback that may enter the library. */
+void swm_rng_fill_bytes_cb(void *user, uint8_t *dest, size_t len);
 void swm_rng_free(swm_rng *rng);
 int swm_rng_next_u64(swm_rng *rng, uint64_t *out);
 int swm_rng_rand_fr(swm_rng *rng, uint64_t out_mont[4]); /* ark_ff UniformRand for Fr (Montgomery limbs) */

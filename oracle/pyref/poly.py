@@ -175,10 +175,11 @@ def poly_divide_by_vanishing(p, domain):
     n = domain.size
     if len(p) < n + 1 and poly_degree(p) < n:
         return [], p
+    # quotient[j] = sum_{i >= 1} p[j + i n] (ark-poly adds the shifted tails one by one: len(p)^2 / n steps, which for the
+    # division of w by v_X, |X| = 4, is quadratic in |H|); the same sums from the top down in one pass
     quotient = list(p[n:])
-    for i in range(1, len(p) // n):
-        for j, s in enumerate(p[n * (i + 1):]):
-            quotient[j] = (quotient[j] + s) % R
+    for j in range(len(quotient) - n - 1, -1, -1):
+        quotient[j] = (quotient[j] + quotient[j + n]) % R
     remainder = list(p[:n])
     for j in range(min(n, len(quotient))):
         remainder[j] = (remainder[j] + quotient[j]) % R

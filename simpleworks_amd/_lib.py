@@ -51,6 +51,10 @@ ABI = {
     "swm_rng_test_new": (_int, [ctypes.POINTER(_vp)]),
     "swm_rng_from_seed": (_int, [ctypes.c_void_p, ctypes.POINTER(_vp)]),
     "swm_rng_from_callback": (_int, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "swm_rng_from_chacha": (_int, [ctypes.c_void_p, ctypes.c_uint64, _int, ctypes.POINTER(_vp)]),
+    "swm_rng_word_pos": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "swm_rng_fill_bytes": (_int, [_vp, ctypes.c_void_p, ctypes.c_size_t]),
+    "swm_rng_fill_bytes_cb": (None, [_vp, ctypes.c_void_p, ctypes.c_size_t]),
     "swm_rng_free": (None, [_vp]),
     "swm_rng_next_u64": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "swm_rng_rand_fr": (_int, [_vp, _u64p]),

@@ -288,6 +288,13 @@ void swm_destroy(swm_ctx* ctx) {
     if (ctx->rccl_send) (void)hipFree(ctx->rccl_send);
     if (ctx->rccl_recv) (void)hipFree(ctx->rccl_recv);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->ext_pinned) (void)hipHostFree(ctx->ext_pinned);
+    for (auto e : ctx->ext_event)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx->host_pool;
     delete ctx;
@@ -625,7 +632,7 @@ int swm_profile_reset(swm_ctx* ctx) {
     prof_flush(ctx);
     ctx->prof.clear();
     ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_msm_digits = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
-    ctx->stat_spmv_calls = ctx->stat_spmv_rows = ctx->stat_spmv_nnz = ctx->stat_msm_adds = 0;
+    ctx->stat_spmv_calls = ctx->stat_spmv_rows = ctx->stat_spmv_nnz = ctx->stat_msm_adds = ctx->stat_msm_zero_points = 0;
     ctx->call_log.clear();
     return SWM_OK;
 }
@@ -645,11 +652,11 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
     }
     char tail[512];
     snprintf(tail, sizeof(tail),
-             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"msm_digits\":%llu,\"msm_adds\":%llu,\"ntt_calls\":%llu,"
+             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"msm_digits\":%llu,\"msm_adds\":%llu,\"msm_zero_points\":%llu,\"ntt_calls\":%llu,"
              "\"ntt_elements\":%llu,\"spmv_calls\":%llu,\"spmv_rows\":%llu,\"spmv_nnz\":%llu}}",
              (unsigned long long)ctx->stat_msm_calls, (unsigned long long)ctx->stat_msm_points,
              (unsigned long long)ctx->stat_msm_digits, (unsigned long long)ctx->stat_msm_adds,
-             (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
+             (unsigned long long)ctx->stat_msm_zero_points, (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
              (unsigned long long)ctx->stat_spmv_calls, (unsigned long long)ctx->stat_spmv_rows,
              (unsigned long long)ctx->stat_spmv_nnz);
     s += tail;

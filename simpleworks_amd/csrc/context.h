@@ -66,6 +66,7 @@ struct swm_ctx {
     uint64_t stat_msm_digits = 0;  // points x windows (zero digits included)
     uint64_t stat_msm_adds = 0;    // NON-ZERO digits = bucket entries = the mixed additions msm_accumulate performs (counted by
                                    // the sort on the device; collected in msm_finish)
+    uint64_t stat_msm_zero_points = 0;  // MSM points with a zero scalar or an identity base (nothing but their scalar is read)
     uint64_t stat_spmv_nnz = 0;
     // the K1-K3 calls themselves while profiling is on ("the log is mandatory"): ('m', points),
     // ('n', log2 size), ('s', rows) + ('z', non-zeros); bench.py replays this list on the CPU oracle
@@ -93,6 +94,11 @@ struct swm_ctx {
     size_t rccl_cap = 0;
     uint64_t stat_exchanges = 0, stat_exchange_bytes = 0;  // all-gathers issued / bytes contributed per rank
     swm::HostPool* host_pool = nullptr;  // created on first use (msm_finish), joined in swm_destroy
+    // bulk draws from a caller-owned generator (sample_fr_bulk): a pinned ring of two chunks filled through the callback
+    // and sent up on a copy stream of its own, so that the transfers run beside whatever the context's stream is doing
+    hipStream_t copy_stream = nullptr;
+    void* ext_pinned = nullptr;
+    hipEvent_t ext_event[3] = {nullptr, nullptr, nullptr};  // [0], [1]: chunk buffer free again; [2]: destination may be written
 };
 
 struct swm_bases {

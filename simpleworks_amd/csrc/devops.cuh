@@ -640,40 +640,106 @@ static __global__ void __launch_bounds__(256) sample_compact(const Fr* __restric
         if (r + 1 == need) *last_idx = (uint32_t)j;
     }
 }
+// candidates uploaded as raw bytes (caller-owned generator): clear the top bits in place, flag the ones below r
+static __global__ void __launch_bounds__(256) sample_flag_raw(Fr* __restrict__ cand, size_t m, uint32_t* __restrict__ flag) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    Fr r = cand[j];
+    r.v[7] &= 0xffffffffu >> 3;
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (!decided && r.v[i] != FrParams::P[i]) {
+            lt = r.v[i] < FrParams::P[i];
+            decided = true;
+        }
+    }
+    cand[j] = r;
+    flag[j] = lt ? 1u : 0u;
+}
 // Draws `need` field elements from rng's stream into out[0..need) (device), advancing rng exactly as `need`
 // successive Fr::rand(rng) calls would.
-inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need) {
+// Caller-owned generator (rng.ext): the candidates come from its fill_bytes in runs of at most EXT_CHUNK and never more than
+// the number still missing, so the stream stops right behind the candidate that completes the draw.  The host only COUNTS
+// the accepted candidates of a run (it has to know how many are still missing); the raw run goes up from a pinned ring of
+// two chunks on the context's copy stream and is flagged, scanned and compacted into place on the GPU (the kernels of the
+// built-in path), while the callback produces the next run: ~170 MB through the callback for 3 * 2^20 elements, i.e. as
+// fast as the caller's generator.  The call returns once the callback is done; the context's stream is made to wait for the
+// last run.  `marked`: sample_fr_ext_mark was called when `out` was allocated — the transfers then wait for that point of
+// the context's stream, not for what was enqueued since (the prover requests the mask after enqueueing the rest of round 1,
+// so that the GPU works while the host draws).
+static constexpr size_t EXT_CHUNK = (size_t)1 << 18;
+inline void sample_fr_ext_mark(swm_ctx* ctx) {  // call right after allocating the destination of a later bulk draw
+    if (!ctx->ext_event[2]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[2], hipEventDisableTiming), "event");
+    hip_check(ctx, hipEventRecord(ctx->ext_event[2], ctx->stream), "record");
+}
+inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, bool marked = false) {
     if (rng.ext) {
-        // caller-owned generator: the candidates come from its fill_bytes in runs of exactly the number still missing,
-        // so the stream stops right behind the candidate that completes the draw (as `need` successive Fr::rand calls
-        // would); rejection on the host, one upload.  ~170 MB through the callback for 3 * 2^20 elements.
-        std::vector<Fr> acc;
-        acc.reserve(need);
-        std::vector<uint8_t> buf;
-        while (acc.size() < need) {
-            size_t want = need - acc.size();
-            buf.resize(want * 32);
-            rng.ext(rng.ext_user, buf.data(), buf.size());
-            for (size_t i = 0; i < want; i++) {
-                Fr r;
-                memcpy(r.v, buf.data() + 32 * i, 32);  // little-endian host: 4 x u64 limbs, low first
-                r.v[7] &= 0xffffffffu >> 3;
-                bool lt = false;
-                for (int k = 7; k >= 0; k--) {
-                    if (r.v[k] < FrParams::P[k]) { lt = true; break; }
-                    if (r.v[k] > FrParams::P[k]) break;
+        if (!ctx->copy_stream) hip_check(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "copy stream");
+        if (!ctx->ext_pinned) hip_check(ctx, hipHostMalloc(&ctx->ext_pinned, 2 * EXT_CHUNK * sizeof(Fr), hipHostMallocDefault), "pinned ring");
+        for (int i = 0; i < 2; i++)
+            if (!ctx->ext_event[i]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[i], hipEventDisableTiming), "event");
+        // device side of the ring: raw candidates, flags, ranks and the scan's tile totals, per slot
+        const unsigned ntiles = (unsigned)((EXT_CHUNK + SC_TILE - 1) / SC_TILE);
+        const size_t slot_bytes = (EXT_CHUNK * (sizeof(Fr) + 8) + ((size_t)ntiles + 2) * 4 + 255) & ~(size_t)255;
+        char* dev = nullptr;
+        if (scratch(ctx, "ext.ring", 2 * slot_bytes, (void**)&dev) != SWM_OK) throw MarlinError(SWM_ERR_OOM, "sample: device ring");
+        if (!marked) sample_fr_ext_mark(ctx);  // no earlier mark: everything enqueued so far may still use the buffer
+        hipStream_t cs = ctx->copy_stream;
+        hip_check(ctx, hipStreamWaitEvent(cs, ctx->ext_event[2], 0), "wait");
+        size_t have = 0;
+        bool used[2] = {false, false};
+        for (int b = 0; have < need; b ^= 1) {
+            const size_t want = std::min(need - have, EXT_CHUNK);
+            uint32_t* buf = reinterpret_cast<uint32_t*>((char*)ctx->ext_pinned + (size_t)b * EXT_CHUNK * sizeof(Fr));
+            if (used[b]) hip_check(ctx, hipEventSynchronize(ctx->ext_event[b]), "ring");
+            rng.ext(rng.ext_user, reinterpret_cast<uint8_t*>(buf), want * 32);
+            size_t acc = 0;
+            const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
+            for (size_t i = 0; i < want; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
+                const uint32_t* r = buf + 8 * i;  // in all but 2^-29 of the cases
+                const uint32_t t = r[7] & top_mask;
+                if (t != p7) {
+                    acc += t < p7;
+                } else {
+                    bool lt = false;
+                    for (int k = 6; k >= 0; k--) {
+                        if (r[k] < FrParams::P[k]) { lt = true; break; }
+                        if (r[k] > FrParams::P[k]) break;
+                    }
+                    acc += lt;
                 }
-                if (lt) acc.push_back(r);
             }
+            Fr* d_raw = reinterpret_cast<Fr*>(dev + (size_t)b * slot_bytes);
+            uint32_t* d_flag = reinterpret_cast<uint32_t*>(d_raw + EXT_CHUNK);
+            uint32_t* d_rank = d_flag + EXT_CHUNK;
+            uint32_t* d_tot = d_rank + EXT_CHUNK;
+            hip_check(ctx, hipMemcpyAsync(d_raw, buf, want * sizeof(Fr), hipMemcpyHostToDevice, cs), "h2d");
+            hip_check(ctx, hipEventRecord(ctx->ext_event[b], cs), "record");  // the pinned chunk may be refilled after the copy
+            used[b] = true;
+            const unsigned grid = (unsigned)((want + 255) / 256), nt = (unsigned)((want + SC_TILE - 1) / SC_TILE);
+            hipLaunchKernelGGL(sample_flag_raw, dim3(grid), dim3(256), 0, cs, d_raw, want, d_flag);
+            hipLaunchKernelGGL(scan_totals, dim3(nt), dim3(SC_BLOCK), 0, cs, (const uint32_t*)d_flag, want, d_tot);
+            hipLaunchKernelGGL(scan_mid, dim3(1), dim3(SC_BLOCK), 0, cs, d_tot, nt);
+            hipLaunchKernelGGL(scan_final, dim3(nt), dim3(SC_BLOCK), 0, cs, (const uint32_t*)d_flag, want, d_tot, d_rank);
+            if (acc)
+                hipLaunchKernelGGL(sample_compact, dim3(grid), dim3(256), 0, cs, (const Fr*)d_raw, (const uint32_t*)d_flag,
+                                   (const uint32_t*)d_rank, want, acc, out + have, d_tot + nt + 1);
+            hip_check(ctx, hipGetLastError(), "sample (caller-owned generator)");
+            have += acc;
         }
-        hip_check(ctx, hipMemcpyAsync(out, acc.data(), need * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
-        hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
+        hip_check(ctx, hipEventRecord(ctx->ext_event[2], cs), "record");
+        hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ext_event[2], 0), "wait");
+        // the device ring is reused by the next draw: its kernels are ordered behind these on the copy stream
         return;
     }
     size_t done = 0;
     while (done < need) {
         size_t want = need - done;
         size_t m = (size_t)((double)want / 0.58 * 1.02) + 2048;
+        // test hook: only as many candidates as elements still missing, so that the retry branch below runs several times
+        // (the acceptance rate is r / 2^253 = 0.58) — tests/test_gpu_marlin.py pins it against the sequential stream
+        if (getenv("SWM_SAMPLE_TIGHT")) m = want;
         DVec cand(ctx, m);
         DBuf<uint32_t> flag(ctx, m), rank(ctx, m), last(ctx, 1);
         ChaChaKey key;

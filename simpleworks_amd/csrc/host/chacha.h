@@ -34,6 +34,54 @@ SWM_HD void chacha_block(const uint32_t key[8], uint64_t counter, int rounds, ui
     for (int i = 0; i < 16; i++) out[i] = s[i] + in[i];
 }
 
+// Eight consecutive blocks at once with AVX2 (lane l of every vector belongs to block counter + l), for bulk keystream on
+// the host (swm_rng_fill_bytes: the test-harness stand-in for a caller's StdRng; rand_chacha vectorises the same way).
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define SWM_CHACHA_WIDE 1
+}  // namespace swm
+#include <immintrin.h>
+namespace swm {
+__attribute__((target("avx2"))) inline void chacha_blocks8_avx2(const uint32_t key[8], uint64_t counter, int rounds, uint32_t* out) {
+    __m256i in[16], s[16];
+    in[0] = _mm256_set1_epi32((int)0x61707865u);
+    in[1] = _mm256_set1_epi32((int)0x3320646eu);
+    in[2] = _mm256_set1_epi32((int)0x79622d32u);
+    in[3] = _mm256_set1_epi32((int)0x6b206574u);
+    for (int i = 0; i < 8; i++) in[4 + i] = _mm256_set1_epi32((int)key[i]);
+    alignas(32) uint32_t lo[8], hi[8];
+    for (int l = 0; l < 8; l++) {
+        const uint64_t c = counter + (uint64_t)l;
+        lo[l] = (uint32_t)c;
+        hi[l] = (uint32_t)(c >> 32);
+    }
+    in[12] = _mm256_load_si256((const __m256i*)lo);
+    in[13] = _mm256_load_si256((const __m256i*)hi);
+    in[14] = _mm256_setzero_si256();
+    in[15] = _mm256_setzero_si256();
+    for (int i = 0; i < 16; i++) s[i] = in[i];
+#define SWM_ROTL8(v, c) _mm256_or_si256(_mm256_slli_epi32(v, c), _mm256_srli_epi32(v, 32 - c))
+#define SWM_QR8(a, b, c, d)                                                    \
+    s[a] = _mm256_add_epi32(s[a], s[b]); s[d] = _mm256_xor_si256(s[d], s[a]); s[d] = SWM_ROTL8(s[d], 16); \
+    s[c] = _mm256_add_epi32(s[c], s[d]); s[b] = _mm256_xor_si256(s[b], s[c]); s[b] = SWM_ROTL8(s[b], 12); \
+    s[a] = _mm256_add_epi32(s[a], s[b]); s[d] = _mm256_xor_si256(s[d], s[a]); s[d] = SWM_ROTL8(s[d], 8);  \
+    s[c] = _mm256_add_epi32(s[c], s[d]); s[b] = _mm256_xor_si256(s[b], s[c]); s[b] = SWM_ROTL8(s[b], 7);
+    for (int r = 0; r < rounds; r += 2) {
+        SWM_QR8(0, 4, 8, 12) SWM_QR8(1, 5, 9, 13) SWM_QR8(2, 6, 10, 14) SWM_QR8(3, 7, 11, 15)
+        SWM_QR8(0, 5, 10, 15) SWM_QR8(1, 6, 11, 12) SWM_QR8(2, 7, 8, 13) SWM_QR8(3, 4, 9, 14)
+    }
+#undef SWM_QR8
+#undef SWM_ROTL8
+    alignas(32) uint32_t t[16][8];
+    for (int i = 0; i < 16; i++) _mm256_store_si256((__m256i*)t[i], _mm256_add_epi32(s[i], in[i]));
+    for (int l = 0; l < 8; l++)
+        for (int i = 0; i < 16; i++) out[16 * l + i] = t[i][l];
+}
+inline bool chacha_have_avx2() {
+    static const bool have = __builtin_cpu_supports("avx2");
+    return have;
+}
+#endif
+
 // Caller-owned randomness (swm_rng_from_callback): the reference passes `&mut StdRng` into setup / prove / verify
 // (src/marlin/mod.rs:49,73,83), so a drop-in has to draw from THAT generator.  rand_core's BlockRng serves
 // next_u32 / next_u64 / fill_bytes from one flat stream of 32-bit words (a u64 is two consecutive words, low first;

@@ -987,16 +987,25 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
     const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
     DVec mask(ctx, mask_len);
-    sample_fr_bulk(ctx, zk, mask.p, mask_len);
-    {
+    // A caller-owned generator (swm_rng_from_callback) produces the mask on the HOST, through its fill_bytes: ~170 MB at
+    // |H| = 2^20, i.e. tens of milliseconds of the caller's ChaCha.  That draw is therefore requested AFTER the rest of
+    // round 1 has been enqueued (witness upload, mat-vecs, the three other polynomials and their commitments, the
+    // challenge-independent transforms of round 2), so that the GPU works while the host draws.  The draw ORDER is
+    // untouched: nothing between here and there touches `zk` (rho_w, rho_a, rho_b were drawn above, the blinding
+    // polynomials are drawn after the round's last commitment is enqueued, as before).
+    const bool mask_late = zk.ext != nullptr;
+    auto draw_mask = [&] {
+        sample_fr_bulk(ctx, zk, mask.p, mask_len, mask_late);
         Fr* mp = mask.p;
         ew(ctx, "mask_fix", 1, [=] __device__(size_t) {
             // remainder mod v_H at coefficient 0 = c[0] + c[H] + c[2H]; subtracting it from c[0] leaves -(c[H] + c[2H])
             mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
         });
-    }
-    P_mask.p = mask.p; P_mask.n = mask_len;
-    begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+        P_mask.p = mask.p; P_mask.n = mask_len;
+        begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    };
+    if (mask_late) sample_fr_ext_mark(ctx);  // the transfers of the late draw only wait for what precedes the allocation
+    else draw_mask();
 
     // ---- z on the device, z_A = A z, z_B = B z  (K3)
     DVec z(ctx, nvars);
@@ -1073,7 +1082,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
-    flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
+    if (!mask_late) flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
@@ -1097,6 +1106,10 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             out[i] = v;
         });
         e_z = on_mul_domain(z_poly.p, H + 1);
+    }
+    if (mask_late) {  // everything else of the round is in flight: now the host draws the mask from the caller's generator
+        draw_mask();
+        flush_commits();
     }
     tr.tick("r1: pre-work enqueued");
     // blinding draws and hiding terms (label order: w, z_a, z_b, mask) while the MSMs run
@@ -1892,6 +1905,56 @@ int swm_rng_from_callback(swm_fill_bytes_fn fill_bytes, void* user, swm_rng** ou
     (*out)->r.ext_user = user;
     return SWM_OK;
 }
+int swm_rng_from_chacha(const uint8_t key[32], uint64_t word_pos, int rounds, swm_rng** out) {
+    if (!out || !key || (rounds != 8 && rounds != 12 && rounds != 20)) return SWM_ERR_INVALID_ARG;
+    *out = new swm_rng();
+    (*out)->r.seed(key, rounds);
+    (*out)->r.pos = word_pos;
+    return SWM_OK;
+}
+int swm_rng_word_pos(const swm_rng* rng, uint64_t* word_pos) {
+    if (!rng || !word_pos || rng->r.ext) return SWM_ERR_INVALID_ARG;
+    *word_pos = rng->r.pos;
+    return SWM_OK;
+}
+int swm_rng_fill_bytes(swm_rng* rng, uint8_t* dest, size_t len) {
+    if (!rng || (len && !dest)) return SWM_ERR_INVALID_ARG;
+    if (rng->r.ext) {
+        rng->r.ext(rng->r.ext_user, dest, len);
+        return SWM_OK;
+    }
+    size_t i = 0;
+    // whole keystream blocks straight into the destination (little-endian host): what a bulk draw through the callback
+    // of a test harness asks for, 8 MB at a time
+#ifdef SWM_CHACHA_WIDE
+    while (chacha_have_avx2() && (rng->r.pos & 15) == 0 && len - i >= 512) {
+        uint32_t blk[128];
+        chacha_blocks8_avx2(rng->r.key, rng->r.pos >> 4, rng->r.rounds, blk);
+        memcpy(dest + i, blk, 512);
+        rng->r.pos += 128;
+        rng->r.have = false;
+        i += 512;
+    }
+#endif
+    while ((rng->r.pos & 15) == 0 && len - i >= 64) {
+        uint32_t blk[16];
+        chacha_block(rng->r.key, rng->r.pos >> 4, rng->r.rounds, blk);
+        memcpy(dest + i, blk, 64);
+        rng->r.pos += 16;
+        rng->r.have = false;
+        i += 64;
+    }
+    for (; i + 4 <= len; i += 4) {
+        uint32_t w = rng->r.next_u32();
+        dest[i] = (uint8_t)w; dest[i + 1] = (uint8_t)(w >> 8); dest[i + 2] = (uint8_t)(w >> 16); dest[i + 3] = (uint8_t)(w >> 24);
+    }
+    if (i < len) {
+        uint32_t w = rng->r.next_u32();
+        for (; i < len; i++, w >>= 8) dest[i] = (uint8_t)w;
+    }
+    return SWM_OK;
+}
+void swm_rng_fill_bytes_cb(void* user, uint8_t* dest, size_t len) { (void)swm_rng_fill_bytes(static_cast<swm_rng*>(user), dest, len); }
 void swm_rng_free(swm_rng* rng) { delete rng; }
 int swm_rng_next_u64(swm_rng* rng, uint64_t* out) {
     if (!rng || !out) return SWM_ERR_INVALID_ARG;

@@ -138,7 +138,7 @@ __device__ __forceinline__ void for_each_digit(const Fr& s, const WinLayout& L, 
 // digits[w * n + i] = code of window w of scalar i (coalesced over i).            HBM: 32 B read + 4 W B written / point
 // A scalar that is not a canonical field element (>= r; arkworks' BigInteger256 scalars always are) raises *bad: the
 // recoding only covers 254 bits, so such an input cannot be given a meaning.  Points flagged in the infinity mask get
-// zero digits (they contribute nothing, as in VariableBaseMSM).
+// zero digits (they contribute nothing, as in VariableBaseMSM).  bad[1] counts the points that contribute nothing.
 __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
                                                   uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
                                                   size_t inf_first, uint32_t* __restrict__ bad) {
@@ -158,6 +158,14 @@ __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars
         if (inf_mask) {
             size_t b = inf_first + i;
             skip = (inf_mask[b >> 5] >> (b & 31)) & 1u;
+        }
+        {   // points that contribute nothing (zero scalar, or an identity base): counted per wave, one atomic per wave —
+            // the measurement prices them at their 32-B scalar only (bench.py: roofline numerator)
+            uint32_t z = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) z |= s.v[k];
+            const unsigned long long m = __ballot(z == 0 || skip);
+            if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(bad + 1, (uint32_t)__popcll(m));
         }
         for_each_digit(s, L, [&](unsigned w, uint32_t code) { digits[(size_t)w * n + i] = skip ? 0u : code; });
     }
@@ -1277,8 +1285,9 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
         Form::store_384(out[o], sm_acc[0]);
         Form::store_384(out[o + 1], sm_r[0]);
         if (blockIdx.x == 0 && w == 0 && job.host_flags) {
-            job.host_flags[0] = *job.status;
+            job.host_flags[0] = job.status[0];
             job.host_flags[1] = *job.entries;
+            job.host_flags[2] = job.status[1];  // points with a zero scalar / identity base
         }
     }
 }
@@ -1964,6 +1973,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
                                     hipMemcpyDeviceToHost, st));
         SWM_HIP(ctx, hipMemcpyAsync((void*)j->host_flags, j->d_status, 4, hipMemcpyDeviceToHost, st));
         SWM_HIP(ctx, hipMemcpyAsync((void*)(j->host_flags + 1), j->d_entries, 4, hipMemcpyDeviceToHost, st));
+        SWM_HIP(ctx, hipMemcpyAsync((void*)(j->host_flags + 2), j->d_status + 1, 4, hipMemcpyDeviceToHost, st));
     }
     for (int i = 0; i < k; i++) {
         SWM_HIP(ctx, hipEventRecord(jobs[i]->done, st));
@@ -1992,6 +2002,7 @@ static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     job->active = false;
     ctx->slot_busy[job->slot] = false;
     ctx->stat_msm_adds += job->host_flags[1];  // entries the sort placed = non-zero digits
+    ctx->stat_msm_zero_points += job->host_flags[2];
     if (job->host_flags[0])
         return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: a scalar is not a canonical field element (>= r)");
     return SWM_OK;

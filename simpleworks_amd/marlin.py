@@ -75,6 +75,18 @@ class Rng:
         _check(load_library().swm_rng_rand_fr(self.h, _p64(out)), "swm_rng_rand_fr")
         return out
 
+    def fill_bytes(self, n):
+        """RngCore::fill_bytes: the next n bytes of the stream (whole 32-bit words are consumed)."""
+        buf = (ctypes.c_uint8 * n)()
+        _check(load_library().swm_rng_fill_bytes(self.h, buf, n), "swm_rng_fill_bytes")
+        return bytes(buf)
+
+    def word_pos(self):
+        """rand_chacha's get_word_pos of a built-in / adopted generator: 32-bit keystream words consumed so far."""
+        v = ctypes.c_uint64(0)
+        _check(load_library().swm_rng_word_pos(self.h, ctypes.byref(v)), "swm_rng_word_pos")
+        return v.value
+
 
 def _check(rc, what, ctx=None):
     if rc != 0:
@@ -96,6 +108,18 @@ def rng_from_seed(seed32):
     return Rng(h)
 
 
+TEST_RNG_SEED = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)  # ark_std::test_rng()
+
+
+def rng_from_chacha(key32, word_pos=0, rounds=12):
+    """swm_rng_from_chacha: adopt the STATE of a caller's ChaCha generator (rand 0.8 StdRng = ChaCha12: get_seed /
+    get_word_pos) instead of calling back into it; read the position back with Rng.word_pos() and set_word_pos it."""
+    h = _vp()
+    buf = (ctypes.c_uint8 * 32)(*bytes(key32))
+    _check(load_library().swm_rng_from_chacha(buf, word_pos, rounds, ctypes.byref(h)), "swm_rng_from_chacha")
+    return Rng(h)
+
+
 _FILL_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
@@ -113,6 +137,19 @@ def rng_from_fill_bytes(fill_bytes):
            "swm_rng_from_callback")
     r = Rng(h)
     r._cb = cb  # the trampoline lives as long as the handle
+    return r
+
+
+def rng_behind_callback(caller_rng):
+    """A handle whose every draw goes, through swm_rng_from_callback, to ANOTHER library generator (`caller_rng`, which
+    stands for the caller's StdRng): the callback is the library's own native trampoline, so what is measured is the
+    callback path itself, not a Python function.  `caller_rng` must outlive the handle."""
+    lib = load_library()
+    h = _vp()
+    _check(lib.swm_rng_from_callback(ctypes.cast(lib.swm_rng_fill_bytes_cb, ctypes.c_void_p), caller_rng.h, ctypes.byref(h)),
+           "swm_rng_from_callback")
+    r = Rng(h)
+    r._caller = caller_rng
     return r
 
 

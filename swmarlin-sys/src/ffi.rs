@@ -40,6 +40,10 @@ extern "C" {
     pub fn swm_rng_test_new(out: *mut *mut swm_rng) -> c_int;
     pub fn swm_rng_from_seed(seed: *const u8, out: *mut *mut swm_rng) -> c_int;
     pub fn swm_rng_from_callback(fill_bytes: swm_fill_bytes_fn, user: *mut c_void, out: *mut *mut swm_rng) -> c_int;
+    pub fn swm_rng_from_chacha(key: *const u8, word_pos: u64, rounds: c_int, out: *mut *mut swm_rng) -> c_int;
+    pub fn swm_rng_word_pos(rng: *const swm_rng, word_pos: *mut u64) -> c_int;
+    pub fn swm_rng_fill_bytes(rng: *mut swm_rng, dest: *mut u8, len: usize) -> c_int;
+    pub fn swm_rng_fill_bytes_cb(user: *mut c_void, dest: *mut u8, len: usize);
     pub fn swm_rng_free(rng: *mut swm_rng);
 
     // generate_universal_srs (src/marlin/mod.rs:45-55)

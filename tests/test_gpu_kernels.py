@@ -519,3 +519,43 @@ def test_msm_small_sets_low_latency_schedule(ctx, orc, n):
         ref = orc.jac_to_affine_int(orc.msm(np.ascontiguousarray(bases[lo:lo + m]), np.ascontiguousarray(sc[:m]), threads=8))
         assert _affine_of(ctx, orc, ctx.msm_g1(bh, np.ascontiguousarray(sc[:m]), offset=lo)) == ref, shape
     bh.free()
+
+
+def test_msm_uniform_2_20_vs_oracle(ctx, orc):
+    """The headline MSM size against the C restatement of VariableBaseMSM (2^19 and 2^22 are covered above)."""
+    from pyref.prng import fr_array
+    n = 1 << 20
+    G = orc.points_to_mont([_pt(golden("g1.json")["generator"])])
+    bases = orc.srs_bases(n, h2i(golden("msm.json")["tau"]), G)
+    bh = ctx.srs_upload(bases)
+    sc = fr_array(n, 2020)
+    ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=8))
+    assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref
+    bh.free()
+
+
+def test_msm_bases_outside_the_prime_order_subgroup(ctx, orc):
+    """VariableBaseMSM takes ANY curve points.  The twisted Edwards tables are only valid for the prime-order subgroup, so a
+    base set with points outside it (here: curve points with small x, cofactor not cleared, mixed with subgroup points and
+    an identity) must be detected at upload and served by the XYZZ tables — same result as the oracle."""
+    from pyref.prng import fr_array
+    from pyref.bls12_377 import Q, fq_sqrt, g1_mul_fast, R
+    n = 2048
+    pts, x = [], 2
+    while len(pts) < n:
+        y = fq_sqrt((x * x * x + 1) % Q)
+        if y is not None:
+            pts.append((x, y))
+        x += 1
+    assert g1_mul_fast(pts[0], R) is not None          # not in the subgroup
+    G = _pt(golden("g1.json")["generator"])
+    pts[5] = G
+    pts[6] = None                                      # identity base
+    pts[7] = g1_mul_fast(G, 12345)
+    bases = orc.points_to_mont(pts)
+    bh = ctx.srs_upload(bases)
+    for seed in (1, 2):
+        sc = fr_array(n, 4000 + seed)
+        ref = orc.jac_to_affine_int(orc.msm(bases, sc, threads=8))
+        assert _affine_of(ctx, orc, ctx.msm_g1(bh, sc)) == ref
+    bh.free()

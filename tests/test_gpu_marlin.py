@@ -665,3 +665,32 @@ def test_golden_proof_bytes_merkle_height_5(M, S, W):
     assert M.verify_proof(vk, public, proof, rng)
     pk.free()
     srs.free()
+
+
+# ---- where the prover's randomness comes from: built-in ChaCha12, the caller's generator behind a callback, the caller's
+# ChaCha STATE adopted (swm_rng_from_chacha) — one stream, three ways to draw it
+def test_rng_modes_give_the_same_proof_at_2p14(M, S, W):
+    """Pins the GPU bulk sampler (rejection + scan compaction of 3|H| = 49 152 mask coefficients) against the sequential
+    stream: the callback mode draws the same coefficients one fill_bytes run after another on the host.  Also: the adopted
+    state ends at the word position the callback mode consumed."""
+    n = 1 << 14
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    cs, public = W.synthetic_r1cs(n, 0x14141414, 0x41414141)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
+    builtin = M.generate_rand()
+    p_builtin = S.serialize_proof(M.generate_proof(cs, pk, builtin))
+    caller = M.generate_rand()                              # "the caller's StdRng"
+    p_callback = S.serialize_proof(M.generate_proof(cs, pk, M.rng_behind_callback(caller)))
+    assert p_callback == p_builtin
+    assert caller.word_pos() == builtin.word_pos()          # same number of keystream words consumed
+    adopted = M.rng_from_chacha(M.TEST_RNG_SEED, 0, 12)
+    p_adopt = S.serialize_proof(M.generate_proof(cs, pk, adopted))
+    assert p_adopt == p_builtin and adopted.word_pos() == builtin.word_pos()
+    # a second proof continues each stream: still identical
+    p2 = S.serialize_proof(M.generate_proof(cs, pk, builtin))
+    adopted2 = M.rng_from_chacha(M.TEST_RNG_SEED, caller.word_pos(), 12)   # the caller's state after the first proof
+    assert S.serialize_proof(M.generate_proof(cs, pk, adopted2)) == p2 != p_builtin
+    assert M.verify_proof(vk, public, S.deserialize_proof(p2), M.generate_rand())
+    pk.free()

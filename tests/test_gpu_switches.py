@@ -48,5 +48,7 @@ def test_switches_select_equivalent_paths():
     assert len(ref) == 2
     for env in ({"SWM_MSM_NO_TABLE": "1"}, {"SWM_MSM_ZERO_COPY": "0"}, {"SWM_MSM_QUEUE_ORDER": "0"},
                 {"SWM_RED_LANES": "64"}, {"SWM_MSM_PIPE": "0"}, {"SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
-                {"SWM_MSM_SMALL_LANES": "1", "SWM_COMMIT_LATE": "1"}):
+                {"SWM_MSM_SMALL_LANES": "1", "SWM_COMMIT_LATE": "1"},
+                {"SWM_MSM_TE": "0"},          # XYZZ tables instead of the twisted Edwards ones
+                {"SWM_SAMPLE_TIGHT": "1"}):   # the bulk sampler's retry branch, several rounds per draw
         assert _run(env) == ref, env

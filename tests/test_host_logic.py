@@ -208,3 +208,35 @@ def test_callback_rng_consumes_the_callers_stream():
         ref.next_u64()
     for _ in range(5):
         assert np.array_equal(rng.rand_fr_mont(), ref.rand_fr_mont())
+
+
+def test_rng_fill_bytes_adopted_state_and_native_callback():
+    """swm_rng_fill_bytes is the flat keystream whatever path produces it (AVX2 blocks of eight, single blocks, words, a
+    1-3 byte tail out of one more word); swm_rng_from_chacha continues a stream at a word position and swm_rng_word_pos
+    reads it back (rand_chacha's get_word_pos / set_word_pos); swm_rng_fill_bytes_cb puts one generator behind another."""
+    g = golden("rng.json")
+    a, b = M.generate_rand(), M.generate_rand()
+    n = 4096 + 64 + 12
+    bulk = a.fill_bytes(n)
+    words = b"".join(b.next_u64().to_bytes(8, "little") for _ in range(n // 8)) + b.fill_bytes(n % 8)
+    assert bulk == words and a.word_pos() == b.word_pos() == n // 4
+    assert bulk[:16] == b"".join(int(x, 16).to_bytes(8, "little") for x in g["test_rng_u64"][:2])
+    # unaligned start: 3 words in, then a bulk request
+    c, d = M.generate_rand(), M.generate_rand()
+    c.fill_bytes(12)
+    d.fill_bytes(12)
+    assert c.fill_bytes(2000) == b"".join(d.fill_bytes(4) for _ in range(500))
+    # a tail consumes a whole word
+    t = M.generate_rand()
+    assert t.fill_bytes(3) == bulk[:3] and t.word_pos() == 1
+    # adoption: continue at a position, read it back
+    e = M.rng_from_chacha(M.TEST_RNG_SEED, 100, 12)
+    assert e.fill_bytes(64) == bulk[400:464] and e.word_pos() == 116
+    with pytest.raises(M.MarlinError):
+        M.rng_from_chacha(M.TEST_RNG_SEED, 0, 13)
+    # one library generator behind the callback of another handle (the bench's stand-in for the caller's StdRng)
+    caller = M.generate_rand()
+    h = M.rng_behind_callback(caller)
+    assert [hex(h.next_u64()) for _ in range(4)] == g["test_rng_u64"][:4] and caller.word_pos() == 8
+    with pytest.raises(M.MarlinError):
+        h.word_pos()  # a callback generator has no position of its own

@@ -35,7 +35,7 @@ live2 = collections.Counter(); last2 = pts[0][0]; noacc = collections.Counter();
 for t, d, k in pts:
     if t > last2:
         n = sum(live2.values())
-        if live2.get("msm_accumulate", 0) > 0:
+        if sum(c for kk, c in live2.items() if kk.startswith("msm_accumulate")) > 0:
             acc_t += t - last2
         else:
             noacc_t += t - last2
