@@ -92,6 +92,15 @@ int swm_g1_add_jac(const uint64_t a[18], const uint64_t b[18], uint64_t out[18])
  * coset pre-scales coefficient i by 22^i (forward) / post-scales by 22^-i (inverse). */
 int swm_ntt_fr(swm_ctx *ctx, uint64_t *data, unsigned log_n, int inverse, int coset);
 int swm_ntt_fr_dev(swm_ctx *ctx, void *d_data, unsigned log_n, int inverse, int coset);
+/* ONE transform over the G ranks of the context's sharding (swm_set_msm_sharding / swm_rccl_init; G a power of two <= 16,
+ * 2^log_n >= G^2): the four-step split with a single all-to-all (SURVEY.md §8e "NTT partitioning (ii)").  `d_local` holds
+ * this rank's n / G elements, in place.  Layouts (m = n / G, blk = m / G):
+ *     CYCLIC   local[j] = v[rank + G j]                       BLOCKS   local[k1 blk + t] = v[m k1 + rank blk + t]
+ * blocks_in = 0: CYCLIC in -> BLOCKS out;  blocks_in = 1: BLOCKS in -> CYCLIC out.  inverse as swm_ntt_fr_dev (scales by
+ * 1 / n).  Every rank calls with the same arguments; the exchange is ncclSend / ncclRecv (grouped) on the context's stream
+ * when a communicator is set, the all-gather callback otherwise.  Evaluations in BLOCKS and coefficients in CYCLIC layout is
+ * what the sharded prover keeps: its commitment MSMs take CYCLIC coefficients where they are. */
+int swm_ntt_fr_sharded_dev(swm_ctx *ctx, void *d_local, unsigned log_n, int inverse, int blocks_in);
 
 /* ---------------------------------------------------------------------------------------------- K3: R1CS mat-vec
  * Replaces the row-wise inner products of ark-marlin's prover_init (z_A = A z, z_B = B z) and the evaluation
@@ -268,6 +277,9 @@ int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);
  * or in Fr (which = 1), element-wise on the GPU.  Inputs/outputs are host buffers in Montgomery form.
  * which = 2, 5, 6 exercise the MSM's 28-bit lazy-limb multipliers of csrc/fq28.cuh (plain, squarer, fused two-product)
  * on packed 384-bit integers; results are canonical residues times 2^-392. */
+/* the device-buffer exchanges of the sharded transform over whatever sharding the context has: alltoall != 0 — chunk c of
+ * d_send (bytes_per_peer bytes) to rank c, chunk i of d_recv from rank i; else an all-gather of bytes_per_peer bytes */
+int swm_selftest_exchange(swm_ctx *ctx, const void *d_send, void *d_recv, size_t bytes_per_peer, int alltoall);
 int swm_selftest_mul(swm_ctx *ctx, int which, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 /* out[i] = jacobian(a[i] (+) b[i]) with a, b affine (n x 12 limbs): exercises the mixed/XYZZ adders incl. doubling. */
 int swm_selftest_g1_add(swm_ctx *ctx, const uint64_t *a_xy, const uint64_t *b_xy, uint64_t *out_jac, size_t n);

@@ -27,6 +27,7 @@ ABI = {
     "swm_rccl_unique_id": (_int, [ctypes.c_void_p]),
     "swm_rccl_init": (_int, [_vp, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "swm_set_rccl_comm": (_int, [_vp, _vp, ctypes.c_uint, ctypes.c_uint]),
+    "swm_selftest_exchange": (_int, [_vp, ctypes.c_void_p, ctypes.c_void_p, _sz, _int]),
     "swm_exchange_stats": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "swm_synchronize": (_int, [_vp]),
     "swm_malloc": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -42,6 +43,7 @@ ABI = {
     "swm_g1_add_jac": (_int, [_u64p, _u64p, _u64p]),
     "swm_ntt_fr": (_int, [_vp, _u64p, ctypes.c_uint, _int, _int]),
     "swm_ntt_fr_dev": (_int, [_vp, _vp, ctypes.c_uint, _int, _int]),
+    "swm_ntt_fr_sharded_dev": (_int, [_vp, ctypes.c_void_p, ctypes.c_uint, _int, _int]),
     "swm_spmv_fr": (_int, [_vp, _u32p, _u32p, _u64p, _u64p, _sz, _u64p, _sz, _sz]),
     "swm_spmv_fr_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "swm_batch_inverse_fr": (_int, [_vp, _u64p, _sz]),
@@ -217,7 +219,9 @@ class Context:
         if world <= 1 or allgather is None:
             self._check(self.lib.swm_set_msm_sharding(self.h, 0, 1, None, None), "swm_set_msm_sharding")
             self._shard_cb = None
+            self.shard_rank, self.shard_world = 0, 1
             return
+        self.shard_rank, self.shard_world = rank, world
 
         def _cb(_user, send, nbytes, recv):
             try:
@@ -240,6 +244,9 @@ class Context:
         prover then exchanges its partial sums with one ncclAllGather per round."""
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self.lib.swm_rccl_init(self.h, buf, rank, world), "swm_rccl_init")
+
+    def selftest_exchange(self, send_buf, recv_buf, bytes_per_peer, alltoall=True):
+        self._check(self.lib.swm_selftest_exchange(self.h, send_buf.ptr, recv_buf.ptr, bytes_per_peer, int(alltoall)), "swm_selftest_exchange")
 
     def exchange_stats(self):
         calls, nbytes = ctypes.c_uint64(0), ctypes.c_uint64(0)
@@ -297,6 +304,12 @@ class Context:
     def ntt_fr_dev(self, dbuf, log_n, inverse=False, coset=False):
         ptr = dbuf.ptr if isinstance(dbuf, DeviceBuffer) else int(dbuf)
         self._check(self.lib.swm_ntt_fr_dev(self.h, ptr, log_n, int(inverse), int(coset)), "swm_ntt_fr_dev")
+
+    def ntt_fr_sharded_dev(self, dbuf, log_n, inverse=False, blocks_in=False):
+        """One transform over the ranks of this context's sharding: in place on the rank's n / G elements,
+        CYCLIC -> BLOCKS layout (blocks_in = False) or BLOCKS -> CYCLIC (include/swmarlin.h: swm_ntt_fr_sharded_dev)."""
+        ptr = dbuf.ptr if isinstance(dbuf, DeviceBuffer) else int(dbuf)
+        self._check(self.lib.swm_ntt_fr_sharded_dev(self.h, ptr, log_n, int(inverse), int(blocks_in)), "swm_ntt_fr_sharded_dev")
 
     # ---- K3
     def spmv_fr(self, rowptr, col, val_mont, z_mont):

@@ -18,6 +18,7 @@ struct swm_rccl_id_arg {  // ncclUniqueId, passed by value to ncclCommInitRank
 namespace swm {
 
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+int ntt_sharded_run(swm_ctx* ctx, void* d_local, unsigned log_n, int inverse, int blocks_in);
 struct SpmvPlan;
 int spmv_run(swm_ctx* ctx, const void* d_rowptr, const void* d_col, const void* d_val, const void* d_z, void* d_out,
              size_t rows, const SpmvPlan* plan = nullptr);
@@ -154,6 +155,10 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, swm_rccl_id_arg, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -169,6 +174,10 @@ RcclApi& rccl() {
         a.CommInitRank = (int (*)(void**, int, swm_rccl_id_arg, int))dlsym(h, "ncclCommInitRank");
         a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
         a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+        a.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+        a.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+        a.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
         a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
         return a;
@@ -205,6 +214,69 @@ int shard_exchange(swm_ctx* ctx, const void* send, size_t bytes, void* recv) {
     if (!ctx->shard_allgather) return set_err(ctx, SWM_ERR_INTERNAL, "msm sharding: no exchange configured");
     if (ctx->shard_allgather(ctx->shard_user, send, bytes, recv) != 0)
         return set_err(ctx, SWM_ERR_INTERNAL, "msm sharding: the all-gather callback failed");
+    return SWM_OK;
+}
+// ---- exchanges of DEVICE buffers (sharded transforms: ntt.hip ntt_sharded_run, the prover's sharded round 1)
+// all-to-all: chunk c of d_send (bytes_per_peer bytes) goes to rank c; chunk i of d_recv comes from rank i.  Through RCCL it
+// is the grouped ncclSend / ncclRecv form of an all-to-all on the context's stream (every pair of GPUs exchanges
+// n * 32 / G^2 bytes over its own xGMI link); through the caller's all-gather callback (tests: a byte all-gather standing
+// in for RCCL) every rank publishes its whole send buffer and picks its chunks.
+int shard_alltoall_dev(swm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer) {
+    const unsigned world = ctx->shard_world, rank = ctx->shard_rank;
+    ctx->stat_exchanges++;
+    ctx->stat_exchange_bytes += bytes_per_peer * (world - 1);
+    // (a world of one normally copies; with SWM_SHARD_FORCE — the one-GPU test hook of the RCCL path — the communicator's
+    // single rank sends to itself, which a grouped ncclSend / ncclRecv pair allows)
+    if (world <= 1 && !(ctx->rccl_comm && getenv("SWM_SHARD_FORCE"))) {
+        SWM_HIP(ctx, hipMemcpyAsync(d_recv, d_send, bytes_per_peer, hipMemcpyDeviceToDevice, ctx->stream));
+        return SWM_OK;
+    }
+    if (ctx->rccl_comm) {
+        if (!rccl().Send || !rccl().Recv || !rccl().GroupStart || !rccl().GroupEnd)
+            return set_err(ctx, SWM_ERR_INTERNAL, "librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        int rc = rccl().GroupStart();
+        for (unsigned p = 0; p < world && rc == 0; p++) {
+            rc = rccl().Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, /*ncclUint8*/ 1, (int)p, ctx->rccl_comm, ctx->stream);
+            if (rc == 0) rc = rccl().Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, 1, (int)p, ctx->rccl_comm, ctx->stream);
+        }
+        int rc2 = rccl().GroupEnd();
+        if (rc != 0 || rc2 != 0) return rccl_fail(ctx, "ncclSend / ncclRecv (all-to-all)", rc ? rc : rc2);
+        return SWM_OK;
+    }
+    if (!ctx->shard_allgather) return set_err(ctx, SWM_ERR_INTERNAL, "sharding: no exchange configured");
+    const size_t mine = bytes_per_peer * world;
+    std::vector<uint8_t> h(mine), all(mine * world);
+    SWM_HIP(ctx, hipMemcpyAsync(h.data(), d_send, mine, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->shard_allgather(ctx->shard_user, h.data(), mine, all.data()) != 0)
+        return set_err(ctx, SWM_ERR_INTERNAL, "sharding: the all-gather callback failed");
+    for (unsigned p = 0; p < world; p++) memcpy(h.data() + (size_t)p * bytes_per_peer, all.data() + (size_t)p * mine + (size_t)rank * bytes_per_peer, bytes_per_peer);
+    SWM_HIP(ctx, hipMemcpyAsync(d_recv, h.data(), mine, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
+// all-gather: d_recv holds world x bytes, rank order
+int shard_allgather_dev(swm_ctx* ctx, const void* d_send, size_t bytes, void* d_recv) {
+    const unsigned world = ctx->shard_world;
+    ctx->stat_exchanges++;
+    ctx->stat_exchange_bytes += bytes;
+    if (world <= 1 && !(ctx->rccl_comm && getenv("SWM_SHARD_FORCE"))) {
+        SWM_HIP(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return SWM_OK;
+    }
+    if (ctx->rccl_comm) {
+        int rc = rccl().AllGather(d_send, d_recv, bytes, /*ncclUint8*/ 1, ctx->rccl_comm, ctx->stream);
+        if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+        return SWM_OK;
+    }
+    if (!ctx->shard_allgather) return set_err(ctx, SWM_ERR_INTERNAL, "sharding: no exchange configured");
+    std::vector<uint8_t> h(bytes), all(bytes * world);
+    SWM_HIP(ctx, hipMemcpyAsync(h.data(), d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->shard_allgather(ctx->shard_user, h.data(), bytes, all.data()) != 0)
+        return set_err(ctx, SWM_ERR_INTERNAL, "sharding: the all-gather callback failed");
+    SWM_HIP(ctx, hipMemcpyAsync(d_recv, all.data(), bytes * world, hipMemcpyHostToDevice, ctx->stream));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SWM_OK;
 }
 }  // namespace swm
@@ -537,6 +609,13 @@ int swm_ntt_fr_dev(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int 
     SWM_ON_DEVICE(ctx);
     return ntt_run(ctx, d_data, log_n, inverse, coset);
 }
+int swm_ntt_fr_sharded_dev(swm_ctx* ctx, void* d_local, unsigned log_n, int inverse, int blocks_in) {
+    if (!ctx || !d_local) return set_err(ctx, SWM_ERR_INVALID_ARG, "sharded ntt: bad arguments");
+    SWM_ON_DEVICE(ctx);
+    SWM_TRY(ntt_sharded_run(ctx, d_local, log_n, inverse, blocks_in));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
 int swm_ntt_fr(swm_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
     if (!ctx || !data || log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: bad arguments");
     SWM_ON_DEVICE(ctx);
@@ -675,6 +754,14 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
 }
 
 // ------------------------------------------------------------------------------------------------ self-tests
+int swm_selftest_exchange(swm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, int alltoall) {
+    if (!ctx || !d_send || !d_recv) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
+    if (alltoall) SWM_TRY(shard_alltoall_dev(ctx, d_send, d_recv, bytes_per_peer));
+    else SWM_TRY(shard_allgather_dev(ctx, d_send, bytes_per_peer, d_recv));
+    SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWM_OK;
+}
 int swm_selftest_mul(swm_ctx* ctx, int which, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!ctx || !a || !b || !out) return SWM_ERR_INVALID_ARG;
     SWM_ON_DEVICE(ctx);

@@ -118,6 +118,9 @@ int set_err(swm_ctx* ctx, int code, const char* fmt, ...);
 void drain_streams(swm_ctx* ctx);
 // all-gather of `bytes` bytes per rank over the exchange configured on the context (RCCL communicator or caller's callback)
 int shard_exchange(swm_ctx* ctx, const void* send, size_t bytes, void* recv);
+// the same for DEVICE buffers, and the all-to-all of a sharded transform (chunk c of d_send -> rank c)
+int shard_allgather_dev(swm_ctx* ctx, const void* d_send, size_t bytes, void* d_recv);
+int shard_alltoall_dev(swm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer);
 
 // Every extern "C" entry point that takes a context runs on that context's GPU, whatever device the calling thread had
 // current (another context, torch, a thread that never called hipSetDevice); the caller's device is restored on exit.

@@ -17,6 +17,9 @@
 namespace swm {
 
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+// one transform of 2^log_n elements over the ranks of the context's sharding (ntt.hip): in place on the rank's n / G
+// elements, CYCLIC -> BLOCKS layout (blocks_in = 0) or BLOCKS -> CYCLIC (blocks_in = 1), one all-to-all
+int ntt_sharded_run(swm_ctx* ctx, void* d_local, unsigned log_n, int inverse, int blocks_in);
 // What is known about a CSR matrix once its row pointers have been seen on the host (spmv.hip): the longest row picks the
 // schedule; rows longer than the direct kernel handles are pre-cut into chunks (row, start, length) with one
 // (row, first chunk, chunk count) record per long row.

@@ -419,6 +419,33 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));
 }
+// The same for coefficients that are ALREADY distributed: this rank holds coefficient rank + G j at local[j] (the CYCLIC
+// layout a sharded inverse transform leaves, ntt.hip) and commits to them where they are — the table rows of its scalars
+// are rank, rank + G, ... (MsmTable::blk_log = 0, bstride = G).  The partial sums are exchanged like those of a range split.
+bool commit_cyclic_possible(swm_ctx* ctx, const swm_pk& pk, size_t n_local) {
+    const G1Affine *b, *b28;
+    MsmTable tab;
+    pk.bases_at(0, 1, &b, &b28, &tab);
+    return msm_flat_applies(tab, n_local);
+}
+void commit_enqueue_cyclic(swm_ctx* ctx, int* lane, const swm_pk& pk, const Fr* local, size_t n_local, AsyncMsm* out) {
+    const unsigned G = ctx->shard_world, rank = ctx->shard_rank;
+    const G1Affine *b = nullptr, *b28 = nullptr;
+    MsmTable tab;
+    out->have_result = false;
+    out->result = g1_xyzz_identity();
+    out->sharded = true;
+    if (!n_local) return;
+    pk.bases_at(0, rank + (size_t)G * (n_local - 1) + 1, &b, &b28, &tab);  // the highest power this rank touches must exist
+    tab.offset += rank;
+    tab.blk_log = 0;
+    tab.bstride = G;
+    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 0;
+    static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
+    const long batch_below = batch_env >= 0 ? batch_env : 200000;
+    rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, local, n_local, 1, &out->job, MsmInfMask(),
+                              (long)n_local <= batch_below, tab));
+}
 // every commitment of a round is enqueued: run their bucket stages together
 void commit_flush(swm_ctx* ctx) { rc_check(ctx, msm_flush_tails(ctx)); }
 // Sum of the per-rank partial sums in rank order: the same group element on every rank.
@@ -1016,9 +1043,51 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         Fr* zp = z.p + ninst + pr.nwit_orig;
         ew(ctx, "z_pad", pr.nwit - pr.nwit_orig, [=] __device__(size_t i) { zp[i] = fp_one<Fr>(); });
     }
-    DVec za_evals = dv_zeros(ctx, H), zb_evals = dv_zeros(ctx, H);
-    rc_check(ctx, spmv_run(ctx, pk.a.rowptr.p, pk.a.col.p, pk.a.val.p, z.p, za_evals.p, pk.a.rows, &pk.a.plan));
-    rc_check(ctx, spmv_run(ctx, pk.b.rowptr.p, pk.b.col.p, pk.b.val.p, z.p, zb_evals.p, pk.b.rows, &pk.b.plan));
+    // One proof over G GPUs: z_A = A z and z_B = B z are computed BY ROWS — every rank the rows of its blocks
+    // (the BLOCKS layout of ntt.hip; z is the witness every rank was handed, so no broadcast is needed) — interpolated by the
+    // sharded inverse transform (one all-to-all each), which leaves the coefficients CYCLIC over the ranks, and committed
+    // where they are (commit_enqueue_cyclic): no gather between mat-vec, transform and MSM.  The rest of the proof still
+    // works on whole polynomials, so the pieces are all-gathered once afterwards (H x 32 B per polynomial over all links).
+    const unsigned SG = ctx->shard_world;
+    unsigned slog_g = 0;
+    while ((1u << slog_g) < SG) slog_g++;
+    const bool shard_r1 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && pk.logH >= 2 * slog_g + 4 && !getenv("SWM_SHARD_R1_OFF") &&
+                          commit_cyclic_possible(ctx, pk, H / SG);
+    const size_t sm = H / (SG ? SG : 1);  // coefficients (evaluations) per rank
+    DVec za_evals, zb_evals, za_loc, zb_loc;
+    if (shard_r1) {
+        za_loc = dv_zeros(ctx, sm + 1);
+        zb_loc = dv_zeros(ctx, sm + 1);
+        const unsigned blk_log = pk.logH - 2 * slog_g;
+        const size_t row0 = (size_t)ctx->shard_rank << blk_log;
+        auto rows_of_my_blocks = [&](const DevCsr& mtx, Fr* out) {
+            const uint32_t* rowptr = mtx.rowptr.p;
+            const uint32_t* col = mtx.col.p;
+            const Fr* val = mtx.val.p;
+            const Fr* zz = z.p;
+            const size_t nrows = mtx.rows;
+            ctx->stat_spmv_calls++;
+            ctx->stat_spmv_rows += sm;
+            ew(ctx, "spmv_rows_blocks", sm, [=] __device__(size_t x) {
+                const size_t r = ((x >> blk_log) * sm) + row0 + (x & (((size_t)1 << blk_log) - 1));  // row m k1 + rank blk + t
+                Fr acc = fp_zero<Fr>();
+                if (r < nrows)
+                    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) {
+                        Fr c = val[k];
+                        Fr zv = zz[col[k]];
+                        acc = fp_add(acc, fp_is_one(c) ? zv : fp_mul(zv, c));
+                    }
+                out[x] = acc;
+            });
+        };
+        rows_of_my_blocks(pk.a, za_loc.p);
+        rows_of_my_blocks(pk.b, zb_loc.p);
+    } else {
+        za_evals = dv_zeros(ctx, H);
+        zb_evals = dv_zeros(ctx, H);
+        rc_check(ctx, spmv_run(ctx, pk.a.rowptr.p, pk.a.col.p, pk.a.val.p, z.p, za_evals.p, pk.a.rows, &pk.a.plan));
+        rc_check(ctx, spmv_run(ctx, pk.b.rowptr.p, pk.b.col.p, pk.b.val.p, z.p, zb_evals.p, pk.b.rows, &pk.b.plan));
+    }
 
     tr.mark("upload z, z_A, z_B");
     // ================= round 1
@@ -1064,22 +1133,49 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const size_t w_len = H + 1 - X;
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
     begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0]);
-    DVec za_poly = dv_zeros(ctx, H + 1);
-    {
+    DVec za_poly = dv_zeros(ctx, H + 1), zb_poly = dv_zeros(ctx, H + 1);
+    // sharded form of "interpolate, add rho v_H, commit" for one of the two polynomials
+    auto sharded_interpolate_and_commit = [&](DVec& loc, const Fr& rho, DVec& poly, CommitJob* job) {
+        rc_check(ctx, ntt_sharded_run(ctx, loc.p, pk.logH, 1, 1));  // evaluations in BLOCKS -> coefficients rank + G j at loc[j]
+        {   // the whole polynomial for the replicated rest of the proof: all-gather the pieces, interleave
+            DVec all(ctx, H);
+            rc_check(ctx, shard_allgather_dev(ctx, loc.p, sm * sizeof(Fr), all.p));
+            const Fr* src = all.p;
+            Fr* dst = poly.p;
+            const unsigned lg = slog_g;
+            const size_t per = sm;
+            ew(ctx, "shard_interleave", H, [=] __device__(size_t i) { dst[i] = src[(i & (((size_t)1 << lg) - 1)) * per + (i >> lg)]; });
+        }
+        add_rho_vh(poly.p, rho);
+        if (ctx->shard_rank == 0) {  // coefficients 0 and H = 0 + G (H / G) both live on rank 0
+            Fr* lp = loc.p;
+            const size_t top = sm;
+            ew(ctx, "add_rho_vh", 1, [=] __device__(size_t) {
+                lp[0] = fp_sub(lp[0], rho);
+                lp[top] = rho;
+            });
+        }
+        job->has_bound = false;
+        job->hiding = true;
+        commit_enqueue_cyclic(ctx, &lane, pk, loc.p, ctx->shard_rank == 0 ? sm + 1 : sm, &job->plain);
+    };
+    if (shard_r1) {
+        sharded_interpolate_and_commit(za_loc, rho_a, za_poly, &j1[1]);
+        sharded_interpolate_and_commit(zb_loc, rho_b, zb_poly, &j1[2]);
+    } else {
         dv_ntt(ctx, za_evals, pk.logH, true);
         hip_check(ctx, hipMemcpyAsync(za_poly.p, za_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
         add_rho_vh(za_poly.p, rho_a);
-    }
-    P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
-    begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
-    DVec zb_poly = dv_zeros(ctx, H + 1);
-    {
         dv_ntt(ctx, zb_evals, pk.logH, true);
         hip_check(ctx, hipMemcpyAsync(zb_poly.p, zb_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
         add_rho_vh(zb_poly.p, rho_b);
     }
+    P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
     P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
-    begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
+    if (!shard_r1) {
+        begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
+        begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
+    }
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
     if (!mask_late) flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
@@ -1820,6 +1916,20 @@ swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
         powers.size() > pk->srs_max_degree + 1 || shifted.size() != max_bound + 1 || pk->gamma_powers.size() < 3 ||
         pk->srs_max_degree != pk->vk.vk.max_degree)
         throw MarlinError(SWM_ERR_SERIALIZATION, "committer key does not fit the index");
+    {   // the committer key has to be the one the embedded verifying key was trimmed from: a key whose halves disagree would
+        // load and then produce proofs that never verify.  enforced_degree_bounds = {|H| - 2, |K| - 2}; powers[0] = g; the
+        // shift power of bound d is [beta^(max_degree - d)] g = shifted[max_bound - d].
+        auto same = [](const G1Affine& a, const G1Affine& b) { return fp_eq(a.x, b.x) && fp_eq(a.y, b.y); };
+        std::vector<uint64_t> want = {pk->H - 2, pk->K - 2};
+        std::sort(want.begin(), want.end());
+        want.erase(std::unique(want.begin(), want.end()), want.end());
+        const auto& dbs = pk->vk.vk.degree_bounds_and_shift_powers;
+        bool ok = bounds == want && dbs.size() == want.size() && same(powers[0], pk->vk.vk.g) &&
+                  same(pk->gamma_powers[0], pk->vk.vk.gamma_g);
+        for (size_t i = 0; ok && i < dbs.size(); i++)
+            ok = dbs[i].first == want[i] && same(shifted[max_bound - dbs[i].first], dbs[i].second);
+        if (!ok) throw MarlinError(SWM_ERR_SERIALIZATION, "committer key and verifying key of the proving key disagree");
+    }
     install_committer_key(ctx, *pk, powers.data(), powers.size(), shifted.data(), shifted.size(), /*device_src=*/false,
                           /*in_subgroup=*/true);  // g1_decompress_kernel checked [r]P = O for every point
     pk->gtab = build_gamma_table(pk->gamma_powers);

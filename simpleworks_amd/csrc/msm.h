@@ -29,7 +29,14 @@ struct MsmTable {
     // the same multiples as twisted Edwards rows (msm_table_build_te; g1.cuh): when set, the flat schedule accumulates and
     // reduces in that form (7 multiplications per mixed addition instead of 8M + 2S) and t28 is not needed
     const G1TE* te = nullptr;
+    // Which base scalar i of the MSM belongs to: offset + (i >> blk_log) * bstride + (i & (2^blk_log - 1)).  The default
+    // (blk_log = 31: one block) is the contiguous range [offset, offset + n); a rank of a sharded transform holds its
+    // coefficients cyclically (blk_log = 0, bstride = G, offset = rank) or in G blocks (blk_log = log2(n / G^2)), and
+    // commits to them where they are (flat schedule only).
+    unsigned blk_log = 31;
+    size_t bstride = 0;
     bool any() const { return t28 != nullptr || te != nullptr; }
+    bool contiguous() const { return blk_log >= 31; }
 };
 unsigned msm_table_windows(unsigned c);
 WinLayout msm_table_layout(unsigned c);
@@ -52,6 +59,10 @@ int msm_install_bases(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool in_
 bool msm_te_enabled();
 // HBM left for a table of `bytes` bytes? (hipMemGetInfo, keeping a quarter of the free memory for the prover's temporaries)
 bool msm_table_fits(size_t bytes);
+
+// does msm_enqueue run the precomputed-window ("flat") schedule for n points on this table?  (callers that hand over a
+// strided layout have to know: only that schedule maps scalars to bases through MsmTable::blk_log / bstride)
+bool msm_flat_applies(const MsmTable& tab, size_t n);
 
 struct MsmJob {
     bool active = false;

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
 // (entry, bucket) pairs grouped by coarse bin; grid (tiles over the points, windows).  entry = table row of the point:
 // w * tstride + toff + i, with the sign of the digit in bit 31.
 __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
-                                                           uint32_t toff, unsigned fb, uint32_t nbins,
+                                                           uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb, uint32_t nbins,
                                                            const uint32_t* __restrict__ bin_off, uint32_t* __restrict__ bin_cursor,
                                                            uint2* __restrict__ tmp) {
     // LDS: PART_TILE pairs | cnt, start, gpos (nbins words each, rounded up to a multiple of 4) | 1024 scan words: sized by
@@ -485,7 +485,8 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         if (c[u]) {
             const uint32_t bucket = (c[u] - 1) >> 1;
             const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
-            const uint32_t row = w * tstride + toff + (uint32_t)(lo + t + (size_t)u * 1024);
+            const uint32_t i = (uint32_t)(lo + t + (size_t)u * 1024);  // scalar i -> its base (MsmTable: blocks of a sharded layout)
+            const uint32_t row = w * tstride + toff + (i >> blk_log) * bstride + (i & ((1u << blk_log) - 1u));
             stage[p] = make_uint2(row | (((c[u] - 1) & 1u) << 31), bucket);
         }
     __syncthreads();
@@ -1526,6 +1527,11 @@ static int streams_concurrent(swm_ctx* ctx, hipStream_t x, hipStream_t y, bool* 
 // The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
+bool msm_flat_applies(const MsmTable& tab, size_t n) {
+    static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
+    return tab.any() && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
+           (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+}
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
                 int mont, MsmJob* job, MsmInfMask inf, bool defer_tail, MsmTable tab) {
     job->active = false;
@@ -1538,11 +1544,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->log_call('m', n);
     // flat schedule: the base set comes with its precomputed window multiples and the MSM is large enough to populate the
     // shared bucket set (below ~2^(c-4) points the per-window schedule with its small windows wins)
-    static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
-    const bool flat = tab.any() && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
-                      (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
+    const bool flat = msm_flat_applies(tab, n);
     const bool te = flat && tab.te != nullptr;  // twisted Edwards rows: accumulation and bucket stage run in that form
     job->te = te;
+    if (!tab.contiguous() && !flat)
+        return set_err(ctx, SWM_ERR_INTERNAL, "msm: a strided base layout needs the precomputed-window schedule");
     // low-latency schedule (flat MSMs below ~2^18 points, where a proof is a chain of dependent additions rather than
     // a throughput problem): short segments (8 points), every bucket with more than two segments folded by a lane
     // group in msm_big_bucket_sum (a tree instead of the serial walk of the bucket stage), one bucket per lane in the
@@ -1613,36 +1619,51 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             // earlier role is replaced by a fresh one, a few times at most — whatever streams the host application created
             // before.  SWM_MSM_QUEUE_ORDER=0 keeps the plain creation order and skips the probe.
             static const bool steer = !(getenv("SWM_MSM_QUEUE_ORDER") && atoi(getenv("SWM_MSM_QUEUE_ORDER")) == 0);
-            for (int i = 0; i < 3; i++) SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
-            if (steer) {
-                hipStream_t ph = nullptr;
-                SWM_HIP(ctx, hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
-                ctx->spare_streams.push_back(ph);
-            }
-            SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[3], hipStreamNonBlocking));
-            if (steer) {
-                SWM_HIP(ctx, hipStreamSynchronize(main_stream));
-                const int roles[3] = {0, 1, 3};  // sort, accumulation 0, tail
-                std::vector<hipStream_t> fixed = {main_stream};
-                int budget = 8;  // replacement streams at most
-                for (int r : roles) {
-                    for (;;) {
-                        bool clash = false;
-                        for (hipStream_t f : fixed) {
-                            bool conc = true;
-                            SWM_TRY(streams_concurrent(ctx, f, ctx->aux_stream[r], &conc));
-                            if (!conc) {
-                                clash = true;
-                                break;
-                            }
-                        }
-                        if (!clash || budget-- <= 0) break;
-                        ctx->spare_streams.push_back(ctx->aux_stream[r]);  // kept alive: destroying it would free its slot
-                        SWM_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[r], hipStreamNonBlocking));
-                    }
-                    fixed.push_back(ctx->aux_stream[r]);
+            // The four streams are created and probed into locals and published to the context only when all of it
+            // succeeded: a failure half way must not leave aux_stream[0] set with the later entries null (every later MSM
+            // would skip this block and silently run its tail on the legacy default stream).
+            hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+            auto setup = [&]() -> int {
+                for (int i = 0; i < 3; i++) SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+                if (steer) {
+                    hipStream_t ph = nullptr;
+                    SWM_HIP(ctx, hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
+                    ctx->spare_streams.push_back(ph);
                 }
+                SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[3], hipStreamNonBlocking));
+                if (steer) {
+                    SWM_HIP(ctx, hipStreamSynchronize(main_stream));
+                    const int roles[3] = {0, 1, 3};  // sort, accumulation 0, tail
+                    std::vector<hipStream_t> fixed = {main_stream};
+                    int budget = 8;  // replacement streams at most
+                    for (int r : roles) {
+                        for (;;) {
+                            bool clash = false;
+                            for (hipStream_t f : fixed) {
+                                bool conc = true;
+                                SWM_TRY(streams_concurrent(ctx, f, aux[r], &conc));
+                                if (!conc) {
+                                    clash = true;
+                                    break;
+                                }
+                            }
+                            if (!clash || budget-- <= 0) break;
+                            ctx->spare_streams.push_back(aux[r]);  // kept alive: destroying it would free its slot
+                            aux[r] = nullptr;
+                            SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[r], hipStreamNonBlocking));
+                        }
+                        fixed.push_back(aux[r]);
+                    }
+                }
+                return SWM_OK;
+            };
+            const int src = setup();
+            if (src != SWM_OK) {
+                for (hipStream_t a : aux)
+                    if (a) ctx->spare_streams.push_back(a);  // destroyed with the context
+                return src;
             }
+            for (int i = 0; i < swm_ctx::MSM_LANES; i++) ctx->aux_stream[i] = aux[i];
         }
         if (one_stream) {
             // lanes 0, 1, 2 on three different hardware queues (accumulation 0, tail, sort); lane 3 shares the
@@ -1836,7 +1857,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                    digits, total, flat_fb, flat_bins, ctile, flat_cnt);
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off);
         SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
-                   dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, flat_fb,
+                   dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
                    flat_bins, flat_off, flat_cur, pairs);
         SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
                    (const uint2*)pairs, flat_fb, pl.NB, flat_off, hist, sorted);
@@ -1998,9 +2019,10 @@ int msm_flush_tails(swm_ctx* ctx) {
 // Waits for a job's download, releases its slot and checks the status words.
 static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     if (job->tail_pending) SWM_TRY(msm_flush_tails(ctx));  // awaited before its round was flushed
-    SWM_HIP(ctx, hipEventSynchronize(job->done));
+    const hipError_t werr = hipEventSynchronize(job->done);
     job->active = false;
-    ctx->slot_busy[job->slot] = false;
+    ctx->slot_busy[job->slot] = false;  // released whatever the wait returned: the slot must not stay blocked for good
+    SWM_HIP(ctx, werr);
     ctx->stat_msm_adds += job->host_flags[1];  // entries the sort placed = non-zero digits
     ctx->stat_msm_zero_points += job->host_flags[2];
     if (job->host_flags[0])

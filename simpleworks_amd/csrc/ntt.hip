@@ -306,4 +306,93 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
     return SWM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- one transform over G GPUs
+// SURVEY.md §8e "NTT partitioning (ii)": the four-step split of ONE transform of n = 2^log_n elements over G = 2^g ranks
+// (m = n / G elements per rank, blk = m / G) with a single all-to-all.  A transform with one exchange maps one layout to
+// the other of
+//     CYCLIC   local[j] = v[rank + G j]                              (j < m)
+//     BLOCKS   local[k1 blk + t] = v[m k1 + rank blk + t]            (k1 < G, t < blk)
+// (with i = i1 + G i2 and k = m k1 + k2:  w^(ik) = w_G^(i1 k1) w_n^(i1 k2) w_m^(i2 k2)):
+//   CYCLIC -> BLOCKS   local length-m transform over i2 (the existing passes) | twiddle w_n^(rank k2) | all-to-all: chunk c of
+//                      k2 to rank c | length-G transform over i1 of what arrived (G values per column, in registers)
+//   BLOCKS -> CYCLIC   the same four steps backwards: length-G transform over the block index | twiddle w_n^(i_lo k1) |
+//                      all-to-all: block k1 to rank k1 | local length-m transform
+// Per pair of GPUs the exchange moves n * 32 / G^2 bytes (2^22, 8 GPUs: 2 MB over each direct xGMI link).  The prover keeps
+// evaluations in BLOCKS and coefficients in CYCLIC layout: an inverse transform (BLOCKS -> CYCLIC) leaves every rank with
+// the coefficients rank, rank + G, ... — which the sharded commitment MSM takes as they are (MsmTable::blk_log = 0,
+// bstride = G): no gather between the transform and the commitment.
+__global__ void __launch_bounds__(256) ntt_shard_twiddle(Fr* __restrict__ v, size_t count, const Fr* __restrict__ lo,
+                                                         const Fr* __restrict__ hi, uint64_t e_mul, uint64_t e_add_mul, unsigned blk_log) {
+    // v[x] *= w^(e(x)):  CYCLIC -> BLOCKS: e = rank * x (e_mul = rank, e_add_mul = 0);
+    //                    BLOCKS -> CYCLIC: x = k1 blk + t, e = (rank blk + t) k1  (e_mul = 0 marks this form, e_add_mul = rank blk)
+    size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (x >= count) return;
+    uint64_t e;
+    if (e_mul) e = e_mul * x;
+    else e = (e_add_mul + (x & (((uint64_t)1 << blk_log) - 1))) * (x >> blk_log);
+    if (e) v[x] = fp_mul(v[x], two_level_pow(lo, hi, e));
+}
+// dst[k1 blk + t] = scale * sum_{i1 < G} w_G^(i1 k1) src[i1 blk + t],  w_G^e = w_n^(e m) from the two-level tables
+template <int G>
+__global__ void __launch_bounds__(256) ntt_shard_cross(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t blk, const Fr* __restrict__ lo,
+                                                       const Fr* __restrict__ hi, uint64_t m, int scale, Fr scale_by) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= blk) return;
+    Fr x[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) x[i] = src[(size_t)i * blk + t];
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+        Fr acc = x[0];
+#pragma unroll
+        for (int i = 1; i < G; i++) {
+            const unsigned e = (unsigned)(i * k) & (G - 1);
+            acc = fp_add(acc, e ? fp_mul(x[i], two_level_pow(lo, hi, (uint64_t)e * m)) : x[i]);
+        }
+        if (scale) acc = fp_mul(acc, scale_by);
+        dst[(size_t)k * blk + t] = acc;
+    }
+}
+int ntt_sharded_run(swm_ctx* ctx, void* d_local, unsigned log_n, int inverse, int blocks_in) {
+    const unsigned G = ctx->shard_world, rank = ctx->shard_rank;
+    unsigned log_g = 0;
+    while ((1u << log_g) < G) log_g++;
+    if ((1u << log_g) != G || G > 16) return set_err(ctx, SWM_ERR_INVALID_ARG, "sharded ntt: the number of ranks must be a power of two <= 16");
+    if (log_n > 30 || log_n < 2 * log_g) return set_err(ctx, SWM_ERR_INVALID_ARG, "sharded ntt: needs at least G^2 elements");
+    if (G == 1) return ntt_run(ctx, d_local, log_n, inverse, 0);
+    const unsigned log_m = log_n - log_g, blk_log = log_m - log_g;
+    const size_t m = (size_t)1 << log_m, blk = (size_t)1 << blk_log;
+    Fr* local = reinterpret_cast<Fr*>(d_local);
+    NttTables* rt = nullptr;
+    SWM_TRY(get_root_tables(ctx, log_n, inverse, &rt));
+    const Fr *lo = reinterpret_cast<const Fr*>(rt->lo), *hi = reinterpret_cast<const Fr*>(rt->hi);
+    Fr* tmp = nullptr;
+    SWM_TRY(scratch(ctx, "ntt.shard", m * sizeof(Fr), (void**)&tmp));
+    Fr g_inv = fp_one<Fr>();
+    if (inverse) g_inv = fp_inv(fp_from_u64<Fr>(G));  // the local transform scales by 1 / m, the cross step by 1 / G
+    const dim3 grid_m((unsigned)((m + 255) / 256)), grid_b((unsigned)((blk + 255) / 256));
+    auto cross = [&](const Fr* src, Fr* dst) -> int {
+        switch (G) {
+            case 2: SWM_LAUNCH(ctx, "ntt_shard_cross", ntt_shard_cross<2>, grid_b, dim3(256), 0, src, dst, blk, lo, hi, (uint64_t)m, inverse, g_inv); break;
+            case 4: SWM_LAUNCH(ctx, "ntt_shard_cross", ntt_shard_cross<4>, grid_b, dim3(256), 0, src, dst, blk, lo, hi, (uint64_t)m, inverse, g_inv); break;
+            case 8: SWM_LAUNCH(ctx, "ntt_shard_cross", ntt_shard_cross<8>, grid_b, dim3(256), 0, src, dst, blk, lo, hi, (uint64_t)m, inverse, g_inv); break;
+            default: SWM_LAUNCH(ctx, "ntt_shard_cross", ntt_shard_cross<16>, grid_b, dim3(256), 0, src, dst, blk, lo, hi, (uint64_t)m, inverse, g_inv); break;
+        }
+        return SWM_OK;
+    };
+    if (!blocks_in) {  // CYCLIC -> BLOCKS
+        SWM_TRY(ntt_run(ctx, local, log_m, inverse, 0));
+        if (rank) SWM_LAUNCH(ctx, "ntt_shard_twiddle", ntt_shard_twiddle, grid_m, dim3(256), 0, local, m, lo, hi, (uint64_t)rank, (uint64_t)0, blk_log);
+        SWM_TRY(shard_alltoall_dev(ctx, local, tmp, blk * sizeof(Fr)));
+        SWM_TRY(cross(tmp, local));
+    } else {           // BLOCKS -> CYCLIC
+        SWM_TRY(cross(local, tmp));
+        SWM_LAUNCH(ctx, "ntt_shard_twiddle", ntt_shard_twiddle, grid_m, dim3(256), 0, tmp, m, lo, hi, (uint64_t)0, (uint64_t)rank * blk, blk_log);
+        SWM_TRY(shard_alltoall_dev(ctx, tmp, local, blk * sizeof(Fr)));
+        SWM_TRY(ntt_run(ctx, local, log_m, inverse, 0));
+    }
+    return SWM_OK;
+}
+
 }  // namespace swm

@@ -87,6 +87,7 @@ extern "C" {
     pub fn swm_msm_g1(ctx: *mut swm_ctx, bases: *const swm_bases, offset: usize, scalars: *const u64, n: usize,
                       out_jac: *mut u64) -> c_int; // VariableBaseMSM::multi_scalar_mul
     pub fn swm_ntt_fr(ctx: *mut swm_ctx, data: *mut u64, log_n: c_uint, inverse: c_int, coset: c_int) -> c_int;
+    pub fn swm_ntt_fr_sharded_dev(ctx: *mut swm_ctx, d_local: *mut c_void, log_n: c_uint, inverse: c_int, blocks_in: c_int) -> c_int;
     pub fn swm_spmv_fr(ctx: *mut swm_ctx, rowptr: *const u32, col: *const u32, val: *const u64, z: *const u64,
                        z_len: usize, out: *mut u64, rows: usize, nnz: usize) -> c_int;
     pub fn swm_batch_inverse_fr(ctx: *mut swm_ctx, data: *mut u64, n: usize) -> c_int;

@@ -508,6 +508,17 @@ def test_rccl_exchange_inside_the_library(M, S, W):
         assert S.serialize_proof(proof).hex() == case["proof"]
         pk.free()
         srs.free()
+        # the exchanges of the sharded transform through the same communicator: grouped ncclSend / ncclRecv (the one rank sends
+        # to itself) and ncclAllGather on device buffers
+        data = np.arange(4096, dtype=np.uint64).reshape(-1, 4)
+        src, dst = ctx.to_device(data), ctx.alloc(data.nbytes)
+        for alltoall in (True, False):
+            ctx.to_device(np.zeros_like(data)).free()
+            ctx.selftest_exchange(src, dst, data.nbytes, alltoall)
+            assert np.array_equal(dst.download(data.shape), data)
+        assert ctx.exchange_stats()[0] == c2 + 2
+        src.free()
+        dst.free()
     finally:
         del os.environ["SWM_SHARD_FORCE"]
         ctx.close()
@@ -536,6 +547,16 @@ for name in ("synthetic_32", "random_sparse"):
     pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
     proof = M.generate_proof(cs, pk, rng)
     ok = ok and S.serialize_verifying_key(vk).hex() == case["vk"] and S.serialize_proof(proof).hex() == case["proof"]
+# tables exist from 512 SRS powers: the sharded round 1 (mat-vec by rows, sharded inverse transform, CYCLIC commitment) runs
+case = golden("marlin_large.json")["synthetic_2p12"]
+rng = M.generate_rand()
+srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+cs, public = W.synthetic_r1cs(case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
+pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+proof = M.generate_proof(cs, pk, rng)
+ok = ok and S.serialize_verifying_key(vk).hex() == case["vk"] and S.serialize_proof(proof).hex() == case["proof"]
+pk.free()
+srs.free()
 n = 1 << 14
 rng = M.generate_rand()
 srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
@@ -628,7 +649,7 @@ def test_proving_key_roundtrip_2p16_and_table_schedule(M, S, W):
 
 # ---- proof bytes at real sizes (BASELINE config #2: "2^16 ... bit-exact vs CPU").  tests/golden/marlin_large.json comes
 # from the independent Python prover with the C restatement of the arkworks kernels plugged in (gen_golden_large.py).
-@pytest.mark.parametrize("name", ["synthetic_2p12", "synthetic_2p16"])
+@pytest.mark.parametrize("name", ["synthetic_2p12", "synthetic_2p16", "synthetic_2p18", "synthetic_2p20"])
 def test_golden_proof_bytes_at_size(M, S, W, name):
     case = golden("marlin_large.json")[name]
     rng = M.generate_rand()
@@ -694,3 +715,55 @@ def test_rng_modes_give_the_same_proof_at_2p14(M, S, W):
     assert S.serialize_proof(M.generate_proof(cs, pk, adopted2)) == p2 != p_builtin
     assert M.verify_proof(vk, public, S.deserialize_proof(p2), M.generate_rand())
     pk.free()
+
+
+# ---- sharded transform and mat-vec (SURVEY.md §8e "NTT partitioning (ii)", "SpMV"): one transform over G contexts with a
+# single all-to-all, coefficients left CYCLIC for the commitment MSM; thread ranks on one GPU, byte all-gather for RCCL
+@pytest.mark.parametrize("world,log_n", [(2, 12), (4, 13), (8, 14)])
+def test_sharded_ntt_vs_oracle(world, log_n):
+    from pyref.prng import fr_array
+    from simpleworks_amd.dist import blocks_rows, cyclic_rows
+    orc = Oracle()
+    n = 1 << log_n
+    x = orc.fr_to_mont(fr_array(n, 900 + log_n))
+    for inverse in (False, True):
+        ref = orc.ntt(x, log_n, int(inverse), 0, 4)
+        for blocks_in in (False, True):
+            def build_rank(ctx, inverse=inverse, blocks_in=blocks_in):
+                rank, w = ctx.shard_rank, world
+                rows_in = (blocks_rows if blocks_in else cyclic_rows)(log_n, w, rank)
+                d = ctx.to_device(np.ascontiguousarray(x[rows_in]))
+                ctx.ntt_fr_sharded_dev(d, log_n, inverse, blocks_in)
+                out = d.download((n // w, 4))
+                d.free()
+                return rank, out
+            for rank, out in _run_sharded(world, build_rank):
+                rows_out = (cyclic_rows if blocks_in else blocks_rows)(log_n, world, rank)
+                assert np.array_equal(out, ref[rows_out]), (world, log_n, inverse, blocks_in, rank)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
+    """One proof over 2 / 4 contexts with the sharded round 1 (mat-vec by rows of the BLOCKS layout, sharded inverse
+    transform, commitment of CYCLIC coefficients in place, one all-gather for the replicated rest): the bytes of the Python
+    model at 2^12 constraints, and the exchanges did take place."""
+    case = golden("marlin_large.json")["synthetic_2p12"]
+    n = case["num_constraints"]
+    cs, public = W.synthetic_r1cs(n, h2i(case["a"]), h2i(case["b"]))
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        before = ctx.exchange_stats()[0]
+        proof = M.generate_proof(cs, pk, rng)
+        exchanges = ctx.exchange_stats()[0] - before
+        out = (S.serialize_verifying_key(vk).hex(), S.serialize_proof(proof).hex(), exchanges)
+        pk.free()
+        srs.free()
+        return out
+
+    for vk_hex, proof_hex, exchanges in _run_sharded(world, build):
+        assert vk_hex == case["vk"]
+        assert proof_hex == case["proof"]
+        assert exchanges >= 4 + 4   # per-round partial sums + (all-to-all, all-gather) for z_A and for z_B
