@@ -364,7 +364,7 @@ void swm_destroy(swm_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    if (ctx->ext_pinned) (void)hipHostFree(ctx->ext_pinned);
+    if (ctx->ext_pinned) free(ctx->ext_pinned);
     for (auto e : ctx->ext_event)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

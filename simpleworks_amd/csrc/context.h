@@ -94,10 +94,10 @@ struct swm_ctx {
     size_t rccl_cap = 0;
     uint64_t stat_exchanges = 0, stat_exchange_bytes = 0;  // all-gathers issued / bytes contributed per rank
     swm::HostPool* host_pool = nullptr;  // created on first use (msm_finish), joined in swm_destroy
-    // bulk draws from a caller-owned generator (sample_fr_bulk): a pinned ring of two chunks filled through the callback
+    // bulk draws from a caller-owned generator (sample_fr_bulk): a ring of two host chunks filled through the callback
     // and sent up on a copy stream of its own, so that the transfers run beside whatever the context's stream is doing
     hipStream_t copy_stream = nullptr;
-    void* ext_pinned = nullptr;
+    void* ext_pinned = nullptr;  // the ring's two host chunks (malloc'd: see sample_fr_bulk)
     hipEvent_t ext_event[3] = {nullptr, nullptr, nullptr};  // [0], [1]: chunk buffer free again; [2]: destination may be written
 };
 

@@ -6,6 +6,7 @@
 // Replaces the cfg_iter!/rayon loops of ark-marlin's ahp/prover.rs and ark-poly's DensePolynomial helpers that
 // /root/reference/src/marlin/mod.rs:75 reaches (sources not vendored; behaviour from SURVEY.md A.3, A.5-A.7).
 #pragma once
+#include <chrono>
 #include <exception>
 #include <utility>
 #include <atomic>
@@ -664,8 +665,8 @@ static __global__ void __launch_bounds__(256) sample_flag_raw(Fr* __restrict__ c
 // successive Fr::rand(rng) calls would.
 // Caller-owned generator (rng.ext): the candidates come from its fill_bytes in runs of at most EXT_CHUNK and never more than
 // the number still missing, so the stream stops right behind the candidate that completes the draw.  The host only COUNTS
-// the accepted candidates of a run (it has to know how many are still missing); the raw run goes up from a pinned ring of
-// two chunks on the context's copy stream and is flagged, scanned and compacted into place on the GPU (the kernels of the
+// the accepted candidates of a run (it has to know how many are still missing); the raw run goes up from a ring of
+// two host chunks on the context's copy stream and is flagged, scanned and compacted into place on the GPU (the kernels of the
 // built-in path), while the callback produces the next run: ~170 MB through the callback for 3 * 2^20 elements, i.e. as
 // fast as the caller's generator.  The call returns once the callback is done; the context's stream is made to wait for the
 // last run.  `marked`: sample_fr_ext_mark was called when `out` was allocated — the transfers then wait for that point of
@@ -679,7 +680,12 @@ inline void sample_fr_ext_mark(swm_ctx* ctx) {  // call right after allocating t
 inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, bool marked = false) {
     if (rng.ext) {
         if (!ctx->copy_stream) hip_check(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "copy stream");
-        if (!ctx->ext_pinned) hip_check(ctx, hipHostMalloc(&ctx->ext_pinned, 2 * EXT_CHUNK * sizeof(Fr), hipHostMallocDefault), "pinned ring");
+        // (the chunks are ordinary cacheable host memory: a host ChaCha fills pinned memory at a fifth of the rate it fills
+        // malloc'd memory on the bench host — 1.1 against 5.2 GB/s — and the runtime's staged copy of 8 MB is fast)
+        if (!ctx->ext_pinned) {
+            ctx->ext_pinned = malloc(2 * EXT_CHUNK * sizeof(Fr));
+            if (!ctx->ext_pinned) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
+        }
         for (int i = 0; i < 2; i++)
             if (!ctx->ext_event[i]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[i], hipEventDisableTiming), "event");
         // device side of the ring: raw candidates, flags, ranks and the scan's tile totals, per slot
@@ -692,11 +698,22 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         hip_check(ctx, hipStreamWaitEvent(cs, ctx->ext_event[2], 0), "wait");
         size_t have = 0;
         bool used[2] = {false, false};
+        static const bool trace = getenv("SWM_TRACE") != nullptr;
+        double t_cb = 0, t_count = 0, t_wait = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
         for (int b = 0; have < need; b ^= 1) {
             const size_t want = std::min(need - have, EXT_CHUNK);
             uint32_t* buf = reinterpret_cast<uint32_t*>((char*)ctx->ext_pinned + (size_t)b * EXT_CHUNK * sizeof(Fr));
+            auto t0 = now();
             if (used[b]) hip_check(ctx, hipEventSynchronize(ctx->ext_event[b]), "ring");
+            auto t1 = now();
             rng.ext(rng.ext_user, reinterpret_cast<uint8_t*>(buf), want * 32);
+            auto t2 = now();
+            t_wait += ms(t0, t1);
+            t_cb += ms(t1, t2);
             size_t acc = 0;
             const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
             for (size_t i = 0; i < want; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
@@ -713,6 +730,7 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
                     acc += lt;
                 }
             }
+            t_count += ms(t2, now());
             Fr* d_raw = reinterpret_cast<Fr*>(dev + (size_t)b * slot_bytes);
             uint32_t* d_flag = reinterpret_cast<uint32_t*>(d_raw + EXT_CHUNK);
             uint32_t* d_rank = d_flag + EXT_CHUNK;
@@ -733,6 +751,9 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         }
         hip_check(ctx, hipEventRecord(ctx->ext_event[2], cs), "record");
         hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ext_event[2], 0), "wait");
+        if (trace)
+            fprintf(stderr, "[swm trace]   bulk draw of %zu elements from the caller's generator: callback %.1f ms, counting %.1f ms, "
+                            "waiting for the ring %.1f ms\n", need, t_cb, t_count, t_wait);
         // the device ring is reused by the next draw: its kernels are ordered behind these on the copy stream
         return;
     }

@@ -2034,6 +2034,12 @@ int swm_rng_fill_bytes(swm_rng* rng, uint8_t* dest, size_t len) {
         return SWM_OK;
     }
     size_t i = 0;
+    auto put_word = [&] {
+        uint32_t w = rng->r.next_u32();
+        dest[i] = (uint8_t)w; dest[i + 1] = (uint8_t)(w >> 8); dest[i + 2] = (uint8_t)(w >> 16); dest[i + 3] = (uint8_t)(w >> 24);
+        i += 4;
+    };
+    while (i + 4 <= len && (rng->r.pos & 15) != 0) put_word();  // up to the next block boundary word by word
     // whole keystream blocks straight into the destination (little-endian host): what a bulk draw through the callback
     // of a test harness asks for, 8 MB at a time
 #ifdef SWM_CHACHA_WIDE
@@ -2054,10 +2060,7 @@ int swm_rng_fill_bytes(swm_rng* rng, uint8_t* dest, size_t len) {
         rng->r.have = false;
         i += 64;
     }
-    for (; i + 4 <= len; i += 4) {
-        uint32_t w = rng->r.next_u32();
-        dest[i] = (uint8_t)w; dest[i + 1] = (uint8_t)(w >> 8); dest[i + 2] = (uint8_t)(w >> 16); dest[i + 3] = (uint8_t)(w >> 24);
-    }
+    while (i + 4 <= len) put_word();
     if (i < len) {
         uint32_t w = rng->r.next_u32();
         for (; i < len; i++, w >>= 8) dest[i] = (uint8_t)w;

@@ -3,8 +3,10 @@
 //! (`anyhow!("{:?}", e)`), with the arithmetic running in libswmarlin.so on an MI355X.
 //!
 //! How arkworks values cross the boundary
-//! * `&mut StdRng`         -> `swm_rng_from_callback` over a `fill_bytes` trampoline: the library draws from the caller's
-//!                            generator, word for word as arkworks would (setup trapdoor, zk blinding, verifier batching).
+//! * `&mut StdRng`         -> by STATE: `swm_rng_from_chacha(seed, word position)`, position written back afterwards — the
+//!                            library produces the caller's ChaCha12 stream itself (on the GPU for the 3|H| mask coefficients),
+//!                            word for word as arkworks would draw it; any other `RngCore` goes through
+//!                            `swm_rng_from_callback` over a `fill_bytes` trampoline (same stream, at the caller's speed).
 //! * `ConstraintSystemRef` -> `PackedR1cs::from_cs` (matrices + assignments as flat arrays).
 //! * `UniversalSRS`        -> `swm_srs_export` / `swm_srs_import` (the fields of kzg10::UniversalParams).
 //! * `ProvingKey`, `VerifyingKey`, `MarlinProof` -> their CanonicalSerialize bytes, which the library reads and writes
@@ -139,9 +141,66 @@ unsafe extern "C" fn fill_bytes_trampoline<R: RngCore>(user: *mut c_void, dest: 
     let rng = &mut *(user as *mut R);
     rng.fill_bytes(std::slice::from_raw_parts_mut(dest, len));
 }
+/// rand 0.8 defines `pub struct StdRng(rand_chacha::ChaCha12Rng)` (private field, no accessor).  A ChaCha12 generator is
+/// fully described by (seed, stream, word position), which `ChaCha12Rng` exposes — so a `StdRng` can be handed to the library
+/// BY STATE (`swm_rng_from_chacha`): the library then produces the caller's stream on the GPU instead of pulling ~170 MB per
+/// 2^20-constraint proof through `fill_bytes`, and the position is written back afterwards (`set_word_pos`): the caller
+/// observes exactly what it would have observed through the callback.  The view below relies on the single-field tuple struct
+/// having its field's layout; `std_rng_view_is_sound` checks that once per process on a generator with a known stream
+/// (size, alignment, seed, position, next words) and the callback path is used if anything differs.
+fn std_rng_as_chacha(rng: &mut StdRng) -> &mut rand_chacha::ChaCha12Rng {
+    unsafe { &mut *(rng as *mut StdRng as *mut rand_chacha::ChaCha12Rng) }
+}
+fn std_rng_view_is_sound() -> bool {
+    use rand::SeedableRng;
+    use std::sync::OnceLock;
+    static OK: OnceLock<bool> = OnceLock::new();
+    *OK.get_or_init(|| {
+        if std::mem::size_of::<StdRng>() != std::mem::size_of::<rand_chacha::ChaCha12Rng>()
+            || std::mem::align_of::<StdRng>() != std::mem::align_of::<rand_chacha::ChaCha12Rng>()
+        {
+            return false;
+        }
+        let seed = [7u8; 32];
+        let mut a = StdRng::from_seed(seed);
+        let mut b = rand_chacha::ChaCha12Rng::from_seed(seed);
+        for _ in 0..5 {
+            if a.next_u32() != b.next_u32() {
+                return false;
+            }
+        }
+        let view = std_rng_as_chacha(&mut a);
+        if view.get_seed() != seed || view.get_stream() != 0 || view.get_word_pos() != 5 {
+            return false;
+        }
+        view.set_word_pos(37);
+        b.set_word_pos(37);
+        a.next_u64() == b.next_u64()
+    })
+}
+
 /// Runs `f` with a library handle that draws from `rng` (any `RngCore`, as `Marlin`'s associated functions accept; the
-/// reference always passes its `StdRng`); the handle does not outlive the borrow.
-fn with_rng<R: RngCore, T>(rng: &mut R, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+/// reference always passes its `StdRng`); the handle does not outlive the borrow.  A `StdRng` on stream 0 is handed over by
+/// state (see above), everything else through the `fill_bytes` callback.
+fn with_rng<R: RngCore + 'static, T>(rng: &mut R, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+    if let Some(std_rng) = (rng as &mut dyn std::any::Any).downcast_mut::<StdRng>() {
+        if std_rng_view_is_sound() {
+            let inner = std_rng_as_chacha(std_rng);
+            let pos = inner.get_word_pos();
+            if inner.get_stream() == 0 && pos < (1u128 << 62) {
+                let seed = inner.get_seed();
+                let mut h = std::ptr::null_mut();
+                check(unsafe { swm_rng_from_chacha(seed.as_ptr(), pos as u64, 12, &mut h) }, "swm_rng_from_chacha", std::ptr::null_mut())?;
+                let out = f(h);
+                let mut end = 0u64;
+                let rc = unsafe { swm_rng_word_pos(h, &mut end) };
+                unsafe { swm_rng_free(h) };
+                check(rc, "swm_rng_word_pos", std::ptr::null_mut())?;
+                inner.set_word_pos(end as u128); // the caller's generator continues where the library stopped
+                return out;
+            }
+        }
+    }
     let mut h = std::ptr::null_mut();
     check(
         unsafe { swm_rng_from_callback(fill_bytes_trampoline::<R>, rng as *mut R as *mut c_void, &mut h) },
@@ -212,7 +271,7 @@ pub fn generate_universal_srs(
     universal_setup(num_constraints, num_variables, num_non_zero, rng).map(Box::new).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn universal_setup<R: RngCore>(nc: usize, nv: usize, nnz: usize, rng: &mut R) -> std::result::Result<UniversalSRS, SwmError> {
+fn universal_setup<R: RngCore + 'static>(nc: usize, nv: usize, nnz: usize, rng: &mut R) -> std::result::Result<UniversalSRS, SwmError> {
     with_state(|st| {
         let ctx = st.ctx;
         let handle = with_rng(rng, |r| {
@@ -350,7 +409,7 @@ pub fn generate_proof(
     prove(&proving_key, constraint_system, rng).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn prove<R: RngCore>(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut R) -> std::result::Result<MarlinProof, SwmError> {
+fn prove<R: RngCore + 'static>(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut R) -> std::result::Result<MarlinProof, SwmError> {
     let packed = PackedR1cs::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "to_matrices", detail: format!("{:?}", e) })?;
     with_state(|st| {
         let ctx = st.ctx;
@@ -373,7 +432,7 @@ pub fn verify_proof(
     verify(&verifying_key, public_inputs, proof, rng).map_err(|e| anyhow!("{:?}", e))
 }
 
-fn verify<R: RngCore>(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, SwmError> {
+fn verify<R: RngCore + 'static>(vk: &VerifyingKey, public_inputs: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, SwmError> {
     let (_, vk_bytes) = vk_key(vk)?;
     let mut proof_bytes = Vec::new();
     proof.serialize(&mut proof_bytes).map_err(|e| SwmError { code: -7, what: "Proof::serialize", detail: format!("{:?}", e) })?;
@@ -431,7 +490,7 @@ fn synthesize<C: ConstraintSynthesizer<Fr>>(c: C, mode: SynthesisMode) -> std::r
 
 impl MarlinInst {
     /// `Marlin::universal_setup` (simple_merkle_tree.rs:39).
-    pub fn universal_setup<R: RngCore>(
+    pub fn universal_setup<R: RngCore + 'static>(
         num_constraints: usize,
         num_variables: usize,
         num_non_zero: usize,
@@ -453,18 +512,18 @@ impl MarlinInst {
 
     /// `Marlin::prove` (simple_merkle_tree.rs:119).  An unsatisfied witness is an `Err` here (ark-marlin panics on a
     /// debug assertion, which the reference's `#[should_panic]` test reaches through `unwrap`: same outcome).
-    pub fn prove<C: ConstraintSynthesizer<Fr>, R: RngCore>(index_pk: &ProvingKey, c: C, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
+    pub fn prove<C: ConstraintSynthesizer<Fr>, R: RngCore + 'static>(index_pk: &ProvingKey, c: C, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
         let cs = synthesize(c, SynthesisMode::Prove { construct_matrices: true })?;
         prove(index_pk, cs, zk_rng).map_err(to_marlin_error)
     }
 
     /// The fork's entry point for an already synthesised system (/root/reference/src/marlin/mod.rs:75).
-    pub fn prove_from_constraint_system<R: RngCore>(index_pk: &ProvingKey, cs: ConstraintSystemRef, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
+    pub fn prove_from_constraint_system<R: RngCore + 'static>(index_pk: &ProvingKey, cs: ConstraintSystemRef, zk_rng: &mut R) -> std::result::Result<MarlinProof, MarlinError> {
         prove(index_pk, cs, zk_rng).map_err(to_marlin_error)
     }
 
     /// `Marlin::verify` (simple_merkle_tree.rs:148).
-    pub fn verify<R: RngCore>(index_vk: &VerifyingKey, public_input: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, MarlinError> {
+    pub fn verify<R: RngCore + 'static>(index_vk: &VerifyingKey, public_input: &[Fr], proof: &MarlinProof, rng: &mut R) -> std::result::Result<bool, MarlinError> {
         verify(index_vk, public_input, proof, rng).map_err(to_marlin_error)
     }
 }

@@ -14,7 +14,7 @@ for src, dst in (("bench_prove.json", "bench_prove.json"), ("bench_msm.json", "b
                  ("ntt_time.log", "ntt_standalone.log"), ("small_proofs.log", "small_proofs.log")):
     if os.path.exists(os.path.join(o, src)):
         shutil.copy(os.path.join(o, src), os.path.join(p, "%s_%s" % (pre, dst)))
-for name, launches, log, cmd in (("prove", 75, "prof_prove", "--steps 5 --warmup 1"),
+for name, launches, log, cmd in (("prove", 75, "prof_prove", "--steps 5 --warmup 1 --no-drop-in"),
                                  ("msm", 12, "prof_msm", "--workload msm --steps 12 --warmup 2")):
     r = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "tools", "rocprof_region.py"),
                                             os.path.join(o, log, "run_kernel_trace.csv"), "msm_accumulate", str(launches)]))
@@ -35,22 +35,7 @@ for name, launches, log, cmd in (("prove", 75, "prof_prove", "--steps 5 --warmup
     print(name, "rocprof", round(r["avg_ms_timed_region"], 4), "bench events", b["roofline"]["avg_launch_ms"])
 
 
-def pmc(kind):
-    rows = list(csv.DictReader(open(os.path.join(o, "pmc_" + kind, "run_counter_collection.csv"))))
-    vals = [float(r["Counter_Value"]) for r in rows][1:]
-    return sum(vals) / len(vals)
-
-
-f, w, n = pmc("fetch"), pmc("write"), 1 << 20
-json.dump({"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "kernel": "msm_accumulate",
-           "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-include-regex msm_accumulate -- "
-                      "python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline   (tools/collect_profiles.sh)",
-           "points_per_launch": n, "hbm_bytes_per_launch": (f + w) * 1024, "hbm_bytes_per_point": (f + w) * 1024 / n,
-           "note": "FETCH_SIZE taken at face value (KB): the access pattern is 6 x 16-B loads per lane into random 96-B "
-                   "records, i.e. two 64-B requests per record; 13 windows x 2^20 records x 128 B = 1.7 GB matches the counter, so "
-                   "the x2 correction the guide gives for wide coalesced streams does not apply. One table row per (point, window) "
-                   "is inherent to the precomputed-window schedule (13 windows at c = 20): the table of a 2^20-point base set is "
-                   "13 x 100 MB, larger than the Infinity Cache, so this is DRAM traffic (0.9 TB/s at 2.0 ms per launch: 11 % of "
-                   "the HBM peak; the kernel is bound by integer issue, see DESIGN.md section 3). Writes: one 192-B partial sum "
-                   "per segment."}, open(os.path.join(p, pre + "_pmc_msm_accumulate.json"), "w"), indent=1)
-print("traffic B/point", (f + w) * 1024 / n)
+# PMC passes: SQ issue counters and FETCH / WRITE of the dominant kernel, FETCH / WRITE of the secondary kernels alone
+subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summaries.py"), tag, pre])
+if os.path.exists(os.path.join(o, "timeline_share.txt")):
+    shutil.copy(os.path.join(o, "timeline_share.txt"), os.path.join(p, pre + "_prove_2p20_timeline_share.txt"))
