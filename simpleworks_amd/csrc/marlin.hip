@@ -1226,9 +1226,38 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
 
     // ================= round 2
     const Fr alpha = st.alpha, eta_a = st.eta_a, eta_b = st.eta_b, eta_c = st.eta_c;
-    // r(alpha, X) on H = v_H(alpha) / (alpha - w^i)
-    DVec r_alpha_evals(ctx, H);
+    // r(alpha, X) = (alpha^|H| - X^|H|) / (alpha - X) is needed on H (input of the transposed mat-vecs) and on the 4|H| domain
+    // (outer sumcheck).  On the 4|H| domain X^|H| takes the four values i4^(i mod 4), i4 a primitive fourth root of unity, so both
+    // come from ONE batch inversion of alpha - w4^i over 4|H| points — instead of an inversion over H, an inverse transform of
+    // size |H| and a forward one of size 4|H| (r03).  H is every fourth point of that domain.  (alpha on the 4|H| domain —
+    // probability 2^-231 — would make a denominator vanish: the transforms are kept for that case.)
+    DVec r_alpha_evals(ctx, H), e_ra;
+    bool ra_closed_form;
     {
+        Fr a4h = alpha;
+        for (unsigned i = 0; i < logM; i++) a4h = fp_sqr(a4h);
+        ra_closed_form = !fp_is_one(a4h) && !getenv("SWM_RALPHA_TRANSFORMS");
+    }
+    if (ra_closed_form) {
+        e_ra = DVec(ctx, M);
+        PowTable wt = root_pow_table(ctx, logM);
+        Fr* out = e_ra.p;
+        ew(ctx, "r_alpha_den", M, [=] __device__(size_t i) { out[i] = fp_sub(alpha, wt.at(i)); });
+        rc_check(ctx, batch_inverse_run(ctx, out, M));
+        Fr aH = alpha;
+        for (unsigned i = 0; i < pk.logH; i++) aH = fp_sqr(aH);
+        HDomain d4(M);
+        Fr i4 = d4.gen;  // w4^|H|
+        for (unsigned i = 0; i < pk.logH; i++) i4 = fp_sqr(i4);
+        Fr n0 = fp_sub(aH, fp_one<Fr>()), n1 = fp_sub(aH, i4), n2 = fp_sub(aH, fp_sqr(i4)), n3 = fp_sub(aH, fp_mul(fp_sqr(i4), i4));
+        Fr* rh = r_alpha_evals.p;
+        ew(ctx, "r_alpha_scale", M, [=] __device__(size_t i) {
+            const unsigned q = (unsigned)(i & 3);
+            Fr v = fp_mul(out[i], q == 0 ? n0 : q == 1 ? n1 : q == 2 ? n2 : n3);
+            out[i] = v;
+            if (q == 0) rh[i >> 2] = v;
+        });
+    } else {
         PowTable wt = root_pow_table(ctx, pk.logH);
         Fr* out = r_alpha_evals.p;
         ew(ctx, "r_alpha_den", H, [=] __device__(size_t i) { out[i] = fp_sub(alpha, wt.at(i)); });
@@ -1257,9 +1286,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
     DVec q1(ctx, M);
     {
-        DVec ra_poly = dv_copy_padded(ctx, r_alpha_evals.p, H, H);
-        dv_ntt(ctx, ra_poly, pk.logH, true);
-        DVec e_ra = on_mul_domain(ra_poly.p, H);
+        if (!ra_closed_form) {
+            DVec ra_poly = dv_copy_padded(ctx, r_alpha_evals.p, H, H);
+            dv_ntt(ctx, ra_poly, pk.logH, true);
+            e_ra = on_mul_domain(ra_poly.p, H);
+        }
         DVec e_t = on_mul_domain(t_poly.p, H);
         Fr* out = q1.p;
         const Fr *pra = e_ra.p, *pza = e_za.p, *pzb = e_zb.p, *pt = e_t.p, *pz = e_z.p;
