@@ -45,7 +45,8 @@ struct swm_ctx {
     std::map<std::string, swm::DevBuf> scratch;
     // NTT root tables keyed by (log_n << 1 | inverse); coset tables keyed by inverse flag
     std::map<uint64_t, swm::NttTables> ntt_tables;
-    std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse)
+    std::map<uint64_t, void*> ntt_small;  // per-radix intra-tile twiddles keyed by (log_r << 1 | inverse); per-pass twiddle tables
+    size_t ntt_pass_table_bytes = 0;      // HBM held by the per-pass twiddle tables of the lazy transform (capped, ntt.hip)
     // asynchronous MSM lanes: auxiliary streams (the prover alternates between two of them), a fork event, pinned result slots with their completion events
     static constexpr int MSM_SLOTS = 8;
     static constexpr int MSM_LANES = 4;

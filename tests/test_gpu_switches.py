@@ -50,5 +50,8 @@ def test_switches_select_equivalent_paths():
                 {"SWM_RED_LANES": "64"}, {"SWM_MSM_PIPE": "0"}, {"SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
                 {"SWM_MSM_SMALL_LANES": "1", "SWM_COMMIT_LATE": "1"},
                 {"SWM_MSM_TE": "0"},          # XYZZ tables instead of the twisted Edwards ones
-                {"SWM_SAMPLE_TIGHT": "1"}):   # the bulk sampler's retry branch, several rounds per draw
+                {"SWM_SAMPLE_TIGHT": "1"},    # the bulk sampler's retry branch, several rounds per draw
+                {"SWM_NTT_LAZY": "0"},        # 8 x 32-bit Comba transform instead of the 9 x 29-bit lazy one
+                {"SWM_NTT_PASS_TABLES": "0"},  # lazy transform with the two-level twiddle product on every pass
+                {"SWM_RALPHA_TRANSFORMS": "1"}):  # r(alpha, X) on 4|H| by two transforms instead of the closed form
         assert _run(env) == ref, env
