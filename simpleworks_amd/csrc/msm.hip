@@ -375,6 +375,10 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort(const uint2* __restr
 static constexpr uint32_t FLAT_MAX_BINS = 4096;
 static constexpr uint32_t FLAT_MAX_FINE = 2048;  // buckets per bin at most (2^fb): fine counts + offsets (16 KB) next to the 128-KB stage
 static constexpr uint32_t FLAT_BIN_CAP = 32768;  // entries a bin may hold to be placed in LDS (128 KB)
+// The per-bin cursors of msm_flat_partition sit one per 128-byte line: every workgroup of the launch reserves its runs with
+// one returning atomic per bin, and packed (32 cursors to a line) those atomics queued up behind one another at the
+// memory side — 135 of the kernel's 191 us at 2^20 points (measured by replacing the atomic with arithmetic).
+static constexpr uint32_t FLAT_CUR_STRIDE = 32;
 __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t total, unsigned fb,
                                                                      uint32_t nbins, uint32_t tile, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t lh[FLAT_MAX_BINS];
@@ -458,24 +462,31 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         v[u] = 4 * t + u < nbins ? cnt[4 * t + u] : 0u;
         sum += v[u];
     }
-    scan[t] = sum;
-    __syncthreads();
-    for (uint32_t dd = 1; dd < 1024; dd <<= 1) {
-        uint32_t x = t >= dd ? scan[t - dd] : 0u;
-        __syncthreads();
-        scan[t] += x;
-        __syncthreads();
+    // inclusive scan over the 1024 lanes: shuffles inside a wave, the 16 wave totals through LDS (two barriers instead of
+    // the twenty of a Hillis-Steele scan in LDS)
+    uint32_t inc = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        uint32_t x = __shfl_up(inc, dd, 64);
+        if ((t & 63) >= (uint32_t)dd) inc += x;
     }
-    uint32_t run = scan[t] - sum;
-    const uint32_t total = scan[1023];
+    if ((t & 63) == 63) scan[t >> 6] = inc;
     __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t wv = 0; wv < 16; wv++) {
+        const uint32_t x = scan[wv];
+        if (wv < (t >> 6)) before += x;
+        total += x;
+    }
+    uint32_t run = before + inc - sum;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const uint32_t b = 4 * t + u;
         if (b < nbins) {
             start[b] = run;
             cnt[b] = run;  // running cursor of the bin inside the staged tile
-            gpos[b] = v[u] ? bin_off[b] + atomicAdd(&bin_cursor[b], v[u]) : 0u;
+            gpos[b] = v[u] ? bin_off[b] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE], v[u]) : 0u;
         }
         run += v[u];
     }
@@ -776,6 +787,9 @@ __device__ __forceinline__ uint32_t bucket_of_segment(const uint32_t* __restrict
 // longest segment; bucket sizes are Poisson-spread (a wave of 64 unsorted segments idles ~25 % of its lane-cycles).
 // Segments are therefore counting-sorted by length (longest first) and handed to lanes in that order.
 static constexpr int ORD_THREADS = 256;
+// the SEG + 1 length counters / cursors sit one per 128-byte line (every workgroup of msm_seg_desc and msm_seg_order
+// updates most of them; packed, those atomics queue up behind one another — see FLAT_CUR_STRIDE)
+static constexpr uint32_t LEN_STRIDE = 32;
 __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __restrict__ bucket_off,
                                                             const uint32_t* __restrict__ seg_off, uint32_t NB,
                                                             uint32_t SEG, uint32_t* __restrict__ seg_start,
@@ -796,16 +810,32 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __re
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS)
-        if (lh[i]) atomicAdd(&len_hist[i], lh[i]);
+        if (lh[i]) atomicAdd(&len_hist[i * LEN_STRIDE], lh[i]);
 }
-__global__ void msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i <= SEG; i++) {
-            uint32_t c = len_hist[i];
-            len_hist[i] = run;
-            run += c;
-        }
+__global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG) {
+    // one wave, three consecutive counters per lane (SEG <= SEG_MAX = 128: 129 counters at most), shuffle scan across the lanes
+    static_assert(SEG_MAX + 1 <= 3 * 64, "three counters per lane");
+    if (blockIdx.x) return;
+    const uint32_t l = threadIdx.x;
+    uint32_t c[3], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const uint32_t i = 3 * l + u;
+        c[u] = i <= SEG ? len_hist[i * LEN_STRIDE] : 0u;
+        sum += c[u];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t x = __shfl_up(inc, d, 64);
+        if (l >= (uint32_t)d) inc += x;
+    }
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const uint32_t i = 3 * l + u;
+        if (i <= SEG) len_hist[i * LEN_STRIDE] = run;
+        run += c[u];
     }
 }
 __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
@@ -825,7 +855,7 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __r
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) {
         uint32_t v = lh[i];
-        if (v) lh[i] = atomicAdd(&len_cursor[i], v);  // reserve a run; lh[i] = its start
+        if (v) lh[i] = atomicAdd(&len_cursor[i * LEN_STRIDE], v);  // reserve a run; lh[i] = its start
     }
     __syncthreads();
     if (live) order[atomicAdd(&lh[bin], 1u)] = seg;
@@ -1809,17 +1839,17 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         flat_bins = (pl.NB + (1u << flat_fb) - 1) >> flat_fb;
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (SEG_MAX + 1) + MAX_WIN + (size_t)pl.nwin * maxbins +
-                              (flat ? 3 * (size_t)FLAT_MAX_BINS + 2 : 0);
+    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
+                              (flat ? (2 + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 2 : 0);
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
-    uint32_t* two_level_bad = len_hist + (SEG_MAX + 1);  // one flag per window, then the per-(window, bin) cursors
+    uint32_t* two_level_bad = len_hist + (SEG_MAX + 1) * LEN_STRIDE;  // one flag per window, then the per-(window, bin) cursors
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
-    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;  // [bins] counts | [bins] cursors | [bins + 1] offsets
-    uint32_t* flat_cur = flat_cnt + FLAT_MAX_BINS;
-    uint32_t* flat_off = flat_cur + FLAT_MAX_BINS;
+    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;  // [bins] counts | [bins + 1] offsets | [bins] cursors, one per line
+    uint32_t* flat_off = flat_cnt + FLAT_MAX_BINS;
+    uint32_t* flat_cur = flat_off + FLAT_MAX_BINS + 2;
     uint2* pairs = nullptr;
     if (two_level || flat) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
