@@ -235,6 +235,32 @@ int swm_r1cs_is_satisfied(swm_ctx *ctx, const swm_r1cs *cs, int *ok, size_t *fir
 int swm_blake2s(const uint8_t *data, size_t len, uint8_t out[32]);
 int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_t out[64]);
 
+/* ---------------------------------------------------------------------------------------------- Pedersen CRH + Merkle tree
+ * The tree BASELINE config #5 builds before it proves membership ("below the line").  Replaces, on the GPU,
+ *   /root/reference/src/merkle_tree/simple_merkle_tree.rs:47-49   MerkleTree::<MerkleConfig>::new(&leaf_params, &two_to_one_params, leaves)
+ *   /root/reference/src/merkle_tree/common.rs:11-30               LeafHash / TwoToOneHash = PedersenCRHCompressor<EdwardsProjective, TECompressor, W>
+ *   /root/reference/src/hash/mod.rs:13-28                         the Pedersen CRH called on its own
+ * swm_pedersen = pedersen::Parameters<EdwardsProjective> [U]: generators[w][j] = 2^j g_w, w < num_windows, j < window_size,
+ * handed over as affine (x, y), 2 x 32 little-endian bytes each in standard form (to_bytes! of the affine point), window
+ * after window.  Refused with SWM_ERR_INVALID_ARG: a coordinate >= r, a point off the curve, a generator that is not twice
+ * its predecessor.  A digest is the affine x coordinate of the sum (TECompressor), 32 little-endian bytes.
+ * swm_pedersen_hash: `count` inputs of `input_len` bytes each, back to back; input_len x 8 <= num_windows x window_size
+ * (else SWM_ERR_INVALID_ARG, where ark-crypto-primitives panics); bits LSB-first inside a byte, missing bits zero.
+ * swm_merkle_tree_build: n_leaves (a power of two >= 2) leaves of leaf_len bytes each (to_bytes! of a leaf: 1 for u8);
+ * nodes = n leaf digests | n / 2 two-to-one digests of (left || right) | ... | root: (2 n - 1) x 32 bytes.  Sibling of
+ * node i of a level is i ^ 1; the path of leaf i is level[l][(i >> l) ^ 1].  _dev: device pointers (digests 4-byte aligned). */
+typedef struct swm_pedersen swm_pedersen;
+int swm_pedersen_create(swm_ctx *ctx, const uint8_t *generators_xy, size_t num_windows, size_t window_size, swm_pedersen **out);
+void swm_pedersen_destroy(swm_ctx *ctx, swm_pedersen *params);
+int swm_pedersen_hash(swm_ctx *ctx, const swm_pedersen *params, const uint8_t *inputs, size_t input_len, size_t count,
+                      uint8_t *digests);
+int swm_pedersen_hash_dev(swm_ctx *ctx, const swm_pedersen *params, const void *d_inputs, size_t input_len, size_t count,
+                          void *d_digests);
+int swm_merkle_tree_build(swm_ctx *ctx, const swm_pedersen *leaf_params, const swm_pedersen *two_to_one_params,
+                          const uint8_t *leaves, size_t leaf_len, size_t n_leaves, uint8_t *nodes);
+int swm_merkle_tree_build_dev(swm_ctx *ctx, const swm_pedersen *leaf_params, const swm_pedersen *two_to_one_params,
+                              const void *d_leaves, size_t leaf_len, size_t n_leaves, void *d_nodes);
+
 /* ---------------------------------------------------------------------------------------------- one proof over several GPUs
  * every commitment MSM of swm_generate_proof / swm_generate_proving_and_verifying_keys is split by
  * point range — rank g of `world` takes coefficients and SRS powers [g n / world, (g+1) n / world) — and the

@@ -628,6 +628,105 @@ void oracle_spmv_fr_mt(const uint32_t *rowptr, const uint32_t *col, const uint64
     }
 }
 
+/* ------------------------------------------------------------------ Pedersen CRH on ed-on-BLS12-377 + Merkle tree
+ * Checker for simpleworks_amd/csrc/pedersen.hip.  Restates ark-crypto-primitives 0.3 [U] (not vendored in /root/reference):
+ *   crh/pedersen CRH::evaluate: input zero-padded to WINDOW_SIZE x NUM_WINDOWS bits, bits LSB-first inside a byte; per
+ *     window `encoded += generators[w][j]` for every set bit j, the windows' points summed;
+ *   crh/injective_map TECompressor: the affine x coordinate;
+ *   merkle_tree MerkleTree::new: leaf digests, then two-to-one hashes of to_bytes![left] || to_bytes![right] level by level;
+ * as reached from /root/reference/src/merkle_tree/simple_merkle_tree.rs:47-49 with the windows of
+ * /root/reference/src/merkle_tree/common.rs:11-30 and from /root/reference/src/hash/mod.rs:23-28.
+ * Group law as ark-ec 0.3 twisted_edwards_extended GroupProjective::add_assign writes it (add-2008-hwcd) — bit by bit,
+ * not the product's tabulated window multiples. */
+typedef struct {
+    uint64_t x[4], y[4], t[4], z[4];
+} ed_t;
+static void ed_set_identity(ed_t *p) {
+    memset(p->x, 0, 32);
+    memset(p->t, 0, 32);
+    memcpy(p->y, FR_R1, 32);
+    memcpy(p->z, FR_R1, 32);
+}
+static void ed_add(ed_t *r, const ed_t *p, const ed_t *q, const uint64_t *d_mont) {
+    uint64_t A[4], B[4], C[4], D[4], E[4], F[4], G[4], H[4], s1[4], s2[4];
+    fr_mul(A, p->x, q->x);
+    fr_mul(B, p->y, q->y);
+    fr_mul(C, p->t, q->t);
+    fr_mul(C, C, d_mont);
+    fr_mul(D, p->z, q->z);
+    fr_add(H, B, A); /* H = B - a A, a = -1 */
+    fr_add(s1, p->x, p->y);
+    fr_add(s2, q->x, q->y);
+    fr_mul(E, s1, s2);
+    fr_sub(E, E, A);
+    fr_sub(E, E, B);
+    fr_sub(F, D, C);
+    fr_add(G, D, C);
+    fr_mul(r->x, E, F);
+    fr_mul(r->y, G, H);
+    fr_mul(r->t, E, H);
+    fr_mul(r->z, F, G);
+}
+static ed_t *ed_load_generators(const uint64_t *gens_xy_std, size_t count) {
+    ed_t *g = (ed_t *)malloc(count * sizeof(ed_t));
+    for (size_t i = 0; i < count; i++) {
+        fr_mul(g[i].x, gens_xy_std + 8 * i, FR_R2);
+        fr_mul(g[i].y, gens_xy_std + 8 * i + 4, FR_R2);
+        fr_mul(g[i].t, g[i].x, g[i].y);
+        memcpy(g[i].z, FR_R1, 32);
+    }
+    return g;
+}
+static void pedersen_one(const ed_t *gens, size_t nw, size_t ws, const uint8_t *msg, size_t len, const uint64_t *d_mont,
+                         uint8_t *digest32) {
+    ed_t sum;
+    ed_set_identity(&sum);
+    for (size_t w = 0; w < nw; w++) {
+        ed_t encoded;
+        ed_set_identity(&encoded);
+        int any = 0;
+        for (size_t j = 0; j < ws; j++) {
+            size_t k = w * ws + j;
+            if (k < 8 * len && ((msg[k >> 3] >> (k & 7)) & 1)) {
+                ed_add(&encoded, &encoded, &gens[w * ws + j], d_mont);
+                any = 1;
+            }
+        }
+        if (any) ed_add(&sum, &sum, &encoded, d_mont); /* adding the identity changes nothing: skipped */
+    }
+    uint64_t zi[4], x[4];
+    static const uint64_t one[4] = {1, 0, 0, 0};
+    fr_inverse(zi, sum.z);
+    fr_mul(x, sum.x, zi);
+    fr_mul(x, x, one); /* out of Montgomery form */
+    for (int i = 0; i < 32; i++) digest32[i] = (uint8_t)(x[i / 8] >> (8 * (i % 8)));
+}
+static void ed_d_mont(uint64_t *d) {
+    static const uint64_t d_std[4] = {3021, 0, 0, 0};
+    fr_mul(d, d_std, FR_R2);
+}
+/* gens_xy_std: [nw][ws] affine points, 8 limbs each (x, y in standard form); digests: 32 little-endian bytes each */
+void oracle_pedersen_hash(const uint64_t *gens_xy_std, size_t nw, size_t ws, const uint8_t *inputs, size_t len, size_t count,
+                          uint8_t *digests, int threads) {
+    uint64_t d[4];
+    ed_d_mont(d);
+    ed_t *g = ed_load_generators(gens_xy_std, nw * ws);
+    int nt = threads > 0 ? threads : 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt) if (count >= 64)
+    for (size_t i = 0; i < count; i++) pedersen_one(g, nw, ws, inputs + i * len, len, d, digests + 32 * i);
+    free(g);
+}
+/* nodes: n leaf digests | n / 2 | ... | root, 32 bytes each */
+void oracle_merkle_tree(const uint64_t *leaf_gens, size_t nw_leaf, const uint64_t *inner_gens, size_t nw_inner, size_t ws,
+                        const uint8_t *leaves, size_t leaf_len, size_t n, uint8_t *nodes, int threads) {
+    oracle_pedersen_hash(leaf_gens, nw_leaf, ws, leaves, leaf_len, n, nodes, threads);
+    size_t off = 0;
+    for (size_t cnt = n; cnt > 1; cnt >>= 1) {
+        oracle_pedersen_hash(inner_gens, nw_inner, ws, nodes + 32 * off, 64, cnt >> 1, nodes + 32 * (off + cnt), threads);
+        off += cnt;
+    }
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

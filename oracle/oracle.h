@@ -71,6 +71,15 @@ void oracle_spmv_fr(const uint32_t *rowptr, const uint32_t *col, const uint64_t 
 void oracle_spmv_fr_mt(const uint32_t *rowptr, const uint32_t *col, const uint64_t *val4, const uint64_t *z4,
                        uint64_t *out4, size_t rows, int threads);
 
+/* ---- Pedersen CRH (+ TECompressor) on ed-on-BLS12-377 and the Merkle tree over it: ark-crypto-primitives 0.3 [U], as reached
+ * from src/hash/mod.rs:23-28 and src/merkle_tree/simple_merkle_tree.rs:47-49 (windows: src/merkle_tree/common.rs:11-30).
+ * gens_xy_std: [nw][ws] affine generators, 8 limbs each (x, y, standard form); inputs: count x len bytes; digests /
+ * nodes: 32 little-endian bytes each; nodes = n leaf digests | n / 2 | ... | root. */
+void oracle_pedersen_hash(const uint64_t *gens_xy_std, size_t nw, size_t ws, const uint8_t *inputs, size_t len, size_t count,
+                          uint8_t *digests, int threads);
+void oracle_merkle_tree(const uint64_t *leaf_gens, size_t nw_leaf, const uint64_t *inner_gens, size_t nw_inner, size_t ws,
+                        const uint8_t *leaves, size_t leaf_len, size_t n, uint8_t *nodes, int threads);
+
 /* number of OpenMP threads the library can use on this host */
 int oracle_max_threads(void);
 

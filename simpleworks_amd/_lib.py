@@ -79,6 +79,12 @@ ABI = {
     "swm_r1cs_is_satisfied": (_int, [_vp, ctypes.c_void_p, ctypes.POINTER(_int), ctypes.POINTER(_sz)]),
     "swm_blake2s": (_int, [ctypes.c_void_p, _sz, ctypes.c_void_p]),
     "swm_chacha_block": (_int, [ctypes.c_void_p, ctypes.c_uint64, _int, ctypes.c_void_p]),
+    "swm_pedersen_create": (_int, [_vp, ctypes.c_void_p, _sz, _sz, ctypes.POINTER(_vp)]),
+    "swm_pedersen_destroy": (None, [_vp, _vp]),
+    "swm_pedersen_hash": (_int, [_vp, _vp, ctypes.c_void_p, _sz, _sz, ctypes.c_void_p]),
+    "swm_pedersen_hash_dev": (_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "swm_merkle_tree_build": (_int, [_vp, _vp, _vp, ctypes.c_void_p, _sz, _sz, ctypes.c_void_p]),
+    "swm_merkle_tree_build_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "swm_profile_enable": (_int, [_vp, _int]),
     "swm_profile_reset": (_int, [_vp]),
     "swm_profile_json": (_int, [_vp, ctypes.c_char_p, _sz]),
@@ -343,6 +349,42 @@ class Context:
         out = np.empty_like(a)
         self._check(self.lib.swm_vec_mul_fr(self.h, _p64(a), _p64(b), _p64(out), a.shape[0]), "swm_vec_mul_fr")
         return out
+
+    # ---- Pedersen CRH + Merkle tree (include/swmarlin.h; simpleworks_amd/hash.py is the caller-facing mirror)
+    def pedersen_create(self, generators_xy, num_windows, window_size):
+        """generators_xy: num_windows * window_size affine points, 64 bytes each (x || y, little-endian standard form)."""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(generators_xy), dtype=np.uint8))
+        assert buf.size == 64 * num_windows * window_size
+        h = _vp()
+        self._check(self.lib.swm_pedersen_create(self.h, buf.ctypes.data, num_windows, window_size, ctypes.byref(h)),
+                    "swm_pedersen_create")
+        return h
+
+    def pedersen_destroy(self, handle):
+        if self.h and handle:
+            self.lib.swm_pedersen_destroy(self.h, handle)
+
+    def pedersen_hash(self, handle, inputs):
+        """inputs: uint8 array [count, input_len] -> uint8 [count, 32] digests (x coordinate, little-endian)."""
+        a = np.ascontiguousarray(inputs, dtype=np.uint8)
+        assert a.ndim == 2
+        out = np.empty((a.shape[0], 32), dtype=np.uint8)
+        self._check(self.lib.swm_pedersen_hash(self.h, handle, a.ctypes.data, a.shape[1], a.shape[0], out.ctypes.data),
+                    "swm_pedersen_hash")
+        return out
+
+    def merkle_tree_build(self, leaf_handle, two_to_one_handle, leaves):
+        """leaves: uint8 [n, leaf_len] -> uint8 [2 n - 1, 32]: n leaf digests | n / 2 | ... | root."""
+        a = np.ascontiguousarray(leaves, dtype=np.uint8)
+        assert a.ndim == 2
+        out = np.empty((2 * a.shape[0] - 1, 32), dtype=np.uint8)
+        self._check(self.lib.swm_merkle_tree_build(self.h, leaf_handle, two_to_one_handle, a.ctypes.data, a.shape[1], a.shape[0],
+                                                   out.ctypes.data), "swm_merkle_tree_build")
+        return out
+
+    def merkle_tree_build_dev(self, leaf_handle, two_to_one_handle, d_leaves, leaf_len, n_leaves, d_nodes):
+        self._check(self.lib.swm_merkle_tree_build_dev(self.h, leaf_handle, two_to_one_handle, d_leaves.ptr, leaf_len, n_leaves,
+                                                       d_nodes.ptr), "swm_merkle_tree_build_dev")
 
     # ---- measurement
     def profile_enable(self, on=True):

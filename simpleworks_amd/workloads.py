@@ -118,8 +118,9 @@ def synthetic_r1cs(n, a, b):
 #
 # The reference synthesises that R1CS with ark-r1cs-std / ark-crypto-primitives gadgets, which are not available here
 # (SURVEY.md §8d), so the constraint-by-constraint layout below is OURS: same statement, same I/O convention, same hash
-# (window sizes, bit order, curve), our own gadget for the conditional point addition.  The Pedersen generators are
-# derived from a seeded PRNG instead of ark_std::test_rng (they are circuit constants; [U] either way).  What matters
+# (window sizes, bit order, curve), our own gadget for the conditional point addition.  The Pedersen generators:
+# MerkleParams.setup(rng) samples them the way CRH::setup does from the caller's generator (SimpleMerkleTree's default);
+# MerkleParams() derives them from a fixed seed (the committed fixtures) — circuit constants either way.  What matters
 # to the hot path is the SHAPE this gives the prover, which the one-term-per-row synthetic circuit lacks:
 #   * multi-term rows (1-3 terms; bit-packing rows with 257 terms), booleanity rows b (1 - b) = 0,
 #   * rows with empty A and B, `0 * 0 = a - b` — the shape simpleworks' own UInt gadgets emit
@@ -244,11 +245,32 @@ class MerkleParams:
     configuration (src/merkle_tree/common.rs:16-30); smaller values give toy instances for the pure-Python prover
     (only the low digest_bits bits of a child digest enter its parent's hash; the rest is carried in one witness)."""
 
-    def __init__(self, digest_bits=256, leaf_windows=144, inner_windows=128, window_size=4, seed=0x5157_4D41_524C_494E):
+    def __init__(self, digest_bits=256, leaf_windows=144, inner_windows=128, window_size=4, seed=0x5157_4D41_524C_494E,
+                 generators=None):
         assert 2 * digest_bits <= inner_windows * window_size and 8 <= leaf_windows * window_size
         self.digest_bits = digest_bits
-        self.leaf_gens = pedersen_generators(leaf_windows, window_size, seed)
-        self.inner_gens = pedersen_generators(inner_windows, window_size, seed ^ 0xA5A5_A5A5_5A5A_5A5A)
+        if generators is not None:
+            self.leaf_gens, self.inner_gens = generators
+        else:
+            self.leaf_gens = pedersen_generators(leaf_windows, window_size, seed)
+            self.inner_gens = pedersen_generators(inner_windows, window_size, seed ^ 0xA5A5_A5A5_5A5A_5A5A)
+        self._crh = None  # (leaf, two-to-one) PedersenCRH handles of the GPU tree builder, created on first use
+
+    @classmethod
+    def setup(cls, rng):
+        """The reference's order of sampling (src/merkle_tree/simple_merkle_tree.rs:43-45): <LeafHash as CRH>::setup(&mut rng),
+        then <TwoToOneHash as TwoToOneCRH>::setup(&mut rng), from the caller's generator."""
+        from .hash import pedersen_setup, LEAF_WINDOWS, TWO_TO_ONE_WINDOWS, WINDOW_SIZE
+        leaf = pedersen_setup(rng, LEAF_WINDOWS, WINDOW_SIZE)
+        inner = pedersen_setup(rng, TWO_TO_ONE_WINDOWS, WINDOW_SIZE)
+        return cls(generators=(leaf, inner))
+
+    def crh(self, ctx=None):
+        """The two hash parameter sets resident on the GPU (simpleworks_amd.hash.PedersenCRH)."""
+        if self._crh is None:
+            from .hash import PedersenCRH
+            self._crh = (PedersenCRH(self.leaf_gens, ctx), PedersenCRH(self.inner_gens, ctx))
+        return self._crh
 
     def leaf_hash(self, leaf_u8):
         return pedersen_hash_bits(_bits_le(leaf_u8, 8), self.leaf_gens)
@@ -263,10 +285,16 @@ class MerkleParams:
             cur = self.inner_hash(s, cur) if (leaf_index >> lvl) & 1 else self.inner_hash(cur, s)
         return cur
 
-    def build_tree(self, leaves_u8):
-        """All levels of the tree over len(leaves) = 2^h leaves, bottom up (native model of MerkleTree::new,
-        src/merkle_tree/simple_merkle_tree.rs:47-49); returns the list of levels, levels[-1][0] is the root."""
+    def build_tree(self, leaves_u8, ctx=None):
+        """All levels of the tree over len(leaves) = 2^h leaves, bottom up (MerkleTree::new,
+        src/merkle_tree/simple_merkle_tree.rs:47-49); returns the list of levels, levels[-1][0] is the root.
+        The reference's configuration (256-bit digests) is built on the GPU (swm_merkle_tree_build); the truncated-digest toy
+        parameter sets of the pure-Python prover fixtures, which are not the reference's hash, stay on the loop below."""
         assert len(leaves_u8) & (len(leaves_u8) - 1) == 0
+        if self.digest_bits == 256:
+            from .hash import MerkleTree
+            leaf, inner = self.crh(ctx)
+            return MerkleTree.new(leaf, inner, [int(v) for v in leaves_u8]).int_levels()
         levels = [[self.leaf_hash(v) for v in leaves_u8]]
         while len(levels[-1]) > 1:
             prev = levels[-1]
@@ -464,7 +492,7 @@ class SimpleMerkleTree:
     and universal_setup(100_000, 25_000, 300_000) in new(), keys from a DUMMY circuit over a blank tree of the same height
     (the circuit's shape depends on the height only), a fresh test_rng per prove / verify, proofs as serialised bytes,
     verify(proof_bytes, leaf_u8) rebuilding the public input [root, 8 bits LSB-first].  Hash parameters: MerkleParams (the
-    reference samples them from the same rng; here they are derived from a seed — circuit constants either way)."""
+    reference samples them from the same rng, after universal_setup: so does this, MerkleParams.setup)."""
 
     def __init__(self, leaves_u8, params=None, srs_sizes=(100_000, 25_000, 300_000), gadget_byte_ops=0, ctx=None):
         from . import marlin as M
@@ -472,9 +500,9 @@ class SimpleMerkleTree:
         self._M, self._S = M, S
         rng = M.generate_rand()                                                  # ark_std::test_rng()
         universal_srs = M.MarlinInst.universal_setup(*srs_sizes, rng, ctx)       # simple_merkle_tree.rs:39
-        self.params = params or MerkleParams()
+        self.params = params or MerkleParams.setup(rng)                          # LeafHash / TwoToOneHash setup(&mut rng), :43-45
         self.leaves = list(leaves_u8)
-        self.levels = self.params.build_tree(self.leaves)                        # MerkleTree::new, :47-49
+        self.levels = self.params.build_tree(self.leaves, ctx)                   # MerkleTree::new, :47-49 (on the GPU)
         height = merkle_tree_height(len(self.leaves))
         blank_path = [0] * (height - 1)                                          # MerkleTree::blank(..).generate_proof(0)
         blank_root = self.params.root_from_path(0, 0, blank_path)

@@ -44,6 +44,8 @@ def load(path=None):
         "oracle_ntt_fr": [_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int],
         "oracle_spmv_fr": [_u32p, _u32p, _u64p, _u64p, _u64p, sz],
         "oracle_spmv_fr_mt": [_u32p, _u32p, _u64p, _u64p, _u64p, sz, ctypes.c_int],
+        "oracle_pedersen_hash": [_u64p, sz, sz, ctypes.c_void_p, sz, sz, ctypes.c_void_p, ctypes.c_int],
+        "oracle_merkle_tree": [_u64p, sz, _u64p, sz, sz, ctypes.c_void_p, sz, sz, ctypes.c_void_p, ctypes.c_int],
     }.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
@@ -199,3 +201,28 @@ class Oracle:
             tk = tk2
         pw = self.fr_from_mont(pwm)
         return self.fixed_base_mul(gen_mont12, pw)
+
+
+# ---- Pedersen CRH + Merkle tree (oracle.c; generators as [[(x, y)]] integers in standard form)
+def _gens_limbs(gens):
+    flat = [c for row in gens for pt in row for c in pt]
+    return np.array([[(v >> (64 * k)) & M64 for k in range(4)] for v in flat], dtype=np.uint64).reshape(-1)
+
+
+def pedersen_hash(lib, gens, inputs, threads=1):
+    """inputs: uint8 [count, len] -> uint8 [count, 32]"""
+    a = np.ascontiguousarray(inputs, dtype=np.uint8)
+    g = _gens_limbs(gens)
+    out = np.empty((a.shape[0], 32), dtype=np.uint8)
+    lib.oracle_pedersen_hash(p64(g), len(gens), len(gens[0]), a.ctypes.data, a.shape[1], a.shape[0], out.ctypes.data, threads)
+    return out
+
+
+def merkle_tree(lib, leaf_gens, inner_gens, leaves, threads=1):
+    """leaves: uint8 [n, leaf_len] -> uint8 [2 n - 1, 32]"""
+    a = np.ascontiguousarray(leaves, dtype=np.uint8)
+    gl, gi = _gens_limbs(leaf_gens), _gens_limbs(inner_gens)
+    out = np.empty((2 * a.shape[0] - 1, 32), dtype=np.uint8)
+    lib.oracle_merkle_tree(p64(gl), len(leaf_gens), p64(gi), len(inner_gens), len(leaf_gens[0]), a.ctypes.data, a.shape[1],
+                           a.shape[0], out.ctypes.data, threads)
+    return out

@@ -240,3 +240,18 @@ def test_rng_fill_bytes_adopted_state_and_native_callback():
     assert [hex(h.next_u64()) for _ in range(4)] == g["test_rng_u64"][:4] and caller.word_pos() == 8
     with pytest.raises(M.MarlinError):
         h.word_pos()  # a callback generator has no position of its own
+
+
+def test_pedersen_setup_of_the_product_matches_the_model():
+    """simpleworks_amd.hash.pedersen_setup (host side of CRH::setup: the library's ChaCha12 stream, Fr::rand, the sign bit of
+    next_u32, Tonelli-Shanks, cofactor clearing) draws the generators the Python model draws — same bytes as the fixture."""
+    import hashlib
+    from simpleworks_amd import hash as H, marlin as M
+    g = golden("pedersen.json")
+    rng = M.generate_rand()
+    leaf = H.pedersen_setup(rng, H.LEAF_WINDOWS)
+    inner = H.pedersen_setup(rng, H.TWO_TO_ONE_WINDOWS)
+    raw = lambda gens: b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") for row in gens for x, y in row)
+    assert hashlib.sha256(raw(leaf)).hexdigest() == g["leaf_generators_sha256"]
+    assert hashlib.sha256(raw(inner)).hexdigest() == g["two_to_one_generators_sha256"]
+    assert [hex(c) for c in inner[127][3]] == g["two_to_one_generator_127_3"]

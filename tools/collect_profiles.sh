@@ -28,4 +28,7 @@ python3 tools/ubench/ntt_one.py 22 10 > $out/ntt_one.json 2> $out/ntt_one.err
 python3 tools/ubench/spmv_one.py 20 10 > $out/spmv_one.json 2> $out/spmv_one.err
 python3 tools/ubench/ntt_time.py > $out/ntt_time.log 2>&1
 python3 tools/small_proofs.py 10 12 14 16 18 > $out/small_proofs.log 2>&1
+# the Pedersen Merkle tree of config #5 (2^18 leaves) beside the CPU oracle on 2^14 leaves, and its kernel stats
+python3 tools/ubench/merkle_build.py 18 5 14 > $out/merkle_build.json 2> $out/merkle_build.err
+rocprofv3 --kernel-trace --stats -d $out/prof_merkle_build -o run --output-format csv -- python3 tools/ubench/merkle_build.py 18 3 0 > $out/prof_merkle_build.log 2>&1
 ls -R $out | head -40
