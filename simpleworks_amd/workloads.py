@@ -447,14 +447,17 @@ def build_merkle_membership(cs, params, leaf_u8, leaf_index, siblings, gadget_by
 
 
 def merkle_membership_circuit(height=19, leaf_u8=0xA7, leaf_index=None, seed=7, gadget_byte_ops=2400, params=None,
-                              root=None):
+                              root=None, siblings=None):
     """BASELINE config #5 stand-in as a ConstraintSystem.  height = merkle_tree_height(number of leaves)
-    (src/merkle_tree/simple_merkle_tree.rs:155-163): height - 1 two-to-one hashes; 19 for 2^18 leaves.  The siblings
-    are random digests (the other 2^18 - 1 leaves are not needed to prove one path).  Returns (cs, public_inputs, params)."""
+    (src/merkle_tree/simple_merkle_tree.rs:155-163): height - 1 two-to-one hashes; 19 for 2^18 leaves.  `siblings`: the
+    authentication path of a real tree (MerkleParams.build_tree + path_of; bench.py --circuit merkle does that); without it
+    the siblings are random digests (the other leaves are not needed to prove one path).  Returns (cs, public_inputs, params)."""
     params = params or MerkleParams()
     g = _SplitMix(seed)
     levels = height - 1
-    siblings = [g.fr() for _ in range(levels)]
+    if siblings is None:
+        siblings = [g.fr() for _ in range(levels)]
+    assert len(siblings) == levels
     if leaf_index is None:
         leaf_index = g.next_u64() % (1 << levels)
     cs = ConstraintSystem()
