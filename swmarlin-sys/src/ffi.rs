@@ -9,6 +9,7 @@ use std::os::raw::{c_char, c_int, c_uint, c_void};
 #[repr(C)] pub struct swm_pk { _p: [u8; 0] }
 #[repr(C)] pub struct swm_vk { _p: [u8; 0] }
 #[repr(C)] pub struct swm_bases { _p: [u8; 0] }
+#[repr(C)] pub struct swm_pedersen { _p: [u8; 0] }
 
 pub const SWM_OK: c_int = 0;
 pub const SWM_ERR_UNSATISFIED: c_int = -5;
@@ -91,4 +92,13 @@ extern "C" {
     pub fn swm_spmv_fr(ctx: *mut swm_ctx, rowptr: *const u32, col: *const u32, val: *const u64, z: *const u64,
                        z_len: usize, out: *mut u64, rows: usize, nnz: usize) -> c_int;
     pub fn swm_batch_inverse_fr(ctx: *mut swm_ctx, data: *mut u64, n: usize) -> c_int;
+
+    // the native Pedersen hash and MerkleTree::new of src/merkle_tree/simple_merkle_tree.rs:47-49, src/hash/mod.rs:23-28
+    pub fn swm_pedersen_create(ctx: *mut swm_ctx, generators_xy: *const u8, num_windows: usize, window_size: usize,
+                               out: *mut *mut swm_pedersen) -> c_int;
+    pub fn swm_pedersen_destroy(ctx: *mut swm_ctx, params: *mut swm_pedersen);
+    pub fn swm_pedersen_hash(ctx: *mut swm_ctx, params: *const swm_pedersen, inputs: *const u8, input_len: usize, count: usize,
+                             digests: *mut u8) -> c_int;
+    pub fn swm_merkle_tree_build(ctx: *mut swm_ctx, leaf_params: *const swm_pedersen, two_to_one_params: *const swm_pedersen,
+                                 leaves: *const u8, leaf_len: usize, n_leaves: usize, nodes: *mut u8) -> c_int;
 }
