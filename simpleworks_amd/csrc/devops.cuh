@@ -18,6 +18,7 @@
 namespace swm {
 
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset);
+int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset, const void* first_src, size_t src_len);
 // one transform of 2^log_n elements over the ranks of the context's sharding (ntt.hip): in place on the rank's n / G
 // elements, CYCLIC -> BLOCKS layout (blocks_in = 0) or BLOCKS -> CYCLIC (blocks_in = 1), one all-to-all
 int ntt_sharded_run(swm_ctx* ctx, void* d_local, unsigned log_n, int inverse, int blocks_in);
@@ -145,6 +146,14 @@ inline PowTable root_pow_table(swm_ctx* ctx, unsigned log_n, bool inverse = fals
 inline void dv_ntt(swm_ctx* ctx, DVec& v, unsigned log_n, bool inverse, bool coset = false) {
     if (v.n != ((size_t)1 << log_n)) throw MarlinError(SWM_ERR_INTERNAL, "dv_ntt: size mismatch");
     rc_check(ctx, ntt_run(ctx, v.p, log_n, inverse ? 1 : 0, coset ? 1 : 0));
+}
+
+// the transform of src[0 .. len) zero-extended to 2^log_n elements, out of place (no padded copy in front: the first pass
+// takes the missing inputs as zero); src is left as it was
+inline DVec dv_ntt_from(swm_ctx* ctx, const Fr* src, size_t len, unsigned log_n, bool inverse, bool coset = false) {
+    DVec v(ctx, (size_t)1 << log_n);
+    rc_check(ctx, ntt_run_from(ctx, v.p, log_n, inverse ? 1 : 0, coset ? 1 : 0, src, len));
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------ suffix recurrence

@@ -762,7 +762,7 @@ __device__ __forceinline__ uint64_t reindex_by_subdomain(uint64_t H, uint64_t X,
 }
 
 void arithmetize(swm_ctx* ctx, swm_pk& pk, const HostCsr& m, MatrixArith& ar) {
-    const uint64_t K = pk.K, H = pk.H, X = pk.X, Bsz = pk.B;
+    const uint64_t K = pk.K, H = pk.H, X = pk.X;
     std::vector<uint32_t> rows(m.nnz());
     for (size_t r = 0; r < m.rows(); r++)
         for (uint32_t k = m.rowptr[r]; k < m.rowptr[r + 1]; k++) rows[k] = (uint32_t)r;
@@ -800,18 +800,14 @@ void arithmetize(swm_ctx* ctx, swm_pk& pk, const HostCsr& m, MatrixArith& ar) {
         prc[k] = fp_mul(rv, cv);
     });
     auto interp = [&](const DVec& evals) {
-        DVec c = dv_copy_padded(ctx, evals.p, K, K);
-        dv_ntt(ctx, c, pk.logK, true);
-        return c;
+        return dv_ntt_from(ctx, evals.p, K, pk.logK, true);
     };
     ar.row = interp(ar.row_K);
     ar.col = interp(ar.col_K);
     ar.val = interp(ar.val_K);
     ar.row_col = interp(rc_K);
     auto on_b = [&](const DVec& coeffs) {
-        DVec e = dv_copy_padded(ctx, coeffs.p, K, Bsz);
-        dv_ntt(ctx, e, pk.logB, false);
-        return e;
+        return dv_ntt_from(ctx, coeffs.p, K, pk.logB, false);
     };
     ar.row_B = on_b(ar.row);
     ar.col_B = on_b(ar.col);
@@ -1095,8 +1091,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     DVec x_poly(ctx, X);
     x_poly.upload(pr.inst.data(), X);
     dv_ntt(ctx, x_poly, pk.logX, true);
-    DVec x_evals = dv_copy_padded(ctx, x_poly.p, X, H);
-    dv_ntt(ctx, x_evals, pk.logH, false);
+    DVec x_evals = dv_ntt_from(ctx, x_poly.p, X, pk.logH, false);
     // w evaluations on H: 0 on the X-subgroup positions, w_extended[k - k/ratio - 1] - x_evals[k] elsewhere
     const uint64_t ratio = H / X;
     const size_t nwit = pr.nwit;
@@ -1116,9 +1111,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         });
     }
     {
-        DVec tmp = dv_copy_padded(ctx, w_poly.p, H, H);
-        dv_ntt(ctx, tmp, pk.logH, true);
-        hip_check(ctx, hipMemcpyAsync(w_poly.p, tmp.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
+        rc_check(ctx, ntt_run(ctx, w_poly.p, pk.logH, 1, 0));  // in place on the first H of its H + 1 slots
     }
     auto add_rho_vh = [&](Fr* poly, const Fr& rho) {  // poly += rho * (X^H - 1); poly has H + 1 slots, slot H = 0
         ew(ctx, "add_rho_vh", 1, [=] __device__(size_t) {
@@ -1163,11 +1156,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         sharded_interpolate_and_commit(za_loc, rho_a, za_poly, &j1[1]);
         sharded_interpolate_and_commit(zb_loc, rho_b, zb_poly, &j1[2]);
     } else {
-        dv_ntt(ctx, za_evals, pk.logH, true);
-        hip_check(ctx, hipMemcpyAsync(za_poly.p, za_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
+        rc_check(ctx, ntt_run_from(ctx, za_poly.p, pk.logH, 1, 0, za_evals.p, H));  // evaluations -> the first H of H + 1 slots
         add_rho_vh(za_poly.p, rho_a);
-        dv_ntt(ctx, zb_evals, pk.logH, true);
-        hip_check(ctx, hipMemcpyAsync(zb_poly.p, zb_evals.p, H * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
+        rc_check(ctx, ntt_run_from(ctx, zb_poly.p, pk.logH, 1, 0, zb_evals.p, H));
         add_rho_vh(zb_poly.p, rho_b);
     }
     P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
@@ -1182,9 +1173,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
-        DVec e = dv_copy_padded(ctx, coeffs, n, M);
-        dv_ntt(ctx, e, logM, false);
-        return e;
+        return dv_ntt_from(ctx, coeffs, n, logM, false);
     };
     DVec e_za = on_mul_domain(za_poly.p, H + 1);
     DVec e_zb = on_mul_domain(zb_poly.p, H + 1);
@@ -1287,8 +1276,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     DVec q1(ctx, M);
     {
         if (!ra_closed_form) {
-            DVec ra_poly = dv_copy_padded(ctx, r_alpha_evals.p, H, H);
-            dv_ntt(ctx, ra_poly, pk.logH, true);
+            DVec ra_poly = dv_ntt_from(ctx, r_alpha_evals.p, H, pk.logH, true);
             e_ra = on_mul_domain(ra_poly.p, H);
         }
         DVec e_t = on_mul_domain(t_poly.p, H);
@@ -1374,8 +1362,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // h_2 = (a - b f) / v_K via evaluations on the 4K domain
     DVec h2(ctx, 3 * K);
     {
-        DVec e_f = dv_copy_padded(ctx, f.p, K, Bsz);
-        dv_ntt(ctx, e_f, pk.logB, false);
+        DVec e_f = dv_ntt_from(ctx, f.p, K, pk.logB, false);
         DVec ab(ctx, Bsz);
         Fr* out = ab.p;
         const Fr* pf = e_f.p;

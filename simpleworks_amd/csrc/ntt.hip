@@ -35,6 +35,7 @@ struct NttPassArgs {
     const Fr* tw_hi;      // w_n^(1024 i)
     const Fr* cs_lo;      // g^i (or g^-i)
     const Fr* cs_hi;
+    uint64_t src_len;     // elements of src that exist: the rest of the 2^log_n inputs are zero (first pass of a zero-extended transform)
     const Fr* pass_tw;    // lazy kernel, passes >= 2: the inter-pass twiddles of THIS pass as a table, [t * Ns + k] = w_n^((k t) << shift)
     int coset_in;         // multiply input i by g^i while loading (first pass of a forward coset transform)
     int scale_out;        // multiply output by n_inv (last pass of an inverse transform)
@@ -68,7 +69,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             unsigned e = e0 + threadIdx.x + u * NTT_THREADS;
-            if (e < R * J) xs[u] = a.src[j0 + e % J + (uint64_t)(e / J) * stride];
+            if (e < R * J) {
+                const uint64_t at = j0 + e % J + (uint64_t)(e / J) * stride;
+                xs[u] = at < a.src_len ? a.src[at] : fp_zero<Fr>();
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -217,7 +221,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_lazy(NttLazyArgs args
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             unsigned e = e0 + threadIdx.x + u * NTT_THREADS;
-            if (e < R * J) xs[u] = a.src[j0 + e % J + (uint64_t)(e / J) * stride];
+            if (e < R * J) {
+                const uint64_t at = j0 + e % J + (uint64_t)(e / J) * stride;
+                xs[u] = at < a.src_len ? a.src[at] : fp_zero<Fr>();
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -462,9 +469,17 @@ static LazyPlan lazy_plan(unsigned log_r, unsigned b_in) {
 }
 
 // In-place (from the caller's view) transform of 2^log_n Montgomery Fr elements resident in HBM.
+int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset, const void* first_src, size_t src_len);
 int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) {
+    return ntt_run_from(ctx, d_data, log_n, inverse, coset, nullptr, 0);
+}
+// The transform of first_src[0 .. src_len) zero-extended to 2^log_n elements, written to d_data (which need not be
+// initialised; first_src is left as it was and must not overlap d_data).  The first pass reads first_src and takes the
+// missing inputs as zero: no padded copy in front of the transform.  first_src == nullptr: in place on d_data.
+int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset, const void* first_src, size_t src_len) {
     if (log_n > 30) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: log_n > 30 unsupported");
     const uint64_t n = 1ull << log_n;
+    if (first_src && src_len > n) src_len = n;
     ctx->stat_ntt_calls++;
     ctx->log_call('n', log_n);
     ctx->stat_ntt_elems += n;
@@ -497,8 +512,8 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
     // data -> tmp -> tmp2 -> ... -> data through a second scratch buffer (one more n-element buffer in HBM instead of a
     // full device-to-device copy in front of every such transform); a single pass (n <= 2^10) copies, it is tiny.
     if (npass % 2 == 1 && npass >= 3) SWM_TRY(scratch(ctx, "ntt.tmp2", n * sizeof(Fr), (void**)&tmp2));
-    const Fr* src = data;
-    if (npass == 1) {
+    const Fr* src = first_src ? reinterpret_cast<const Fr*>(first_src) : data;
+    if (npass == 1 && !first_src) {
         SWM_HIP(ctx, hipMemcpyAsync(tmp, data, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
         src = tmp;
     }
@@ -509,6 +524,7 @@ int ntt_run(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int coset) 
         if (p == npass - 1) a.dst = data;
         else if (tmp2) a.dst = (p % 2 == 0) ? tmp : tmp2;
         else a.dst = (src == tmp) ? data : tmp;
+        a.src_len = (p == 0 && first_src) ? (uint64_t)src_len : n;
         a.log_n = log_n;
         a.log_r = radices[p];
         a.log_ns = log_ns;
