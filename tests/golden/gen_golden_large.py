@@ -200,10 +200,54 @@ def case_merkle_h5():
     return out
 
 
+SIMPLE_MERKLE_TREE = dict(leaves=[3, 200, 77, 9, 0, 255, 16, 42], index=5, srs=[100_000, 25_000, 300_000])
+
+
+def case_simple_merkle_tree():
+    """SimpleMerkleTree::new followed by ::prove, call for call (src/merkle_tree/simple_merkle_tree.rs:35-127), in the model:
+    ONE test_rng for universal_setup(100_000, 25_000, 300_000), LeafHash::setup and TwoToOneHash::setup (:38-45); the tree
+    over the leaves (:47-49); keys indexed from the DUMMY circuit over a blank path (:59-83); the proof of leaf `index` with
+    a FRESH test_rng (:116-119).  The circuit description is host logic shared with the product (as in case_merkle_h5)."""
+    from pyref import pedersen as PP
+    from simpleworks_amd import workloads as W
+    kw = SIMPLE_MERKLE_TREE
+    t0 = time.time()
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(*kw["srs"], rng)
+    leaf = PP.pedersen_setup(rng, PP.LEAF_WINDOWS)
+    inner = PP.pedersen_setup(rng, PP.TWO_TO_ONE_WINDOWS)
+    params = W.MerkleParams(generators=(leaf, inner))
+    levels = PP.merkle_tree(leaf, inner, [bytes([v]) for v in kw["leaves"]])
+    root, path = levels[-1][0], PP.merkle_path(levels, kw["index"])
+    height = W.merkle_tree_height(len(kw["leaves"]))
+    blank_path = [0] * (height - 1)
+    blank_root = params.root_from_path(0, 0, blank_path)
+    dummy = M.ConstraintSystem()
+    W.build_merkle_membership(dummy, params, 0, 0, blank_path, 0, blank_root)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, dummy)
+    t1 = time.time()
+    real = M.ConstraintSystem()
+    public = W.build_merkle_membership(real, params, kw["leaves"][kw["index"]], kw["index"], path, 0, root)
+    assert real.is_satisfied() and public[0] == root
+    proof = M.prove(pk, real, M.generate_rand(), {})
+    pbytes, vbytes = M.serialize_proof(proof), M.serialize_verifying_key(vk)
+    assert M.verify_proof(vk, public, M.deserialize_proof(pbytes), M.generate_rand())
+    assert not M.verify_proof(vk, [root] + [(kw["leaves"][0] >> i) & 1 for i in range(8)], M.deserialize_proof(pbytes), M.generate_rand())
+    print(" simple merkle tree: setup + index %.0fs, prove + verify %.0fs; %d constraints" %
+          (t1 - t0, time.time() - t1, vk["num_constraints"]), flush=True)
+    raw = lambda gens: b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") for row in gens for x, y in row)
+    return dict(kw, max_degree=srs.max_degree, root=hex(root), path=[hex(v) for v in path],
+                leaf_generators_sha256=hashlib.sha256(raw(leaf)).hexdigest(),
+                two_to_one_generators_sha256=hashlib.sha256(raw(inner)).hexdigest(),
+                num_constraints=vk["num_constraints"], num_variables=vk["num_variables"], num_non_zero=vk["num_non_zero"],
+                proof=pbytes.hex(), vk_sha256=hashlib.sha256(vbytes).hexdigest(), vk=vbytes.hex())
+
+
 CASES = {"synthetic_2p12": lambda: case_synthetic(12), "synthetic_2p16": lambda: case_synthetic(16),
          "merkle_h5": case_merkle_h5}
 # not part of the default run (tens of minutes and several GB of Python integers): python gen_golden_large.py synthetic_2p18
-EXTRA_CASES = {"synthetic_2p18": lambda: case_synthetic(18), "synthetic_2p20": lambda: case_synthetic(20)}
+EXTRA_CASES = {"synthetic_2p18": lambda: case_synthetic(18), "synthetic_2p20": lambda: case_synthetic(20),
+               "simple_merkle_tree": case_simple_merkle_tree}
 
 if __name__ == "__main__":
     install()

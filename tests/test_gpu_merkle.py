@@ -235,3 +235,25 @@ def test_marlin_inst_with_a_synthesizer_matches_golden_bytes(M, S):
     assert S.serialize_proof(M.MarlinInst.prove_from_constraint_system(pk2, cs, rng)).hex() == case["proof"]
     for h in (index_pk, pk2, universal_srs, srs2):
         h.free()
+
+
+def test_simple_merkle_tree_golden_bytes(M, S, W):
+    """SimpleMerkleTree::new + ::prove with the reference's own sizes and order of draws — ONE test_rng for
+    universal_setup(100_000, 25_000, 300_000), LeafHash::setup, TwoToOneHash::setup; the tree built natively; keys from the dummy
+    circuit; a fresh test_rng for the proof (src/merkle_tree/simple_merkle_tree.rs:35-127) — against the same sequence run
+    through the Python model (tests/golden/gen_golden_large.py simple_merkle_tree): same generators, same root and path (GPU
+    tree vs the model's), same verifying-key bytes, same proof bytes."""
+    import hashlib
+    case = golden("marlin_large.json")["simple_merkle_tree"]
+    tree = W.SimpleMerkleTree(case["leaves"], srs_sizes=tuple(case["srs"]))
+    raw = lambda gens: b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") for row in gens for x, y in row)
+    assert hashlib.sha256(raw(tree.params.leaf_gens)).hexdigest() == case["leaf_generators_sha256"]
+    assert hashlib.sha256(raw(tree.params.inner_gens)).hexdigest() == case["two_to_one_generators_sha256"]
+    assert tree.root() == h2i(case["root"])
+    idx, path = tree.get_merkle_path(case["index"])
+    assert path == [h2i(v) for v in case["path"]]
+    assert S.serialize_verifying_key(tree.verifying_key).hex() == case["vk"]
+    proof = tree.prove(case["leaves"][case["index"]], (idx, path))
+    assert proof.hex() == case["proof"]
+    assert tree.verify(proof, case["leaves"][case["index"]]) and not tree.verify(proof, case["leaves"][0])
+    tree.free()
