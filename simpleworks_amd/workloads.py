@@ -21,6 +21,34 @@ def manual_constraints_circuit(a, b):
     return cs
 
 
+def build_test_circuit(cs, a, b):
+    """examples/test-circuit.rs:13-26 (BASELINE configs[0]): two PRIVATE u8 values as UInt8::new_witness — eight booleans each,
+    least significant first, every one with its booleanity row (1 - x) x = 0 — and a.enforce_equal(&b) bit by bit,
+    (a_i - b_i) 1 = 0.  24 constraints, 16 witnesses, no public input (the reference verifies with `&[]`, :80).  `cs` is any
+    builder with ark-relations' vocabulary."""
+    one = cs.one()
+    bits = []
+    for v in (a, b):
+        row = []
+        for i in range(8):
+            x = cs.new_witness_variable((v >> i) & 1)
+            cs.enforce_constraint([(1, one), (R_MODULUS - 1, x)], [(1, x)], [])
+            row.append(x)
+        bits.append(row)
+    for xa, xb in zip(*bits):
+        cs.enforce_constraint([(1, xa), (R_MODULUS - 1, xb)], [(1, one)], [])
+    return []
+
+
+def test_circuit(a, b):
+    cs = ConstraintSystem()
+    build_test_circuit(cs, a, b)
+    return cs
+
+
+test_circuit.__test__ = False  # a circuit constructor, not a pytest case
+
+
 def synthetic_circuit(n, a, b):
     """Same circuit through the ConstraintSystem builder (small n)."""
     assert n >= 8 and n & (n - 1) == 0

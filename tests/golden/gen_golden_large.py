@@ -200,6 +200,19 @@ def case_merkle_h5():
     return out
 
 
+def case_test_circuit():
+    """examples/test-circuit.rs:72-81 (BASELINE configs[0]): universal_setup(100, 25, 300), index, prove, verify(&[]) with ONE
+    test_rng; the circuit description is host logic shared with the product (workloads.build_test_circuit)."""
+    from simpleworks_amd import workloads as W
+    cs = M.ConstraintSystem()
+    W.build_test_circuit(cs, 1, 1)
+    assert cs.is_satisfied() and cs.num_constraints == 24 and len(cs.instance) == 1
+    bad = M.ConstraintSystem()
+    W.build_test_circuit(bad, 1, 2)
+    assert not bad.is_satisfied()          # :52-61 different_values_should_fail
+    return run_case(cs, (100, 25, 300), [], "test-circuit")
+
+
 SIMPLE_MERKLE_TREE = dict(leaves=[3, 200, 77, 9, 0, 255, 16, 42], index=5, srs=[100_000, 25_000, 300_000])
 
 
@@ -247,7 +260,7 @@ CASES = {"synthetic_2p12": lambda: case_synthetic(12), "synthetic_2p16": lambda:
          "merkle_h5": case_merkle_h5}
 # not part of the default run (tens of minutes and several GB of Python integers): python gen_golden_large.py synthetic_2p18
 EXTRA_CASES = {"synthetic_2p18": lambda: case_synthetic(18), "synthetic_2p20": lambda: case_synthetic(20),
-               "simple_merkle_tree": case_simple_merkle_tree}
+               "simple_merkle_tree": case_simple_merkle_tree, "test_circuit": case_test_circuit}
 
 if __name__ == "__main__":
     install()

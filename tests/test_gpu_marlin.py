@@ -767,3 +767,33 @@ def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
         assert vk_hex == case["vk"]
         assert proof_hex == case["proof"]
         assert exchanges >= 4 + 4   # per-round partial sums + (all-to-all, all-gather) for z_A and for z_B
+
+
+def test_reference_test_circuit_example(M, S, W):
+    """BASELINE configs[0], examples/test-circuit.rs: the UInt8 equality circuit (two private bytes, 24 constraints, NO public
+    input) through MarlinInst::{universal_setup(100, 25, 300), index, prove, verify(&[])} with one test_rng (:72-81) — the
+    model's key and proof bytes; `same_values_should_pass` / `different_values_should_fail` (:35-61); and the test the
+    reference keeps commented out (:83-96, a = 1, b = 2): here proving an unsatisfied circuit is an error, not a panic."""
+    case = golden("marlin_large.json")["test_circuit"]
+
+    class TestCircuit:
+        def __init__(self, a, b):
+            self.a, self.b = a, b
+
+        def generate_constraints(self, cs):
+            W.build_test_circuit(cs, self.a, self.b)
+
+    assert W.test_circuit(1, 1).pack().is_satisfied() and not W.test_circuit(1, 2).pack().is_satisfied()
+    rng = M.generate_rand()
+    srs = M.MarlinInst.universal_setup(100, 25, 300, rng)
+    assert srs.max_degree == case["max_degree"]
+    pk, vk = M.MarlinInst.index(srs, TestCircuit(1, 1))
+    assert S.serialize_verifying_key(vk).hex() == case["vk"]
+    proof = M.MarlinInst.prove(pk, TestCircuit(1, 1), rng)
+    assert S.serialize_proof(proof).hex() == case["proof"]
+    assert M.MarlinInst.verify(vk, [], proof, rng)
+    assert not M.MarlinInst.verify(vk, [1], proof, rng)
+    with pytest.raises(M.MarlinError):
+        M.MarlinInst.prove(pk, TestCircuit(1, 2), M.generate_rand())
+    pk.free()
+    srs.free()
