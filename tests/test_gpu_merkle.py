@@ -257,3 +257,29 @@ def test_simple_merkle_tree_golden_bytes(M, S, W):
     assert proof.hex() == case["proof"]
     assert tree.verify(proof, case["leaves"][case["index"]]) and not tree.verify(proof, case["leaves"][0])
     tree.free()
+
+
+def test_simple_merkle_tree_config5_2p18_leaves(M, W):
+    """BASELINE configs[4] end to end, the reference's call sequence at its size (examples/merkle-tree, 2^18 leaves):
+    SimpleMerkleTree::new — universal_setup(100_000, 25_000, 300_000), both CRH setups, the tree over 2^18 u8 leaves (on the GPU),
+    keys from the dummy circuit of height 19 — then get_merkle_path, prove, verify (src/merkle_tree/simple_merkle_tree.rs:35-153)."""
+    import time
+    rng = np.random.default_rng(2018)
+    leaves = [int(v) for v in rng.integers(0, 256, size=1 << 18)]
+    t0 = time.time()
+    tree = W.SimpleMerkleTree(leaves)
+    t1 = time.time()
+    assert W.merkle_tree_height(len(leaves)) == 19 and len(tree.levels) == 19
+    i = 0x2B3C5
+    path = tree.get_merkle_path(i)
+    assert tree.params.root_from_path(leaves[i], *path) == tree.root()      # the path of the GPU tree folds to its root
+    proof = tree.prove(leaves[i], path)
+    t2 = time.time()
+    assert tree.verify(proof, leaves[i])
+    assert not tree.verify(proof, leaves[i] ^ 0x10)
+    other = (i + 12345) % len(leaves)
+    with pytest.raises(M.MarlinError):                                      # a path that is not this leaf's: unsatisfied
+        tree.prove(leaves[i] ^ 1, path)
+    assert tree.verify(tree.prove(leaves[other], tree.get_merkle_path(other)), leaves[other])
+    print("SimpleMerkleTree 2^18 leaves: new %.1f s (incl. two circuit syntheses in Python), prove %.1f s" % (t1 - t0, t2 - t1))
+    tree.free()
