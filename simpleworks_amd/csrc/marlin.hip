@@ -403,7 +403,17 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     out->result = g1_xyzz_identity();  // an empty range (n = 0, or a rank's empty shard) contributes the identity
     const bool force_exchange = getenv("SWM_SHARD_FORCE") != nullptr;  // test hook: exchange with a world of one
     out->sharded = ctx->shard_world > 1 || (force_exchange && (ctx->rccl_comm || ctx->shard_allgather));
-    if (out->sharded) {
+    // Split of a replicated polynomial's commitment over the ranks: by point range (default: the bucket stage then runs in
+    // full on every rank), or — SWM_SHARD_BUCKETS=1, table schedule only — by BUCKET range (every rank has all coefficients:
+    // all points stay, the digits are filtered; accumulation, sort and bucket stage all shrink with the number of ranks).
+    // Measured per rank on one GPU (tools/ubench/shard_emulate.py, profiles/r03_shard_emulate.jsonl): the bucket split balances
+    // two ranks better (38.1 vs 40.0 ms at 2^20) and loses at eight (2^22: 71.4 vs 67.2 ms — 1/8 of the buckets at full
+    // depth are too few lanes for the accumulation), so it is not the default.  (Read per call: tests switch it.)
+    const bool by_bucket = getenv("SWM_SHARD_BUCKETS") && atoi(getenv("SWM_SHARD_BUCKETS")) != 0;
+    if (out->sharded && by_bucket && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous()) {
+        tab.shard_rank = ctx->shard_rank;
+        tab.shard_world = ctx->shard_world;
+    } else if (out->sharded) {
         lo = (size_t)(((unsigned __int128)n * ctx->shard_rank) / ctx->shard_world);
         hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
     }

@@ -35,6 +35,12 @@ struct MsmTable {
     // commits to them where they are (flat schedule only).
     unsigned blk_log = 31;
     size_t bstride = 0;
+    // One proof over G ranks, split by BUCKET range (flat schedule, every rank holds all n scalars): the MSM takes all its
+    // points but keeps only the digits whose bucket lies in the rank's share of the bucket-stage workgroups — windows
+    // narrower than the table width (the top one) are split by point range instead, their few low buckets are reduced by
+    // every rank.  Accumulation, sort AND bucket stage shrink with G; the per-rank sums add up to the MSM like those of a
+    // point-range split.  shard_world <= 1: off.
+    unsigned shard_rank = 0, shard_world = 0;
     bool any() const { return t28 != nullptr || te != nullptr; }
     bool contiguous() const { return blk_log >= 31; }
 };
@@ -70,6 +76,7 @@ struct MsmJob {
     WinLayout pl;
     unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
     unsigned red_blocks = 0, log_m = 0, rb = 256;  // bucket stage: workgroups per window, log2 buckets per lane, lanes per workgroup
+    unsigned blk_lo = 0, blk_hi = 0, blk_low = 0;  // workgroups [blk_lo, blk_hi) and [0, blk_low) hold buckets of this rank (bucket-range split); the others emit the identity
     bool te = false;         // partial sums and workgroup results are twisted Edwards points (the host fold converts the total)
     int slot = 0;            // index of the pinned result slot (ctx->slot_busy)
     // deferred bucket stage (msm_flush_tails): what it reads / writes, the stream the job ran on and its "partials ready" event

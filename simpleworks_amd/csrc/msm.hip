@@ -139,9 +139,15 @@ __device__ __forceinline__ void for_each_digit(const Fr& s, const WinLayout& L, 
 // A scalar that is not a canonical field element (>= r; arkworks' BigInteger256 scalars always are) raises *bad: the
 // recoding only covers 254 bits, so such an input cannot be given a meaning.  Points flagged in the infinity mask get
 // zero digits (they contribute nothing, as in VariableBaseMSM).  bad[1] counts the points that contribute nothing.
+// Bucket-range split of one proof over several ranks (MsmTable::shard_world): a digit of a full-width window is kept when
+// its bucket lies in [blo, bhi), a digit of a narrower window when its point lies in [plo, phi).
+struct DigitShard {
+    uint32_t on, cfull, blo, bhi;
+    uint64_t plo, phi;
+};
 __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
                                                   uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
-                                                  size_t inf_first, uint32_t* __restrict__ bad) {
+                                                  size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr s = scalars[i];
         bool ge = true;  // s >= r ?
@@ -167,7 +173,14 @@ __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars
             const unsigned long long m = __ballot(z == 0 || skip);
             if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(bad + 1, (uint32_t)__popcll(m));
         }
-        for_each_digit(s, L, [&](unsigned w, uint32_t code) { digits[(size_t)w * n + i] = skip ? 0u : code; });
+        for_each_digit(s, L, [&](unsigned w, uint32_t code) {
+            if (sh.on && code) {
+                const uint32_t bucket = (code - 1) >> 1;
+                const bool keep = L.c[w] == sh.cfull ? (bucket >= sh.blo && bucket < sh.bhi) : (i >= sh.plo && i < sh.phi);
+                if (!keep) code = 0;
+            }
+            digits[(size_t)w * n + i] = skip ? 0u : code;
+        });
     }
 }
 
@@ -1191,6 +1204,7 @@ struct TailJob {
     const uint32_t* seg_off;
     G1XYZZ* out;
     unsigned log_m, red_blocks, big_nseg;
+    unsigned blk_lo, blk_hi, blk_low;   // workgroups of this rank's bucket share (MsmJob); the others only emit the identity
     const uint32_t *status, *entries;  // device status words of the job, forwarded to ...
     uint32_t* host_flags;              // ... the tail of its pinned result slot
     WinLayout L;
@@ -1216,6 +1230,21 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     G1XYZZ* sm_acc = sm_alt + RB;
     G1XYZZ* sm_r = sm_acc + RB;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
+    if (!((blockIdx.x >= job.blk_lo && blockIdx.x < job.blk_hi) || blockIdx.x < job.blk_low)) {
+        // not a workgroup of this rank's bucket share: its buckets are empty here, the host fold sees the identity
+        if (t == 0) {
+            Form::store_identity(sm_run[0]);
+            size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
+            Form::store_384(out[o], sm_run[0]);
+            Form::store_384(out[o + 1], sm_run[0]);
+            if (blockIdx.x == 0 && w == 0 && job.host_flags) {
+                job.host_flags[0] = job.status[0];
+                job.host_flags[1] = *job.entries;
+                job.host_flags[2] = job.status[1];
+            }
+        }
+        return;
+    }
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
@@ -1741,6 +1770,28 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->stream = st_tail;
     job->pl = rl;
     job->red_blocks = red_blocks;
+    job->blk_lo = 0;
+    job->blk_hi = red_blocks;
+    job->blk_low = 0;
+    DigitShard dshard{};
+    if (tab.shard_world > 1) {
+        if (!flat || !tab.contiguous()) return set_err(ctx, SWM_ERR_INTERNAL, "msm: a bucket-range split needs the table schedule");
+        const unsigned G = tab.shard_world, g = tab.shard_rank;
+        const uint64_t span = (uint64_t)rb << log_m;  // buckets per bucket-stage workgroup
+        job->blk_lo = (unsigned)((uint64_t)red_blocks * g / G);
+        job->blk_hi = (unsigned)((uint64_t)red_blocks * (g + 1) / G);
+        unsigned cfull = 0, cnarrow = 0;
+        for (unsigned w = 0; w < pl.nwin; w++) cfull = std::max<unsigned>(cfull, pl.c[w]);
+        for (unsigned w = 0; w < pl.nwin; w++)
+            if (pl.c[w] < cfull) cnarrow = std::max<unsigned>(cnarrow, pl.c[w]);
+        if (cnarrow) job->blk_low = (unsigned)((((uint64_t)1 << (cnarrow - 1)) + span - 1) / span);  // digits of a narrow window: buckets < 2^(c - 1)
+        dshard.on = 1;
+        dshard.cfull = cfull;
+        dshard.blo = (uint32_t)std::min<uint64_t>(job->blk_lo * span, pl.NB);
+        dshard.bhi = (uint32_t)std::min<uint64_t>(job->blk_hi * span, pl.NB);
+        dshard.plo = (uint64_t)(((unsigned __int128)n * g) / G);
+        dshard.phi = (uint64_t)(((unsigned __int128)n * (g + 1)) / G);
+    }
     job->log_m = log_m;
     job->rb = rb;
 
@@ -1872,7 +1923,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
-               big_count + 1 /* zeroed with the histogram */);
+               big_count + 1 /* zeroed with the histogram */, dshard);
     const unsigned scan_tiles_ = scan_tiles;
     if (flat) {
         // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the
@@ -1995,6 +2046,9 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         batch.j[i].host_flags = j->zero_copy ? j->host_flags_dev : nullptr;
         batch.j[i].log_m = j->log_m;
         batch.j[i].red_blocks = j->red_blocks;
+        batch.j[i].blk_lo = j->blk_lo;
+        batch.j[i].blk_hi = j->blk_hi;
+        batch.j[i].blk_low = j->blk_low;
         batch.j[i].big_nseg = j->big_nseg;
         batch.j[i].L = j->pl;
         max_red = std::max(max_red, j->red_blocks);

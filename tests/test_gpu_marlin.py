@@ -599,9 +599,14 @@ def test_sharded_prover_two_processes_real_kernels(tmp_path):
     assert outs[0]["exchanges"] == outs[1]["exchanges"] > 0
 
 
-def test_sharded_prover_with_window_tables_2p17(M, S, W):
-    """Keys of >= 2^17 SRS powers carry the precomputed window multiples: a rank's shard then starts at a table OFFSET.
-    Three thread-ranks (uneven ranges) must reproduce the single-context bytes."""
+@pytest.mark.parametrize("world,by_bucket", [(3, 0), (3, 1), (8, 1), (8, 0)])
+def test_sharded_prover_with_window_tables_2p17(M, S, W, world, by_bucket, monkeypatch):
+    """Keys of >= 2^17 SRS powers carry the precomputed window multiples.  The commitments of a replicated polynomial are split by
+    point range (a rank's shard starts at a table OFFSET) or, with SWM_SHARD_BUCKETS=1, by BUCKET range (every rank keeps the
+    digits of its share of the bucket-stage workgroups; the narrow top window by point range): thread-ranks with uneven shares
+    must reproduce the single-context bytes, and every non-zero digit must be accumulated by exactly one rank (the ranks'
+    mixed additions add up to the single context's)."""
+    monkeypatch.setenv("SWM_SHARD_BUCKETS", str(by_bucket))
     n = 1 << 17
     cs, public = W.synthetic_r1cs(n, 0x1717, 0x7171)
 
@@ -610,18 +615,26 @@ def test_sharded_prover_with_window_tables_2p17(M, S, W):
         srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
         pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
         srs.free()
+        ctx.profile_reset()
+        ctx.profile_enable(2)
         proof = M.generate_proof(cs, pk, M.rng_from_seed(bytes([5] * 32)))
-        out = (S.serialize_verifying_key(vk), S.serialize_proof(proof))
+        ctx.profile_enable(False)
+        ctx.profile()
+        out = (S.serialize_verifying_key(vk), S.serialize_proof(proof), dict(ctx.last_work))
         pk.free()
         return out
 
     from simpleworks_amd._lib import Context
     single_ctx = Context(0)
-    vk1, proof1 = build(single_ctx)
+    vk1, proof1, work1 = build(single_ctx)
     single_ctx.close()
-    for vk_b, proof_b in _run_sharded(3, build):
+    ranks = _run_sharded(world, build)
+    for vk_b, proof_b, _ in ranks:
         assert vk_b == vk1
         assert proof_b == proof1
+    adds = [r[2]["msm_adds"] for r in ranks]
+    assert sum(adds) == work1["msm_adds"], (adds, work1["msm_adds"])
+    assert max(adds) < 2.2 * work1["msm_adds"] / world        # and the shares are of the same order (uniform scalars)
     assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
 
 
