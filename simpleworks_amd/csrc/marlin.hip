@@ -407,7 +407,7 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // full on every rank), or — SWM_SHARD_BUCKETS=1, table schedule only — by BUCKET range (every rank has all coefficients:
     // all points stay, the digits are filtered; accumulation, sort and bucket stage all shrink with the number of ranks).
     // Measured per rank on one GPU (tools/ubench/shard_emulate.py, profiles/r03_shard_emulate.jsonl): the bucket split balances
-    // two ranks better (38.1 vs 40.0 ms at 2^20) and loses at eight (2^22: 71.4 vs 67.2 ms — 1/8 of the buckets at full
+    // two ranks better (36.5 vs 38.4 ms at 2^20) and loses at eight (2^22: 69.6 vs 66.8 ms — 1/8 of the buckets at full
     // depth are too few lanes for the accumulation), so it is not the default.  (Read per call: tests switch it.)
     const bool by_bucket = getenv("SWM_SHARD_BUCKETS") && atoi(getenv("SWM_SHARD_BUCKETS")) != 0;
     if (out->sharded && by_bucket && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous()) {

@@ -1517,6 +1517,19 @@ int msm_install_bases(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool in_
     *d28 = nullptr;
     *te = nullptr;
     *c = msm_table_width(n);
+    // A context that is one rank of a sharded proof (swm_set_msm_sharding before the key is built) accumulates n / G points per
+    // MSM into the same bucket set, and the bucket stage — which every rank runs over all 2^(c-1) buckets — becomes the largest
+    // replicated item: the table is as many bits narrower as the width rule gives for the rank's share of the set, at most
+    // log2(G) - 1.  Measured per rank (tools/ubench/shard_emulate.py, same box): 2^20 constraints, G = 8: c = 20 / 18 / 17 ->
+    // 23.7 / 20.9 / 20.9 ms; G = 4: flat; 2^22 constraints (1.5 M points per rank and more): 20 stays best (18: + 3 %).
+    if (*c > 12 && ctx->shard_world >= 4 && !getenv("SWM_MSM_TABLE_C")) {
+        unsigned lg = 0;
+        while ((2u << lg) <= ctx->shard_world) lg++;
+        const unsigned share = msm_table_width(std::max<size_t>(n / ctx->shard_world, 512));
+        const unsigned delta = share && share < *c ? std::min(*c - share, lg - 1) : 0;
+        *c = std::max(12u, *c - delta);
+    }
+    if (getenv("SWM_TRACE")) fprintf(stderr, "[swm] base set of %zu points: table width %u (world %u)\n", n, *c, ctx->shard_world);
     if (*c && (uint64_t)n * msm_table_windows(*c) >= (1ull << 31)) *c = 0;  // the sort addresses table rows with 31 bits
     const unsigned W = *c ? msm_table_windows(*c) : 0;
     if (*c && msm_te_enabled()) {

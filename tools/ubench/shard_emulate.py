@@ -3,7 +3,7 @@ exchange callback hands back this rank's own contribution in every slot (so the 
 of interest: everything a rank computes, with the exchange reduced to a host memcpy).  What the number says: the time one
 rank needs when the other G - 1 GPUs work beside it, i.e. the strong-scaling bound of the split (xGMI exchanges of 192 B x
 commitments per round are microseconds).  Prints one JSON line per (G, rank).
-usage: shard_emulate.py [log_n=20] [steps=5]        env: SWM_SHARD_BUCKETS=0 -> point-range split (r02), SWM_SHARD_R1_OFF"""
+usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_BUCKETS=1 -> bucket-range split, SWM_SHARD_R1_OFF"""
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
@@ -14,17 +14,17 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 1 << lg
 ctx = M.default_context()
-rng = M.generate_rand()
-srs = M.generate_universal_srs(n, n, n, rng)
 cs, public = W.synthetic_r1cs(n, 0x1234567, 0x7654321)
-pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
-srs.free()
-mode = "points" if os.environ.get("SWM_SHARD_BUCKETS") == "0" else "buckets"
-for G in (1, 2, 4, 8):
+mode = "buckets" if os.environ.get("SWM_SHARD_BUCKETS", "0") not in ("", "0") else "points"
+for G in ([int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]):
+    # the key is built by a context that already knows its world: the table width follows the rank's share (msm_install_bases)
+    ctx.set_msm_sharding(0, G, None if G == 1 else (lambda send, G=G: bytes(send) * G))
+    rng = M.generate_rand()
+    srs = M.generate_universal_srs(n, n, n, rng)
+    pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+    srs.free()
     for rank in sorted({0, G - 1}):
-        if G == 1:
-            ctx.set_msm_sharding(0, 1, None)
-        else:
+        if G > 1:
             ctx.set_msm_sharding(rank, G, lambda send, G=G: bytes(send) * G)
         for _ in range(2):
             M.generate_proof(cs, pk, rng)
@@ -41,4 +41,5 @@ for G in (1, 2, 4, 8):
         print(json.dumps({"log_n": lg, "split": mode, "ranks": G, "rank": rank, "ms_per_proof_on_this_rank": dt * 1e3,
                           "msm_adds": ctx.last_work.get("msm_adds"), "accumulate_ms": prof.get("msm_accumulate", {}).get("total_ms", 0) / steps}),
               flush=True)
+    pk.free()
 ctx.set_msm_sharding(0, 1, None)
