@@ -78,6 +78,42 @@ template <class F> SWM_HD bool fp_is_one(const F& a) {
     return acc == 0;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ---- host side: the same little-endian bytes seen as 64-bit limbs (the verifier's pairing, the prover's host folds)
+template <class F> inline void host_limbs64(const F& a, uint64_t* o) {
+    for (int i = 0; i < F::N / 2; i++) o[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+}
+template <class F> inline void host_store64(F& r, const uint64_t* t) {
+    for (int i = 0; i < F::N / 2; i++) {
+        r.v[2 * i] = (uint32_t)t[i];
+        r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+}
+template <class F> struct HostModulus {  // compile-time constants: the loops below unroll with immediate operands
+    static constexpr int M = F::N / 2;
+    static constexpr uint64_t limb(int i) { return (uint64_t)F::Params::P[2 * i] | ((uint64_t)F::Params::P[2 * i + 1] << 32); }
+    static constexpr uint64_t neg_inv() {  // -p^-1 mod 2^64 by Newton iteration
+        uint64_t x = 1;
+        for (int i = 0; i < 6; i++) x *= 2 - limb(0) * x;
+        return 0 - x;
+    }
+    static constexpr uint64_t inv = neg_inv();
+};
+// t (M limbs, + carry bit `extra`) < 2p  ->  t mod p
+template <class F> inline void host_cond_sub(uint64_t* t, uint64_t extra) {
+    constexpr int M = F::N / 2;
+    uint64_t s[M];
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < M; i++) {
+        unsigned __int128 d = (unsigned __int128)t[i] - HostModulus<F>::limb(i) - (uint64_t)borrow;
+        s[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+    if (extra || !borrow)
+        for (int i = 0; i < M; i++) t[i] = s[i];
+}
+#endif
+
 // r = a - p if a >= p else a   (a < 2p; `extra` = carry bit above the top limb)
 template <class F> SWM_HD void fp_cond_sub_p(F& a, uint32_t extra) {
     uint32_t s[F::N];
@@ -95,6 +131,23 @@ template <class F> SWM_HD void fp_cond_sub_p(F& a, uint32_t extra) {
 
 template <class F> SWM_HD F fp_add(const F& a, const F& b) {
     F r;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+        constexpr int M = F::N / 2;
+        uint64_t x[M], y[M];
+        host_limbs64(a, x);
+        host_limbs64(b, y);
+        unsigned __int128 c = 0;
+        for (int i = 0; i < M; i++) {
+            c += (unsigned __int128)x[i] + y[i];
+            x[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        host_cond_sub<F>(x, (uint64_t)c);
+        host_store64(r, x);
+        return r;
+    }
+#endif
     uint32_t carry = 0;
 #pragma unroll
     for (int i = 0; i < F::N; i++) {
@@ -107,6 +160,30 @@ template <class F> SWM_HD F fp_add(const F& a, const F& b) {
 }
 template <class F> SWM_HD F fp_sub(const F& a, const F& b) {
     F r;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+        constexpr int M = F::N / 2;
+        uint64_t x[M], y[M];
+        host_limbs64(a, x);
+        host_limbs64(b, y);
+        uint64_t borrow = 0;
+        for (int i = 0; i < M; i++) {
+            unsigned __int128 d = (unsigned __int128)x[i] - y[i] - borrow;
+            x[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+        if (borrow) {
+            unsigned __int128 c = 0;
+            for (int i = 0; i < M; i++) {
+                c += (unsigned __int128)x[i] + HostModulus<F>::limb(i);
+                x[i] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
+        host_store64(r, x);
+        return r;
+    }
+#endif
     uint32_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < F::N; i++) {
@@ -182,16 +259,10 @@ template <class F> SWM_HD F fp_mul(const F& a, const F& b) {
 #else
     // host: CIOS on 64-bit limbs (same little-endian bytes as the 32-bit view) with unsigned __int128
     constexpr int M = N / 2;
-    uint64_t a64[M], b64[M], p64[M], t[M + 2];
-    for (int i = 0; i < M; i++) {
-        a64[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
-        b64[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
-        p64[i] = (uint64_t)F::Params::P[2 * i] | ((uint64_t)F::Params::P[2 * i + 1] << 32);
-    }
-    // -p^-1 mod 2^64 by Newton iteration from the 32-bit value (p = 1 mod 2^32)
-    uint64_t inv = 1;
-    for (int i = 0; i < 6; i++) inv *= 2 - p64[0] * inv;
-    inv = 0 - inv;
+    constexpr uint64_t inv = HostModulus<F>::inv;
+    uint64_t a64[M], b64[M], t[M + 2];
+    host_limbs64(a, a64);
+    host_limbs64(b, b64);
     for (int i = 0; i < M + 2; i++) t[i] = 0;
     for (int i = 0; i < M; i++) {
         uint64_t c = 0;
@@ -204,10 +275,10 @@ template <class F> SWM_HD F fp_mul(const F& a, const F& b) {
         t[M] = (uint64_t)x;
         t[M + 1] = (uint64_t)(x >> 64);
         uint64_t mm = t[0] * inv;
-        x = (unsigned __int128)mm * p64[0] + t[0];
+        x = (unsigned __int128)mm * HostModulus<F>::limb(0) + t[0];
         c = (uint64_t)(x >> 64);
         for (int j = 1; j < M; j++) {
-            x = (unsigned __int128)mm * p64[j] + t[j] + c;
+            x = (unsigned __int128)mm * HostModulus<F>::limb(j) + t[j] + c;
             t[j - 1] = (uint64_t)x;
             c = (uint64_t)(x >> 64);
         }
@@ -215,11 +286,8 @@ template <class F> SWM_HD F fp_mul(const F& a, const F& b) {
         t[M - 1] = (uint64_t)x;
         t[M] = t[M + 1] + (uint64_t)(x >> 64);
     }
-    for (int i = 0; i < M; i++) {
-        r.v[2 * i] = (uint32_t)t[i];
-        r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
-    }
-    fp_cond_sub_p(r, (uint32_t)t[M]);
+    host_cond_sub<F>(t, t[M]);
+    host_store64(r, t);
 #endif
     return r;
 }
@@ -258,7 +326,91 @@ template <class F> SWM_HD F fp_pow(const F& a, const uint32_t* e, int elimbs) {
     return acc;
 }
 // Fermat inverse; 0 -> 0 (matches the "zeros stay zero" convention of ark_ff::batch_inversion callers)
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host: binary extended Euclid on 64-bit limbs (a few microseconds against ~40 for the Fermat chain): a x1 = u, a x2 = v mod p
+// throughout; the Montgomery factor of the input comes out inverted and is put back by two multiplications by R^2.
+template <class F> inline F host_inv_euclid(const F& a_mont) {
+    constexpr int M = F::N / 2;
+    uint64_t u[M], v[M], x1[M], x2[M];
+    host_limbs64(a_mont, u);
+    for (int i = 0; i < M; i++) {
+        v[i] = HostModulus<F>::limb(i);
+        x1[i] = x2[i] = 0;
+    }
+    x1[0] = 1;
+    auto is_one = [](const uint64_t* x) {
+        uint64_t acc = x[0] ^ 1;
+        for (int i = 1; i < M; i++) acc |= x[i];
+        return acc == 0;
+    };
+    auto halve = [&](uint64_t* w, uint64_t* x) {  // w even: w /= 2, x = x / 2 mod p
+        for (int i = 0; i < M - 1; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 63);
+        w[M - 1] >>= 1;
+        uint64_t top = 0;
+        if (x[0] & 1) {
+            unsigned __int128 c = 0;
+            for (int i = 0; i < M; i++) {
+                c += (unsigned __int128)x[i] + HostModulus<F>::limb(i);
+                x[i] = (uint64_t)c;
+                c >>= 64;
+            }
+            top = (uint64_t)c;
+        }
+        for (int i = 0; i < M - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 63);
+        x[M - 1] = (x[M - 1] >> 1) | (top << 63);
+    };
+    auto geq = [](const uint64_t* x, const uint64_t* y) {
+        for (int i = M - 1; i >= 0; i--)
+            if (x[i] != y[i]) return x[i] > y[i];
+        return true;
+    };
+    auto sub = [](uint64_t* x, const uint64_t* y) {  // x -= y, x >= y
+        uint64_t borrow = 0;
+        for (int i = 0; i < M; i++) {
+            unsigned __int128 d = (unsigned __int128)x[i] - y[i] - borrow;
+            x[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+    };
+    auto sub_mod = [&](uint64_t* x, const uint64_t* y) {  // x = x - y mod p, both < p
+        uint64_t borrow = 0;
+        for (int i = 0; i < M; i++) {
+            unsigned __int128 d = (unsigned __int128)x[i] - y[i] - borrow;
+            x[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+        if (borrow) {
+            unsigned __int128 c = 0;
+            for (int i = 0; i < M; i++) {
+                c += (unsigned __int128)x[i] + HostModulus<F>::limb(i);
+                x[i] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1)) halve(u, x1);
+        while (!(v[0] & 1)) halve(v, x2);
+        if (geq(u, v)) {
+            sub(u, v);
+            sub_mod(x1, x2);
+        } else {
+            sub(v, u);
+            sub_mod(x2, x1);
+        }
+    }
+    F inv_plain;  // (a R)^-1 as a plain residue = a^-1 R^-1
+    host_store64(inv_plain, is_one(u) ? x1 : x2);
+    F r2;
+    for (int i = 0; i < F::N; i++) r2.v[i] = F::Params::R2[i];
+    return fp_mul(fp_mul(inv_plain, r2), r2);
+}
+#endif
 template <class F> SWM_HD F fp_inv(const F& a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (fp_is_zero(a)) return a;
+    return host_inv_euclid(a);
+#endif
     // The exponent limbs are read straight from the constant table, one limb per outer iteration: a private copy
     // indexed by a loop variable lives in scratch memory on the GPU, and its ~250 dependent loads made a single
     // inversion (the serial tail of every batch inversion) twice as slow as its multiplications.

@@ -4,6 +4,9 @@
 // vendored, restated from SURVEY.md A.6-A.8 [U]) for the instance fixed at /root/reference/src/marlin/mod.rs:12-14.
 // verify() is the counterpart of verify_proof (src/marlin/mod.rs:79-86): milliseconds of host work, no GPU.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include "blake2s.h"
 #include "chacha.h"
@@ -205,6 +208,16 @@ LcSet construct_linear_combinations(const IndexInfo& info, const std::vector<Fr>
 // Marlin::verify + MarlinKZG10::check_combinations + KZG10::batch_check.  `rng` is the caller's generator
 // (the batch_check randomiser is drawn from it, as in arkworks).
 inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const Proof& proof, ChaChaRng& rng) {
+    const bool vtrace = getenv("SWM_TRACE") != nullptr;
+    auto vnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double vt0 = vnow();
+    auto vmark = [&](const char* what) {
+        if (vtrace) {
+            double t = vnow();
+            fprintf(stderr, "[swm trace] verify: %-28s %7.3f ms\n", what, t - vt0);
+            vt0 = t;
+        }
+    };
     HDomain dx(public_input.size() + 1);
     size_t padded = std::max<size_t>(public_input.size(), dx.size - 1);
     public_input.resize(padded, fp_zero<Fr>());
@@ -259,12 +272,14 @@ inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const P
     if (eval_labels.size() != proof.evaluations.size()) return false;
     for (size_t i = 0; i < eval_labels.size(); i++) evaluations[eval_labels[i]] = proof.evaluations[i];
     auto provider = [&](const std::string& label, const LcTerms&, const Fr&) { return evaluations.at(label); };
+    vmark("transcript");
     LcSet lcs = construct_linear_combinations(vk.info, public_input, provider, st);
+    vmark("linear combinations");
     // check_combinations: combine commitments, fold constant terms into the claimed evaluations
     std::map<std::string, LComm> lc_comms;
     for (auto& kv : lcs) {
         const std::string& label = kv.first;
-        G1XYZZ comm = g1_xyzz_identity(), shifted = g1_xyzz_identity();
+        std::vector<std::pair<G1Affine, Fr>> comm_terms, shifted_terms;  // summed by one Straus chain each (g1_msm_host)
         bool has_bound = false;
         uint64_t bound = 0;
         for (auto& term : kv.second) {
@@ -280,17 +295,18 @@ inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const P
             } else if (cur.has_bound) {
                 return false;  // EquationHasDegreeBounds
             }
-            g1_add_mixed(comm, g1_mul_fr(cur.c.comm, term.first));
-            if (cur.c.has_shifted) g1_add_mixed(shifted, g1_mul_fr(cur.c.shifted, term.first));
+            comm_terms.push_back({cur.c.comm, term.first});
+            if (cur.c.has_shifted) shifted_terms.push_back({cur.c.shifted, term.first});
         }
         LComm out;
-        out.c.comm = g1_to_affine(comm);
+        out.c.comm = g1_to_affine(g1_msm_host(comm_terms));
         out.c.has_shifted = has_bound;
-        if (has_bound) out.c.shifted = g1_to_affine(shifted);
+        if (has_bound) out.c.shifted = g1_to_affine(g1_msm_host(shifted_terms));
         out.has_bound = has_bound;
         out.bound = bound;
         lc_comms[label] = out;
     }
+    vmark("combined commitments");
     // batch_check: per query point (beta, then gamma), labels in sorted order, challenges xi^0, xi^1, ...
     struct Combined {
         G1Affine c;
@@ -303,13 +319,13 @@ inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const P
         for (auto& q : kQuerySet)
             if (std::string(q.point) == pl) labels.push_back(q.label);
         std::sort(labels.begin(), labels.end());
-        G1XYZZ cc = g1_xyzz_identity();
+        std::vector<std::pair<G1Affine, Fr>> cc_terms;
         Fr cv = fp_zero<Fr>();
         Fr ch = fp_one<Fr>();  // xi^ctr
         for (auto& l : labels) {
             const LComm& lc = lc_comms.at(l);
             const Fr& v = evaluations.at(l);
-            g1_add_mixed(cc, g1_mul_fr(lc.c.comm, ch));
+            cc_terms.push_back({lc.c.comm, ch});
             cv = fp_add(cv, fp_mul(v, ch));
             ch = fp_mul(ch, xi);
             if (lc.has_bound) {
@@ -317,32 +333,37 @@ inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const P
                 for (auto& ds : vk.vk.degree_bounds_and_shift_powers)
                     if (ds.first == lc.bound) sp = &ds.second;
                 if (!sp) return false;
-                G1Affine adj = g1_sub_affine(lc.c.shifted, g1_mul_fr(*sp, v));
-                g1_add_mixed(cc, g1_mul_fr(adj, ch));
+                // (shifted - v * shift_power) * ch as two terms of the same sum
+                cc_terms.push_back({lc.c.shifted, ch});
+                cc_terms.push_back({*sp, fp_neg(fp_mul(v, ch))});
                 ch = fp_mul(ch, xi);
             }
         }
-        combined.push_back({g1_to_affine(cc), std::string(pl) == "beta" ? st.beta : st.gamma, cv});
+        combined.push_back({g1_to_affine(g1_msm_host(cc_terms)), std::string(pl) == "beta" ? st.beta : st.gamma, cv});
     }
-    G1XYZZ total_c = g1_xyzz_identity(), total_w = g1_xyzz_identity();
+    vmark("batched openings");
+    // total_c = sum_i randomizer_i (z_i w_i + c_i) - g_mult g - gamma_g_mult gamma_g,  total_w = sum_i randomizer_i w_i
+    std::vector<std::pair<G1Affine, Fr>> c_terms, w_terms;
     Fr randomizer = fp_one<Fr>(), g_mult = fp_zero<Fr>(), gamma_g_mult = fp_zero<Fr>();
     for (size_t i = 0; i < combined.size(); i++) {
         const PcProof& pp = proof.pc_proof[i];
-        G1Affine tmp = g1_add_affine(g1_mul_fr(pp.w, combined[i].z), combined[i].c);
         g_mult = fp_add(g_mult, fp_mul(randomizer, combined[i].v));
         if (pp.has_random_v) gamma_g_mult = fp_add(gamma_g_mult, fp_mul(randomizer, pp.random_v));
-        g1_add_mixed(total_c, g1_mul_fr(tmp, randomizer));
-        g1_add_mixed(total_w, g1_mul_fr(pp.w, randomizer));
+        c_terms.push_back({pp.w, fp_mul(randomizer, combined[i].z)});
+        c_terms.push_back({combined[i].c, randomizer});
+        w_terms.push_back({pp.w, randomizer});
         uint64_t rv[2];
         rng.gen_u128(rv);
         randomizer = fr_from_u128(rv);
     }
-    g1_add_mixed(total_c, g1_neg(g1_mul_fr(vk.vk.g, g_mult)));
-    G1Affine gg = g1_mul_fr(vk.vk.gamma_g, gamma_g_mult);
-    if (!g1_is_inf(gg)) g1_add_mixed(total_c, g1_neg(gg));
-    G1Affine tw = g1_to_affine(total_w), tc = g1_to_affine(total_c);
+    c_terms.push_back({vk.vk.g, fp_neg(g_mult)});
+    c_terms.push_back({vk.vk.gamma_g, fp_neg(gamma_g_mult)});
+    G1Affine tw = g1_to_affine(g1_msm_host(w_terms)), tc = g1_to_affine(g1_msm_host(c_terms));
     if (!g1_is_inf(tw)) tw = g1_neg(tw);
-    return product_of_pairings_is_one({{tw, vk.vk.beta_h}, {tc, vk.vk.h}});
+    vmark("pairing inputs");
+    const bool ok = product_of_pairings_is_one({{tw, vk.vk.beta_h}, {tc, vk.vk.h}});
+    vmark("two pairings");
+    return ok;
 }
 
 }  // namespace swm

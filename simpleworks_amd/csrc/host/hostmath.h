@@ -147,6 +147,38 @@ inline G1Affine g1_mul_fr(const G1Affine& p, const Fr& k_mont) {
     Fr s = fp_to_std(k_mont);
     return g1_to_affine(g1_mul_limbs(p, s.v, 8));
 }
+// sum_i k_i P_i on the host (the verifier's linear combinations of commitments): Straus — one chain of doublings for all
+// terms, 4-bit windows, 15 multiples per point.  The same group element as term-by-term double-and-add at a third of the cost
+// from a dozen terms on.
+inline G1XYZZ g1_msm_host(const std::vector<std::pair<G1Affine, Fr>>& terms) {
+    struct Entry {
+        G1XYZZ mult[16];
+        Fr k;
+    };
+    std::vector<Entry> es;
+    for (auto& t : terms) {
+        if (g1_is_inf(t.first) || fp_is_zero(t.second)) continue;
+        es.emplace_back();
+        Entry& e = es.back();
+        e.k = fp_to_std(t.second);
+        e.mult[0] = g1_xyzz_identity();
+        e.mult[1] = g1_from_affine(t.first);
+        for (int m = 2; m < 16; m++) {
+            e.mult[m] = e.mult[m - 1];
+            g1_add_mixed(e.mult[m], t.first);
+        }
+    }
+    G1XYZZ acc = g1_xyzz_identity();
+    for (int w = 63; w >= 0; w--) {  // 256 bits, most significant nibble first
+        if (w != 63)
+            for (int d = 0; d < 4; d++) acc = g1_dbl(acc);
+        for (auto& e : es) {
+            const unsigned nib = (e.k.v[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (nib) g1_add(acc, e.mult[nib]);
+        }
+    }
+    return acc;
+}
 inline G1Affine g1_add_affine(const G1Affine& a, const G1Affine& b) {
     G1XYZZ acc = g1_from_affine(a);
     g1_add_mixed(acc, b);

@@ -2,8 +2,8 @@
 // Needed by verify_proof (/root/reference/src/marlin/mod.rs:79-86 -> MarlinKZG10::check_combinations ->
 // KZG10::batch_check: one product of two pairings) and by universal setup (a random G2 element and beta*h).
 // The reference delegates to ark-ec 0.3 bls12 (not vendored); this is a restatement with a deliberately plain
-// structure — affine Miller loop with generic Fq12 line evaluation — because the verifier is milliseconds of host
-// work, not a hot path.  Tower: Fq2 = Fq[u]/(u^2+5), Fq6 = Fq2[v]/(v^3-u), Fq12 = Fq6[w]/(w^2-v);
+// structure (affine Miller loop on the twist with a dense Fq12 product per line, cyclotomic squarings in the final
+// exponentiation, no Frobenius-based addition chain): the verifier is milliseconds of host work, not a hot path.  Tower: Fq2 = Fq[u]/(u^2+5), Fq6 = Fq2[v]/(v^3-u), Fq12 = Fq6[w]/(w^2-v);
 // G2: y^2 = x^3 + 1/u (D-type twist).
 #pragma once
 #include <vector>
@@ -148,44 +148,107 @@ inline G2Affine g2_mul(const G2Affine& p, const uint32_t* k, int limbs) {
 }
 
 // ------------------------------------------------------------------------------------------------ pairing
-// Ate Miller loop f_{x,Q}(P) with Q untwisted into E(Fq12): (x', y') -> (x' w^2, y' w^3).
-inline Fq12 miller_loop(const G1Affine& P, const G2Affine& Q) {
-    if (g1_is_inf(P) || Q.inf) return Fq12::one();
-    // w^2 = v -> (0,1,0) in c0 ; w^3 = v w -> (0,1,0) in c1
-    Fq12 xq = {{Fq2::zero(), Q.x, Fq2::zero()}, Fq6::zero()};
-    Fq12 yq = {Fq6::zero(), {Fq2::zero(), Q.y, Fq2::zero()}};
-    Fq12 xp = Fq12::from_fq(P.x), yp = Fq12::from_fq(P.y);
-    Fq12 f = Fq12::one(), tx = xq, ty = yq;
+// Ate Miller loop f_{x,Q}(P) with Q untwisted into E(Fq12): psi(x', y') = (x' w^2, y' w^3).  The running point T stays on the
+// twist, in affine coordinates over Fq2 (one Fq2 inversion per step: a binary Euclid on the host, ff.cuh).  With the
+// slope lambda' of the twist curve, the slope over Fq12 is lambda' w and the line through psi(T) evaluated at P = (xp, yp) is
+//     l = yp - lambda' xp w + (lambda' x_T - y_T) w^3            (coefficients at 1, w and w^3 = v w only)
+// — the same VALUE the plain Fq12 formulation of r01 produced, so the product is the same field element, not only the same
+// pairing.  Several pairings share one accumulator: one Fq12 squaring per loop step whatever their number.
+struct MillerPair {
+    Fq xp, yp;
+    Fq2 xq, yq, tx, ty;
+};
+inline Fq12 miller_line(const MillerPair& m, const Fq2& lam) {
+    Fq12 l;
+    l.c0 = {{m.yp, fp_zero<Fq>()}, Fq2::zero(), Fq2::zero()};
+    l.c1 = {-(lam.mul_fq(m.xp)), lam * m.tx - m.ty, Fq2::zero()};
+    return l;
+}
+inline Fq12 multi_miller_loop(const std::vector<std::pair<G1Affine, G2Affine>>& pairs) {
+    std::vector<MillerPair> ms;
+    for (auto& pq : pairs)
+        if (!g1_is_inf(pq.first) && !pq.second.inf) ms.push_back({pq.first.x, pq.first.y, pq.second.x, pq.second.y, pq.second.x, pq.second.y});
+    Fq12 f = Fq12::one();
+    if (ms.empty()) return f;
     const uint64_t X = SWM_BLS_X;
     int top = 63;
     while (!((X >> top) & 1)) top--;
     for (int i = top - 1; i >= 0; i--) {
-        Fq12 txx = tx * tx;
-        Fq12 lam = (txx + txx + txx) * (ty + ty).inverse();
-        f = f * f * (yp - ty - lam * (xp - tx));
-        Fq12 nx = lam * lam - tx - tx;
-        ty = lam * (tx - nx) - ty;
-        tx = nx;
-        if ((X >> i) & 1) {
-            lam = (yq - ty) * (xq - tx).inverse();
-            f = f * (yp - ty - lam * (xp - tx));
-            nx = lam * lam - tx - xq;
-            ty = lam * (tx - nx) - ty;
-            tx = nx;
+        f = f * f;
+        for (auto& m : ms) {  // doubling step (T never has order two: it lies in the prime-order subgroup)
+            Fq2 xx = m.tx.square();
+            Fq2 lam = (xx + xx + xx) * (m.ty + m.ty).inverse();
+            f = f * miller_line(m, lam);
+            Fq2 nx = lam.square() - m.tx - m.tx;
+            m.ty = lam * (m.tx - nx) - m.ty;
+            m.tx = nx;
         }
+        if ((X >> i) & 1)
+            for (auto& m : ms) {  // addition step (T = k Q with 1 < k < r: never +-Q)
+                Fq2 lam = (m.yq - m.ty) * (m.xq - m.tx).inverse();
+                f = f * miller_line(m, lam);
+                Fq2 nx = lam.square() - m.tx - m.xq;
+                m.ty = lam * (m.tx - nx) - m.ty;
+                m.tx = nx;
+            }
     }
     return f;
 }
-// f^((q^12-1)/r) = (conj(f) * f^-1)^((q^6+1)/r)
+inline Fq12 miller_loop(const G1Affine& P, const G2Affine& Q) { return multi_miller_loop({{P, Q}}); }
+
+// q^2-Frobenius: Fq2 is fixed; v^i w^j -> gamma^(2 i + j) v^i w^j, gamma = 5^((q-1)/6) (constants_gen.h)
+inline Fq12 frobenius2(const Fq12& a) {
+    static const uint32_t gl[12] = SWM_FROB2_GAMMA_MONT;
+    static const Fq g1 = fq_from_limbs(gl);
+    static const Fq g2 = fp_mul(g1, g1), g3 = fp_mul(g2, g1), g4 = fp_mul(g3, g1), g5 = fp_mul(g4, g1);
+    return {{a.c0.c0, a.c0.c1.mul_fq(g2), a.c0.c2.mul_fq(g4)}, {a.c1.c0.mul_fq(g1), a.c1.c1.mul_fq(g3), a.c1.c2.mul_fq(g5)}};
+}
+// Squaring in the cyclotomic subgroup (Granger-Scott; Guide to Pairing-Based Cryptography alg. 5.5.4, as ark-ff's
+// Fp12::cyclotomic_square arranges it for this tower): three Fq4 squarings instead of a full Fq12 one.  Only valid for
+// elements of the subgroup, i.e. after the easy part of the final exponentiation.
+inline Fq12 cyclotomic_square(const Fq12& a) {
+    const Fq2 &r0 = a.c0.c0, &r4 = a.c0.c1, &r3 = a.c0.c2, &r2 = a.c1.c0, &r1 = a.c1.c1, &r5 = a.c1.c2;
+    auto sq4 = [](const Fq2& x, const Fq2& y, Fq2* t0, Fq2* t1) {  // (x + y s)^2 with s^2 = u: t0 = x^2 + u y^2, t1 = 2 x y
+        Fq2 xy = x * y;
+        *t0 = (x + y) * (y.mul_by_nonresidue() + x) - xy - xy.mul_by_nonresidue();
+        *t1 = xy + xy;
+    };
+    Fq2 t0, t1, t2, t3, t4, t5;
+    sq4(r0, r1, &t0, &t1);
+    sq4(r2, r3, &t2, &t3);
+    sq4(r4, r5, &t4, &t5);
+    auto three_minus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = t - z; return d + d + t; };   // 3 t - 2 z
+    auto three_plus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = t + z; return d + d + t; };    // 3 t + 2 z
+    Fq2 z0 = three_minus_two(t0, r0), z1 = three_plus_two(t1, r1);
+    Fq2 z2 = three_plus_two(t5.mul_by_nonresidue(), r2), z3 = three_minus_two(t4, r3);
+    Fq2 z4 = three_minus_two(t2, r4), z5 = three_plus_two(t3, r5);
+    return {{z0, z4, z3}, {z2, z1, z5}};
+}
+// f^((q^12-1)/r): easy part f^((q^6-1)(q^2+1)) by a conjugation, an inversion and the q^2-Frobenius; hard part
+// (q^4 - q^2 + 1) / r (1270 bits) by a 4-bit window over cyclotomic squarings.
 inline Fq12 final_exponentiation(const Fq12& f) {
-    static const uint32_t e[SWM_FINAL_EXP2_LIMBS] = SWM_FINAL_EXP2;
+    static const uint32_t e[SWM_FINAL_EXP_HARD_LIMBS] = SWM_FINAL_EXP_HARD;
     Fq12 g = f.conjugate() * f.inverse();
-    return g.pow(e, SWM_FINAL_EXP2_LIMBS);
+    g = frobenius2(g) * g;
+    Fq12 table[16];
+    table[0] = Fq12::one();
+    table[1] = g;
+    for (int i = 2; i < 16; i++) table[i] = table[i - 1] * g;
+    Fq12 acc = Fq12::one();
+    bool started = false;
+    for (int i = SWM_FINAL_EXP_HARD_LIMBS * 8 - 1; i >= 0; i--) {
+        const unsigned nib = (e[i >> 3] >> ((i & 7) * 4)) & 15u;
+        if (started)
+            for (int k = 0; k < 4; k++) acc = cyclotomic_square(acc);
+        if (nib) {
+            acc = started ? acc * table[nib] : table[nib];
+            started = true;
+        }
+    }
+    return acc;
 }
 inline bool product_of_pairings_is_one(const std::vector<std::pair<G1Affine, G2Affine>>& pairs) {
-    Fq12 f = Fq12::one();
-    for (auto& pq : pairs) f = f * miller_loop(pq.first, pq.second);
-    return final_exponentiation(f).is_one();
+    return final_exponentiation(multi_miller_loop(pairs)).is_one();
 }
 
 }  // namespace swm
