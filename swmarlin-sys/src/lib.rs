@@ -14,4 +14,5 @@
 //! EXPERIMENTAL: written without a Rust toolchain or the arkworks sources at hand; never compiled.  See INTEGRATION.md.
 pub mod ffi;
 pub mod marlin;
+pub mod merkle;
 mod convert;

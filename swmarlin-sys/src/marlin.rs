@@ -126,6 +126,10 @@ impl Drop for State {
 thread_local! {
     static STATE: RefCell<Option<State>> = RefCell::new(None);
 }
+/// Runs one C-ABI call on this thread's context (crate::merkle uses it); `f` returns the library's status code.
+pub(crate) fn with_context(f: impl FnOnce(*mut swm_ctx) -> c_int, what: &'static str) -> Result<()> {
+    with_state(|st| check(f(st.ctx), what, st.ctx)).map_err(|e| anyhow!("{:?}", e))
+}
 fn with_state<T>(f: impl FnOnce(&mut State) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
     STATE.with(|cell| {
         let mut slot = cell.borrow_mut();
