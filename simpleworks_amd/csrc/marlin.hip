@@ -403,17 +403,38 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     out->result = g1_xyzz_identity();  // an empty range (n = 0, or a rank's empty shard) contributes the identity
     const bool force_exchange = getenv("SWM_SHARD_FORCE") != nullptr;  // test hook: exchange with a world of one
     out->sharded = ctx->shard_world > 1 || (force_exchange && (ctx->rccl_comm || ctx->shard_allgather));
-    // Split of a replicated polynomial's commitment over the ranks: by point range (default: the bucket stage then runs in
-    // full on every rank), or — SWM_SHARD_BUCKETS=1, table schedule only — by BUCKET range (every rank has all coefficients:
-    // all points stay, the digits are filtered; accumulation, sort and bucket stage all shrink with the number of ranks).
-    // Measured per rank on one GPU (tools/ubench/shard_emulate.py, profiles/r03_shard_emulate.jsonl): the bucket split balances
-    // two ranks better (36.5 vs 38.4 ms at 2^20) and loses at eight (2^22: 69.6 vs 66.8 ms — 1/8 of the buckets at full
-    // depth are too few lanes for the accumulation), so it is not the default.  (Read per call: tests switch it.)
+    // Split of a replicated polynomial's commitment over the ranks (every rank holds all n coefficients):
+    //  * CYCLIC (default, table schedule): rank g takes the coefficients g, g + G, ... (strided scalars, table rows g + G j).
+    //    Polynomials are zero-padded at the top, so a range split hands the last ranks the zeros and the first ranks the
+    //    work (2^20, G = 8: 196 M mixed additions on rank 0, 145 M on rank 7); the cyclic split gives every rank the same;
+    //  * by point RANGE (no table, or SWM_SHARD_RANGE=1): the r02 split;
+    //  * by BUCKET range (SWM_SHARD_BUCKETS=1, table schedule): all points stay, the digits are filtered; accumulation, sort
+    //    AND bucket stage shrink with G.  Measured per rank on one GPU (tools/ubench/shard_emulate.py): it balances two ranks
+    //    and loses at eight (1/8 of the buckets at full depth are too few lanes for the accumulation), so it is not the default.
+    // (The switches are read per call: tests flip them.)
     const bool by_bucket = getenv("SWM_SHARD_BUCKETS") && atoi(getenv("SWM_SHARD_BUCKETS")) != 0;
-    if (out->sharded && by_bucket && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous()) {
+    const bool by_range = getenv("SWM_SHARD_RANGE") && atoi(getenv("SWM_SHARD_RANGE")) != 0;
+    const bool table_split = out->sharded && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous();
+    size_t first = 0, count = n;   // scalars coeffs[first + i * stride], i < count
+    if (table_split && by_bucket) {
         tab.shard_rank = ctx->shard_rank;
         tab.shard_world = ctx->shard_world;
-    } else if (out->sharded) {
+    } else if (table_split && !by_range) {
+        const size_t G = ctx->shard_world, g = ctx->shard_rank;
+        first = g;
+        count = n > g ? (n - g + G - 1) / G : 0;
+        tab.offset += g;
+        tab.blk_log = 0;
+        tab.bstride = G;
+        tab.scalar_stride = G;
+        if (count && !msm_flat_applies(tab, count)) {  // too few points for the table schedule: fall back to the range
+            tab = MsmTable();
+            pk.bases_at(offset, n, &b, &b28, &tab);
+            first = 0;
+            count = n;
+        }
+    }
+    if (out->sharded && tab.scalar_stride == 1 && tab.shard_world <= 1) {
         lo = (size_t)(((unsigned __int128)n * ctx->shard_rank) / ctx->shard_world);
         hi = (size_t)(((unsigned __int128)n * (ctx->shard_rank + 1)) / ctx->shard_world);
     }
@@ -425,6 +446,11 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // whose tail overlaps the next commitment's accumulation.
     static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
     const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? 200000 : 32768);
+    if (tab.scalar_stride != 1) {
+        rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, coeffs + first, count, 1, &out->job, MsmInfMask(),
+                                  (long)count <= batch_below, tab));
+        return;
+    }
     tab.offset += lo;
     rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));

@@ -147,9 +147,9 @@ struct DigitShard {
 };
 __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
                                                   uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
-                                                  size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh) {
+                                                  size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh, size_t sstride) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = scalars[i];
+        Fr s = scalars[i * sstride];
         bool ge = true;  // s >= r ?
 #pragma unroll
         for (int k = 7; k >= 0; k--) {
@@ -1786,6 +1786,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->blk_lo = 0;
     job->blk_hi = red_blocks;
     job->blk_low = 0;
+    if (tab.scalar_stride != 1 && !flat) return set_err(ctx, SWM_ERR_INTERNAL, "msm: strided scalars need the table schedule");
     DigitShard dshard{};
     if (tab.shard_world > 1) {
         if (!flat || !tab.contiguous()) return set_err(ctx, SWM_ERR_INTERNAL, "msm: a bucket-range split needs the table schedule");
@@ -1936,7 +1937,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
-               big_count + 1 /* zeroed with the histogram */, dshard);
+               big_count + 1 /* zeroed with the histogram */, dshard, tab.scalar_stride);
     const unsigned scan_tiles_ = scan_tiles;
     if (flat) {
         // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the

@@ -602,11 +602,11 @@ def test_sharded_prover_two_processes_real_kernels(tmp_path):
 @pytest.mark.parametrize("world", [3, 8])
 def test_sharded_prover_with_window_tables_2p17(M, S, W, world, monkeypatch):
     """Keys of >= 2^17 SRS powers carry the precomputed window multiples (of a width chosen for the rank's share of the points).
-    The commitments of a replicated polynomial are split by point range (a rank's shard starts at a table OFFSET) or, with
-    SWM_SHARD_BUCKETS=1, by BUCKET range (every rank keeps the digits of its share of the bucket-stage workgroups; the narrow
-    top window by point range): thread-ranks with uneven shares must reproduce the single-context bytes in both forms, and
-    every non-zero digit must be accumulated by exactly one rank — the ranks' mixed additions add up to the same total in
-    both forms."""
+    The commitments of a replicated polynomial are split cyclically (rank g takes the coefficients g, g + G, ...: strided
+    scalars and table rows), by point range (SWM_SHARD_RANGE=1: a rank's shard starts at a table OFFSET) or by BUCKET range
+    (SWM_SHARD_BUCKETS=1: every rank keeps the digits of its share of the bucket-stage workgroups): thread-ranks with uneven
+    shares must reproduce the single-context bytes in all three forms, and every non-zero digit must be accumulated by exactly
+    one rank — the ranks' mixed additions add up to the same total in all of them."""
     n = 1 << 17
     cs, public = W.synthetic_r1cs(n, 0x1717, 0x7171)
 
@@ -629,8 +629,9 @@ def test_sharded_prover_with_window_tables_2p17(M, S, W, world, monkeypatch):
     vk1, proof1, work1 = build(single_ctx)
     single_ctx.close()
     totals = []
-    for by_bucket in (0, 1):
-        monkeypatch.setenv("SWM_SHARD_BUCKETS", str(by_bucket))
+    for split in ({}, {"SWM_SHARD_RANGE": "1"}, {"SWM_SHARD_BUCKETS": "1"}):   # cyclic (default), point ranges, bucket ranges
+        for k in ("SWM_SHARD_RANGE", "SWM_SHARD_BUCKETS"):
+            monkeypatch.setenv(k, split.get(k, "0"))
         ranks = _run_sharded(world, build)
         for vk_b, proof_b, _ in ranks:
             assert vk_b == vk1
@@ -638,7 +639,7 @@ def test_sharded_prover_with_window_tables_2p17(M, S, W, world, monkeypatch):
         adds = [r[2]["msm_adds"] for r in ranks]
         assert max(adds) < 2.2 * sum(adds) / world            # the shares are of the same order (uniform scalars)
         totals.append(sum(adds))
-    assert totals[0] == totals[1] >= work1["msm_adds"], (totals, work1["msm_adds"])   # narrower tables: more windows per point
+    assert totals[0] == totals[1] == totals[2] >= work1["msm_adds"], (totals, work1["msm_adds"])   # narrower tables: more windows per point
     assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
 
 

@@ -32,8 +32,9 @@ python3 tools/small_proofs.py 10 12 14 16 18 > $out/small_proofs.log 2>&1
 python3 tools/ubench/merkle_build.py 18 5 14 > $out/merkle_build.json 2> $out/merkle_build.err
 rocprofv3 --kernel-trace --stats -d $out/prof_merkle_build -o run --output-format csv -- python3 tools/ubench/merkle_build.py 18 3 0 > $out/prof_merkle_build.log 2>&1
 # what ONE rank of a proof split over G = 1, 2, 4, 8 ranks computes (exchange emulated on the host): strong-scaling bound, DESIGN.md section 6
-SWM_SHARD_R1_OFF=1 python3 tools/ubench/shard_emulate.py 20 8 2> $out/shard_emulate.err | grep "^{" > $out/shard_emulate.jsonl
-SWM_SHARD_R1_OFF=1 SWM_SHARD_BUCKETS=1 python3 tools/ubench/shard_emulate.py 20 8 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
-SWM_SHARD_R1_OFF=1 python3 tools/ubench/shard_emulate.py 22 3 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
-SWM_SHARD_R1_OFF=1 SWM_SHARD_BUCKETS=1 python3 tools/ubench/shard_emulate.py 22 3 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
+for lg in "20 8" "22 3"; do
+  SWM_SHARD_R1_OFF=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
+  SWM_SHARD_R1_OFF=1 SWM_SHARD_RANGE=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
+  SWM_SHARD_R1_OFF=1 SWM_SHARD_BUCKETS=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
+done
 ls -R $out | head -40

@@ -3,7 +3,7 @@ exchange callback hands back this rank's own contribution in every slot (so the 
 of interest: everything a rank computes, with the exchange reduced to a host memcpy).  What the number says: the time one
 rank needs when the other G - 1 GPUs work beside it, i.e. the strong-scaling bound of the split (xGMI exchanges of 192 B x
 commitments per round are microseconds).  Prints one JSON line per (G, rank).
-usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_BUCKETS=1 -> bucket-range split, SWM_SHARD_R1_OFF"""
+usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_RANGE=1 / SWM_SHARD_BUCKETS=1 -> point-range / bucket-range split instead of the cyclic one, SWM_SHARD_R1_OFF"""
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
@@ -15,7 +15,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 1 << lg
 ctx = M.default_context()
 cs, public = W.synthetic_r1cs(n, 0x1234567, 0x7654321)
-mode = "buckets" if os.environ.get("SWM_SHARD_BUCKETS", "0") not in ("", "0") else "points"
+mode = ("buckets" if os.environ.get("SWM_SHARD_BUCKETS", "0") not in ("", "0") else
+        "ranges" if os.environ.get("SWM_SHARD_RANGE", "0") not in ("", "0") else "cyclic")
 for G in ([int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]):
     # the key is built by a context that already knows its world: the table width follows the rank's share (msm_install_bases)
     ctx.set_msm_sharding(0, G, None if G == 1 else (lambda send, G=G: bytes(send) * G))
