@@ -311,6 +311,12 @@ int swm_selftest_mul(swm_ctx *ctx, int which, const uint64_t *a, const uint64_t 
 int swm_selftest_g1_add(swm_ctx *ctx, const uint64_t *a_xy, const uint64_t *b_xy, uint64_t *out_jac, size_t n);
 /* Throughput probe: `iters` dependent Montgomery multiplications per thread on `threads` threads; returns ms. */
 int swm_selftest_mul_throughput(swm_ctx *ctx, int which, size_t threads, int iters, float *ms);
+/* Host pairing code of the verifier against itself (no GPU): bit k of *failed is set when identity k does not hold —
+ * 0 cyclotomic squaring == plain squaring on the cyclotomic subgroup; 1 the 4-bit-window hard part == the plain power by
+ * (q^6 + 1) / r; 2 the addition chain == the cube of that; 3 q-Frobenius twice == q^2-Frobenius; 4 e(2P, Q) == e(P, Q)^2 and
+ * e(P, Q) != 1; 5 e(P, Q) e(-P, Q) == 1 and e(P, Q)^2 != 1 through product_of_pairings_is_one; 6 the shared Miller
+ * accumulator of two pairs == the product of two single loops. */
+int swm_selftest_pairing(unsigned *failed);
 
 #ifdef __cplusplus
 }

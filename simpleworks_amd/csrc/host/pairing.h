@@ -224,9 +224,29 @@ inline Fq12 cyclotomic_square(const Fq12& a) {
     Fq2 z4 = three_minus_two(t2, r4), z5 = three_plus_two(t3, r5);
     return {{z0, z4, z3}, {z2, z1, z5}};
 }
-// f^((q^12-1)/r): easy part f^((q^6-1)(q^2+1)) by a conjugation, an inversion and the q^2-Frobenius; hard part
-// (q^4 - q^2 + 1) / r (1270 bits) by a 4-bit window over cyclotomic squarings.
-inline Fq12 final_exponentiation(const Fq12& f) {
+// q-Frobenius: the Fq2 coefficients are conjugated and v^i w^j is multiplied by zeta^(2 i + j), zeta = u^((q-1)/6) in Fq2
+inline Fq12 frobenius1(const Fq12& a) {
+    static const uint32_t z0[12] = SWM_FROB1_ZETA_C0_MONT, z1[12] = SWM_FROB1_ZETA_C1_MONT;
+    static const Fq2 g1 = {fq_from_limbs(z0), fq_from_limbs(z1)};
+    static const Fq2 g2 = g1 * g1, g3 = g2 * g1, g4 = g3 * g1, g5 = g4 * g1;
+    auto cj = [](const Fq2& x) { return Fq2{x.c0, fp_neg(x.c1)}; };
+    return {{cj(a.c0.c0), cj(a.c0.c1) * g2, cj(a.c0.c2) * g4}, {cj(a.c1.c0) * g1, cj(a.c1.c1) * g3, cj(a.c1.c2) * g5}};
+}
+// g^x for the curve parameter x (64 bits, seven of them set) in the cyclotomic subgroup
+inline Fq12 cyclotomic_exp_x(const Fq12& g) {
+    const uint64_t X = SWM_BLS_X;
+    int top = 63;
+    while (!((X >> top) & 1)) top--;
+    Fq12 acc = g;
+    for (int i = top - 1; i >= 0; i--) {
+        acc = cyclotomic_square(acc);
+        if ((X >> i) & 1) acc = acc * g;
+    }
+    return acc;
+}
+// The plain form of the hard part: (q^4 - q^2 + 1) / r (1270 bits) by a 4-bit window over cyclotomic squarings.  Kept as the
+// reference the addition chain below is checked against (tests: swm_selftest_pairing).
+inline Fq12 final_exponentiation_windowed(const Fq12& f) {
     static const uint32_t e[SWM_FINAL_EXP_HARD_LIMBS] = SWM_FINAL_EXP_HARD;
     Fq12 g = f.conjugate() * f.inverse();
     g = frobenius2(g) * g;
@@ -246,6 +266,19 @@ inline Fq12 final_exponentiation(const Fq12& f) {
         }
     }
     return acc;
+}
+// f^(3 (q^12-1)/r): easy part f^((q^6-1)(q^2+1)) by a conjugation, an inversion and the q^2-Frobenius; hard part by the
+// BLS12 addition chain  3 (q^4 - q^2 + 1) / r = (x - 1)^2 (x + q) (x^2 + q^2 - 1) + 3  (Hayashida, Hayasaka, Teruya 2020): five
+// exponentiations by the 64-bit x over cyclotomic squarings, inverses by conjugation.  The CUBE of the reduced pairing:
+// 3 does not divide r, so it is one exactly when the pairing is — and that is the only question the verifier asks.
+inline Fq12 final_exponentiation(const Fq12& f) {
+    Fq12 g = f.conjugate() * f.inverse();
+    g = frobenius2(g) * g;                                                  // in the cyclotomic subgroup from here
+    Fq12 t0 = cyclotomic_exp_x(g) * g.conjugate();                          // g^(x-1)
+    Fq12 t1 = cyclotomic_exp_x(t0) * t0.conjugate();                        // g^((x-1)^2)
+    Fq12 t2 = cyclotomic_exp_x(t1) * frobenius1(t1);                        // ^(x+q)
+    Fq12 t3 = cyclotomic_exp_x(cyclotomic_exp_x(t2)) * frobenius2(t2) * t2.conjugate();   // ^(x^2+q^2-1)
+    return t3 * cyclotomic_square(g) * g;                                   // * g^3
 }
 inline bool product_of_pairings_is_one(const std::vector<std::pair<G1Affine, G2Affine>>& pairs) {
     return final_exponentiation(multi_miller_loop(pairs)).is_one();

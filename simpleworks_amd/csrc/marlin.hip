@@ -2319,3 +2319,43 @@ int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ pairing self-test (host only)
+extern "C" int swm_selftest_pairing(unsigned* failed) {
+    using namespace swm;
+    if (!failed) return SWM_ERR_INVALID_ARG;
+    static const uint32_t gx[12] = SWM_G1_GEN_X_MONT, gy[12] = SWM_G1_GEN_Y_MONT;
+    G1Affine P;
+    for (int i = 0; i < 12; i++) {
+        P.x.v[i] = gx[i];
+        P.y.v[i] = gy[i];
+    }
+    G2Affine Q = g2_identity();  // a point of the prime-order subgroup of the twist: first abscissa s + u with a square, cofactor cleared
+    for (unsigned s = 1; s < 200 && Q.inf; s++) {
+        Fq2 x = {fp_from_u64<Fq>(s), fp_from_u64<Fq>(1)}, y;
+        if (fq2_sqrt(x * x * x + g2_coeff_b(), &y)) {
+            static const uint32_t cof[SWM_G2_COFACTOR_LIMBS] = SWM_G2_COFACTOR;
+            Q = g2_mul({x, y, false}, cof, SWM_G2_COFACTOR_LIMBS);
+        }
+    }
+    if (Q.inf) return SWM_ERR_INTERNAL;
+    unsigned bad = 0;
+    const Fq12 f = miller_loop(P, Q);
+    Fq12 g = f.conjugate() * f.inverse();
+    g = frobenius2(g) * g;
+    if (!(cyclotomic_square(g) == g * g)) bad |= 1u << 0;
+    static const uint32_t e2[SWM_FINAL_EXP2_LIMBS] = SWM_FINAL_EXP2;
+    const Fq12 plain = (f.conjugate() * f.inverse()).pow(e2, SWM_FINAL_EXP2_LIMBS);
+    const Fq12 win = final_exponentiation_windowed(f);
+    if (!(win == plain)) bad |= 1u << 1;
+    const Fq12 e = final_exponentiation(f);
+    if (!(e == win * win * win)) bad |= 1u << 2;
+    if (!(frobenius1(frobenius1(f)) == frobenius2(f))) bad |= 1u << 3;
+    const G1Affine P2 = g1_mul_fr(P, fp_from_u64<Fr>(2));
+    if (!(final_exponentiation(miller_loop(P2, Q)) == e * e) || e.is_one()) bad |= 1u << 4;
+    if (!product_of_pairings_is_one({{P, Q}, {g1_neg(P), Q}}) || product_of_pairings_is_one({{P, Q}, {P, Q}})) bad |= 1u << 5;
+    if (!(multi_miller_loop({{P, Q}, {P2, Q}}) == f * miller_loop(P2, Q))) bad |= 1u << 6;
+    *failed = bad;
+    return SWM_OK;
+}
+

@@ -255,3 +255,12 @@ def test_pedersen_setup_of_the_product_matches_the_model():
     assert hashlib.sha256(raw(leaf)).hexdigest() == g["leaf_generators_sha256"]
     assert hashlib.sha256(raw(inner)).hexdigest() == g["two_to_one_generators_sha256"]
     assert [hex(c) for c in inner[127][3]] == g["two_to_one_generator_127_3"]
+
+
+def test_host_pairing_identities():
+    """The verifier's pairing code against itself (host only, include/swmarlin.h swm_selftest_pairing): cyclotomic squaring,
+    the windowed hard part against the plain power, the addition chain against its cube, the two Frobenius maps,
+    bilinearity, and the shared Miller accumulator of two pairs."""
+    failed = ctypes.c_uint(0xFFFF)
+    assert L.load_library().swm_selftest_pairing(ctypes.byref(failed)) == 0
+    assert failed.value == 0, bin(failed.value)
