@@ -53,5 +53,6 @@ def test_switches_select_equivalent_paths():
                 {"SWM_SAMPLE_TIGHT": "1"},    # the bulk sampler's retry branch, several rounds per draw
                 {"SWM_NTT_LAZY": "0"},        # 8 x 32-bit Comba transform instead of the 9 x 29-bit lazy one
                 {"SWM_NTT_PASS_TABLES": "0"},  # lazy transform with the two-level twiddle product on every pass
-                {"SWM_RALPHA_TRANSFORMS": "1"}):  # r(alpha, X) on 4|H| by two transforms instead of the closed form
+                {"SWM_RALPHA_TRANSFORMS": "1"},  # r(alpha, X) on 4|H| by two transforms instead of the closed form
+                {"SWM_MSM_TABLE_C": "15"}):      # narrower window tables (what a rank of a sharded proof takes)
         assert _run(env) == ref, env
