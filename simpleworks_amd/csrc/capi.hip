@@ -231,6 +231,15 @@ int shard_alltoall_dev(swm_ctx* ctx, const void* d_send, void* d_recv, size_t by
         SWM_HIP(ctx, hipMemcpyAsync(d_recv, d_send, bytes_per_peer, hipMemcpyDeviceToDevice, ctx->stream));
         return SWM_OK;
     }
+    // SWM_SHARD_EMULATE (measurement hook, tools/ubench/ntt_sharded_one.py): ONE context plays rank R of G and every slot of a
+    // device exchange receives this rank's own chunk by a device copy — wrong values, the right amount of work on this rank
+    static const bool emulate = getenv("SWM_SHARD_EMULATE") != nullptr;
+    if (emulate && !ctx->rccl_comm) {
+        for (unsigned p = 0; p < world; p++)
+            SWM_HIP(ctx, hipMemcpyAsync((char*)d_recv + (size_t)p * bytes_per_peer, (const char*)d_send + (size_t)rank * bytes_per_peer,
+                                        bytes_per_peer, hipMemcpyDeviceToDevice, ctx->stream));
+        return SWM_OK;
+    }
     if (ctx->rccl_comm) {
         if (!rccl().Send || !rccl().Recv || !rccl().GroupStart || !rccl().GroupEnd)
             return set_err(ctx, SWM_ERR_INTERNAL, "librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
@@ -262,6 +271,12 @@ int shard_allgather_dev(swm_ctx* ctx, const void* d_send, size_t bytes, void* d_
     ctx->stat_exchange_bytes += bytes;
     if (world <= 1 && !(ctx->rccl_comm && getenv("SWM_SHARD_FORCE"))) {
         SWM_HIP(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return SWM_OK;
+    }
+    static const bool emulate = getenv("SWM_SHARD_EMULATE") != nullptr;
+    if (emulate && !ctx->rccl_comm) {
+        for (unsigned p = 0; p < world; p++)
+            SWM_HIP(ctx, hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         return SWM_OK;
     }
     if (ctx->rccl_comm) {

@@ -1208,8 +1208,24 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     if (!mask_late) flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
     // Challenge-independent part of round 2, issued now so that it runs under the round-1 commitments instead of
     // after them: z_A, z_B and z = w v_X + x in evaluation form on the 4|H| domain.
+    // Round 2 over G ranks (r03): the four transforms of size 4|H| into the product domain, the pointwise outer-sumcheck form and
+    // the transform back run on a rank's share — CYCLIC coefficients (every rank holds the polynomials: it takes g, g + G, ...)
+    // -> BLOCKS evaluations by ONE all-to-all each (ntt_sharded_run), pointwise on the blocks, BLOCKS -> CYCLIC back; the mask
+    // and the division by v_H are local in the CYCLIC layout (G divides |H|: index j + k|H| stays on its rank).  h_1 and X g_1 are
+    // all-gathered afterwards (4|H| x 32 B per proof): the openings work on whole polynomials.  SWM_SHARD_R2_OFF disables it.
+    const bool shard_r2 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && logM >= 2 * slog_g + 4 && !getenv("SWM_SHARD_R2_OFF");
+    const size_t Mloc = shard_r2 ? M / SG : M, Mblk = shard_r2 ? Mloc / SG : M;
+    const size_t s_rank = ctx->shard_rank, s_world = SG;
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
-        return dv_ntt_from(ctx, coeffs, n, logM, false);
+        if (!shard_r2) return dv_ntt_from(ctx, coeffs, n, logM, false);
+        DVec loc(ctx, Mloc);
+        Fr* out = loc.p;
+        ew(ctx, "shard_take_cyclic", Mloc, [=] __device__(size_t j) {
+            const size_t i = s_rank + s_world * j;
+            out[j] = i < n ? coeffs[i] : fp_zero<Fr>();
+        });
+        rc_check(ctx, ntt_sharded_run(ctx, loc.p, logM, 0, 0));
+        return loc;
     };
     DVec e_za = on_mul_domain(za_poly.p, H + 1);
     DVec e_zb = on_mul_domain(zb_poly.p, H + 1);
@@ -1263,7 +1279,36 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         for (unsigned i = 0; i < logM; i++) a4h = fp_sqr(a4h);
         ra_closed_form = !fp_is_one(a4h) && !getenv("SWM_RALPHA_TRANSFORMS");
     }
-    if (ra_closed_form) {
+    if (ra_closed_form && shard_r2) {
+        // the rank's BLOCKS indices of the 4|H| domain for the product form; r(alpha, .) on H (every rank needs all of it for the
+        // transposed mat-vecs) by its own inversion over |H| points
+        e_ra = DVec(ctx, Mloc);
+        PowTable wt = root_pow_table(ctx, logM);
+        Fr* out = e_ra.p;
+        const size_t mloc = Mloc, mblk = Mblk;
+        ew(ctx, "r_alpha_den", Mloc, [=] __device__(size_t p) {
+            const size_t i = mloc * (p / mblk) + s_rank * mblk + (p % mblk);
+            out[p] = fp_sub(alpha, wt.at(i));
+        });
+        rc_check(ctx, batch_inverse_run(ctx, out, Mloc));
+        Fr aH = alpha;
+        for (unsigned i = 0; i < pk.logH; i++) aH = fp_sqr(aH);
+        HDomain d4(M);
+        Fr i4 = d4.gen;
+        for (unsigned i = 0; i < pk.logH; i++) i4 = fp_sqr(i4);
+        Fr n0 = fp_sub(aH, fp_one<Fr>()), n1 = fp_sub(aH, i4), n2 = fp_sub(aH, fp_sqr(i4)), n3 = fp_sub(aH, fp_mul(fp_sqr(i4), i4));
+        ew(ctx, "r_alpha_scale", Mloc, [=] __device__(size_t p) {
+            const size_t i = mloc * (p / mblk) + s_rank * mblk + (p % mblk);
+            const unsigned q = (unsigned)(i & 3);
+            out[p] = fp_mul(out[p], q == 0 ? n0 : q == 1 ? n1 : q == 2 ? n2 : n3);
+        });
+        PowTable wh = root_pow_table(ctx, pk.logH);
+        Fr* rh = r_alpha_evals.p;
+        ew(ctx, "r_alpha_den", H, [=] __device__(size_t i) { rh[i] = fp_sub(alpha, wh.at(i)); });
+        rc_check(ctx, batch_inverse_run(ctx, rh, H));
+        Fr vh = dh.vanishing(alpha);
+        ew(ctx, "r_alpha_scale", H, [=] __device__(size_t i) { rh[i] = fp_mul(rh[i], vh); });
+    } else if (ra_closed_form) {
         e_ra = DVec(ctx, M);
         PowTable wt = root_pow_table(ctx, logM);
         Fr* out = e_ra.p;
@@ -1309,7 +1354,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     CommitJob j2[3];
     P_t.p = t_poly.p; P_t.n = H;
     begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
-    DVec q1(ctx, M);
+    DVec q1(ctx, Mloc);  // the whole product domain, or the rank's share of it (shard_r2)
     {
         if (!ra_closed_form) {
             DVec ra_poly = dv_ntt_from(ctx, r_alpha_evals.p, H, pk.logH, true);
@@ -1318,7 +1363,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         DVec e_t = on_mul_domain(t_poly.p, H);
         Fr* out = q1.p;
         const Fr *pra = e_ra.p, *pza = e_za.p, *pzb = e_zb.p, *pt = e_t.p, *pz = e_z.p;
-        ew(ctx, "round2_pointwise", M, [=] __device__(size_t i) {
+        ew(ctx, "round2_pointwise", Mloc, [=] __device__(size_t i) {
             Fr a = pza[i], b = pzb[i];
             Fr summed = fp_add(fp_add(fp_mul(eta_c, fp_mul(a, b)), fp_mul(eta_a, a)), fp_mul(eta_b, b));
             out[i] = fp_sub(fp_mul(pra[i], summed), fp_mul(pz[i], pt[i]));
@@ -1326,13 +1371,45 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         e_za.release();
         e_zb.release();
         e_z.release();
-        dv_ntt(ctx, q1, logM, true);
         const Fr* mp = mask.p;
-        ew(ctx, "q1_add_mask", mask_len, [=] __device__(size_t i) { out[i] = fp_add(out[i], mp[i]); });
+        if (shard_r2) {
+            rc_check(ctx, ntt_sharded_run(ctx, q1.p, logM, 1, 1));  // BLOCKS evaluations -> CYCLIC coefficients: q1[j] = q_1[rank + G j]
+            ew(ctx, "q1_add_mask", Mloc, [=] __device__(size_t j) {
+                const size_t i = s_rank + s_world * j;
+                if (i < mask_len) out[j] = fp_add(out[j], mp[i]);
+            });
+        } else {
+            dv_ntt(ctx, q1, logM, true);
+            ew(ctx, "q1_add_mask", mask_len, [=] __device__(size_t i) { out[i] = fp_add(out[i], mp[i]); });
+        }
     }
     // (h_1, X g_1) = divide_by_vanishing_poly(q_1, H)
     DVec h1(ctx, 3 * H), g1x(ctx, H);
-    {
+    if (shard_r2) {
+        // local in the CYCLIC layout: coefficient j + k|H| of q_1 sits on the same rank, |H| / G places further
+        const size_t Hl = H / SG;
+        DVec loc(ctx, 4 * Hl), all(ctx, 4 * Hl * SG);  // [h_1 share: 3 Hl | (X g_1) share: Hl]
+        Fr* pl = loc.p;
+        const Fr* q = q1.p;
+        const size_t mloc = Mloc;
+        ew(ctx, "div_vh", 3 * Hl, [=] __device__(size_t j) {
+            Fr acc = q[j + Hl];
+            if (j + 2 * Hl < mloc) acc = fp_add(acc, q[j + 2 * Hl]);
+            if (j + 3 * Hl < mloc) acc = fp_add(acc, q[j + 3 * Hl]);
+            pl[j] = acc;
+            if (j < Hl) pl[3 * Hl + j] = fp_add(q[j], acc);
+        });
+        rc_check(ctx, shard_allgather_dev(ctx, loc.p, 4 * Hl * sizeof(Fr), all.p));
+        Fr* ph = h1.p;
+        Fr* pg = g1x.p;
+        const Fr* pa = all.p;
+        const unsigned lg = slog_g;
+        ew(ctx, "shard_interleave", 3 * H, [=] __device__(size_t i) {
+            const size_t r = i & (((size_t)1 << lg) - 1), j = i >> lg;
+            ph[i] = pa[r * 4 * Hl + j];
+            if (i < Hl << lg) pg[i] = pa[r * 4 * Hl + 3 * Hl + j];  // |H| of them
+        });
+    } else {
         Fr* ph = h1.p;
         Fr* pg = g1x.p;
         const Fr* q = q1.p;

@@ -763,8 +763,9 @@ def test_sharded_ntt_vs_oracle(world, log_n):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
     """One proof over 2 / 4 contexts with the sharded round 1 (mat-vec by rows of the BLOCKS layout, sharded inverse
-    transform, commitment of CYCLIC coefficients in place, one all-gather for the replicated rest): the bytes of the Python
-    model at 2^12 constraints, and the exchanges did take place."""
+    transform, commitment of CYCLIC coefficients in place, one all-gather for the replicated rest) and the sharded round 2 (the
+    four transforms into the product domain, the pointwise form and the transform back on a rank's share, mask and division by
+    v_H local in the CYCLIC layout): the bytes of the Python model at 2^12 constraints, and the exchanges did take place."""
     case = golden("marlin_large.json")["synthetic_2p12"]
     n = case["num_constraints"]
     cs, public = W.synthetic_r1cs(n, h2i(case["a"]), h2i(case["b"]))
@@ -784,7 +785,9 @@ def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
     for vk_hex, proof_hex, exchanges in _run_sharded(world, build):
         assert vk_hex == case["vk"]
         assert proof_hex == case["proof"]
-        assert exchanges >= 4 + 4   # per-round partial sums + (all-to-all, all-gather) for z_A and for z_B
+        # per-round partial sums (4) + (all-to-all, all-gather) for z_A and for z_B (4) + round 2: four transforms into the product
+        # domain and one back (5 all-to-alls) and the all-gather of h_1 and X g_1
+        assert exchanges >= 4 + 4 + 6, exchanges
 
 
 def test_reference_test_circuit_example(M, S, W):

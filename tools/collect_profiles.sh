@@ -37,4 +37,5 @@ for lg in "20 8" "22 3"; do
   SWM_SHARD_R1_OFF=1 SWM_SHARD_RANGE=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
   SWM_SHARD_R1_OFF=1 SWM_SHARD_BUCKETS=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
 done
+SWM_SHARD_EMULATE=1 python3 tools/ubench/ntt_sharded_one.py 22 24 > $out/ntt_sharded_one.jsonl 2> $out/ntt_sharded_one.err
 ls -R $out | head -40

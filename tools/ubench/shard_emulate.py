@@ -5,6 +5,10 @@ rank needs when the other G - 1 GPUs work beside it, i.e. the strong-scaling bou
 commitments per round are microseconds).  Prints one JSON line per (G, rank).
 usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_RANGE=1 / SWM_SHARD_BUCKETS=1 -> point-range / bucket-range split instead of the cyclic one, SWM_SHARD_R1_OFF"""
 import json, os, sys, time
+# the sharded rounds 1 and 2 exchange DATA the rest of the proof depends on (an emulated exchange makes the prover's own checks
+# fail): they are measured apart (tools/ubench/ntt_sharded_one.py); here every transform runs whole on the rank
+os.environ.setdefault("SWM_SHARD_R1_OFF", "1")
+os.environ.setdefault("SWM_SHARD_R2_OFF", "1")
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import simpleworks_amd as swm
