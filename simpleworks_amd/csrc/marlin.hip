@@ -1474,7 +1474,58 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     begin_commit(P_g2.p, P_g2.n, true, K - 2, false, &j3[0]);  // overlaps the 4|K|-domain work below
     // h_2 = (a - b f) / v_K via evaluations on the 4K domain
     DVec h2(ctx, 3 * K);
-    {
+    // Round 3 over G ranks, the same way as round 2 (shard_r2 above): f into the 4|K| domain, the pointwise form a - b f (the key's
+    // twelve arrays read at the rank's BLOCKS indices) and the transform back on a rank's share; the division by v_K is local in
+    // the CYCLIC layout; h_2 is all-gathered afterwards (3|K| x 32 B).
+    const bool shard_r3 = shard_r2 && pk.logB >= 2 * slog_g + 4 && K % SG == 0;
+    if (shard_r3) {
+        const size_t Bloc = Bsz / SG, Bblk = Bloc / SG, Kl = K / SG;
+        DVec e_f(ctx, Bloc);
+        {
+            Fr* o = e_f.p;
+            const Fr* src = f.p;
+            ew(ctx, "shard_take_cyclic", Bloc, [=] __device__(size_t j) {
+                const size_t i = s_rank + s_world * j;
+                o[j] = i < K ? src[i] : fp_zero<Fr>();
+            });
+            rc_check(ctx, ntt_sharded_run(ctx, e_f.p, pk.logB, 0, 0));
+        }
+        DVec ab(ctx, Bloc);
+        Fr* out = ab.p;
+        const Fr* pf = e_f.p;
+        const Fr *ar_ = pk.ar[0].row_B.p, *ac_ = pk.ar[0].col_B.p, *arc = pk.ar[0].row_col_B.p, *av = pk.ar[0].val_B.p;
+        const Fr *br_ = pk.ar[1].row_B.p, *bc_ = pk.ar[1].col_B.p, *brc = pk.ar[1].row_col_B.p, *bv = pk.ar[1].val_B.p;
+        const Fr *cr_ = pk.ar[2].row_B.p, *cc_ = pk.ar[2].col_B.p, *crc = pk.ar[2].row_col_B.p, *cv = pk.ar[2].val_B.p;
+        Fr ab_const = fp_mul(beta, alpha);
+        ew(ctx, "round3_pointwise_B", Bloc, [=] __device__(size_t p) {
+            const size_t i = Bloc * (p / Bblk) + s_rank * Bblk + (p % Bblk);  // BLOCKS: the rank's indices of the 4|K| domain
+            Fr da = fp_add(fp_sub(fp_sub(ab_const, fp_mul(ar_[i], alpha)), fp_mul(beta, ac_[i])), arc[i]);
+            Fr db = fp_add(fp_sub(fp_sub(ab_const, fp_mul(br_[i], alpha)), fp_mul(beta, bc_[i])), brc[i]);
+            Fr dc = fp_add(fp_sub(fp_sub(ab_const, fp_mul(cr_[i], alpha)), fp_mul(beta, cc_[i])), crc[i]);
+            Fr dbc = fp_mul(db, dc);
+            Fr t = fp_add(fp_add(fp_mul(fp_mul(eta_a, av[i]), dbc), fp_mul(fp_mul(fp_mul(eta_b, bv[i]), da), dc)),
+                          fp_mul(fp_mul(fp_mul(eta_c, cv[i]), da), db));
+            Fr a_val = fp_mul(vhab, t);
+            Fr b_val = fp_mul(da, dbc);
+            out[p] = fp_sub(a_val, fp_mul(b_val, pf[p]));
+        });
+        rc_check(ctx, ntt_sharded_run(ctx, ab.p, pk.logB, 1, 1));  // -> CYCLIC coefficients: ab[j] = (a - b f)[rank + G j]
+        DVec loc(ctx, 3 * Kl), all(ctx, 3 * Kl * SG);
+        Fr* pl = loc.p;
+        const Fr* q = ab.p;
+        ew(ctx, "div_vk", 3 * Kl, [=] __device__(size_t j) {
+            Fr acc = fp_zero<Fr>();
+            for (uint64_t i = 1; j + i * Kl < Bloc; i++) acc = fp_add(acc, q[j + i * Kl]);
+            pl[j] = acc;
+        });
+        rc_check(ctx, shard_allgather_dev(ctx, loc.p, 3 * Kl * sizeof(Fr), all.p));
+        Fr* ph = h2.p;
+        const Fr* pa = all.p;
+        const unsigned lg = slog_g;
+        ew(ctx, "shard_interleave", 3 * K, [=] __device__(size_t i) {
+            ph[i] = pa[(i & (((size_t)1 << lg) - 1)) * 3 * Kl + (i >> lg)];
+        });
+    } else {
         DVec e_f = dv_ntt_from(ctx, f.p, K, pk.logB, false);
         DVec ab(ctx, Bsz);
         Fr* out = ab.p;

@@ -706,6 +706,32 @@ def test_golden_proof_bytes_merkle_height_5(M, S, W):
     srs.free()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prover_merkle_height_5_golden_bytes(M, S, W, world):
+    """The same circuit (|K| = 2 |H|, multi-term rows, rows with empty A and B) proved by 2 / 4 thread ranks with rounds 1 - 3 on a
+    rank's share: the model's key and proof bytes on every rank."""
+    case = golden("marlin_large.json")["merkle_h5"]
+    kw = case["circuit"]
+    cs, public, _ = W.merkle_membership_circuit(height=kw["height"], leaf_u8=kw["leaf_u8"], seed=kw["seed"],
+                                                gadget_byte_ops=kw["gadget_byte_ops"])
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        before = ctx.exchange_stats()[0]
+        proof = M.generate_proof(cs, pk, rng)
+        out = (S.serialize_verifying_key(vk).hex(), S.serialize_proof(proof).hex(), ctx.exchange_stats()[0] - before)
+        pk.free()
+        return out
+
+    for vk_hex, proof_hex, exchanges in _run_sharded(world, build):
+        assert vk_hex == case["vk"]
+        assert proof_hex == case["proof"]
+        assert exchanges >= 17, exchanges
+
+
 # ---- where the prover's randomness comes from: built-in ChaCha12, the caller's generator behind a callback, the caller's
 # ChaCha STATE adopted (swm_rng_from_chacha) — one stream, three ways to draw it
 def test_rng_modes_give_the_same_proof_at_2p14(M, S, W):
@@ -765,7 +791,8 @@ def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
     """One proof over 2 / 4 contexts with the sharded round 1 (mat-vec by rows of the BLOCKS layout, sharded inverse
     transform, commitment of CYCLIC coefficients in place, one all-gather for the replicated rest) and the sharded round 2 (the
     four transforms into the product domain, the pointwise form and the transform back on a rank's share, mask and division by
-    v_H local in the CYCLIC layout): the bytes of the Python model at 2^12 constraints, and the exchanges did take place."""
+    v_H local in the CYCLIC layout; round 3 the same way on the 4|K| domain): the bytes of the Python model at 2^12 constraints, and the
+    exchanges did take place."""
     case = golden("marlin_large.json")["synthetic_2p12"]
     n = case["num_constraints"]
     cs, public = W.synthetic_r1cs(n, h2i(case["a"]), h2i(case["b"]))
@@ -787,7 +814,7 @@ def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
         assert proof_hex == case["proof"]
         # per-round partial sums (4) + (all-to-all, all-gather) for z_A and for z_B (4) + round 2: four transforms into the product
         # domain and one back (5 all-to-alls) and the all-gather of h_1 and X g_1
-        assert exchanges >= 4 + 4 + 6, exchanges
+        assert exchanges >= 4 + 4 + 6 + 3, exchanges   # + round 3: f into the 4|K| domain and back, the all-gather of h_2
 
 
 def test_reference_test_circuit_example(M, S, W):
