@@ -533,7 +533,14 @@ class SimpleMerkleTree:
         universal_srs = M.MarlinInst.universal_setup(*srs_sizes, rng, ctx)       # simple_merkle_tree.rs:39
         self.params = params or MerkleParams.setup(rng)                          # LeafHash / TwoToOneHash setup(&mut rng), :43-45
         self.leaves = list(leaves_u8)
-        self.levels = self.params.build_tree(self.leaves, ctx)                   # MerkleTree::new, :47-49 (on the GPU)
+        if self.params.digest_bits == 256:                                       # MerkleTree::new, :47-49 (on the GPU)
+            from .hash import MerkleTree
+            leaf_crh, inner_crh = self.params.crh(ctx)
+            self.tree = MerkleTree.new(leaf_crh, inner_crh, [int(v) for v in self.leaves])
+            self.levels = self.tree.levels                                       # digests as bytes: converted where they are used
+        else:
+            self.tree = None
+            self.levels = self.params.build_tree(self.leaves, ctx)
         height = merkle_tree_height(len(self.leaves))
         blank_path = [0] * (height - 1)                                          # MerkleTree::blank(..).generate_proof(0)
         blank_root = self.params.root_from_path(0, 0, blank_path)
@@ -543,9 +550,11 @@ class SimpleMerkleTree:
         universal_srs.free()
 
     def root(self):
-        return self.levels[-1][0]
+        return self.tree.root() if self.tree is not None else self.levels[-1][0]
 
     def get_merkle_path(self, leaf_index):
+        if self.tree is not None:
+            return leaf_index, self.tree.generate_proof(leaf_index)              # tree.generate_proof(leaf_index), :99-103
         return leaf_index, MerkleParams.path_of(self.levels, leaf_index)
 
     def prove(self, leaf, merkle_path):
