@@ -44,8 +44,11 @@ def test_chacha_keystream_vectors(lib):
         out = (ctypes.c_uint8 * 64)()
         assert lib.swm_chacha_block(key, ctr, rounds, out) == 0
         assert bytes(out).hex() == g[name]
-    # djb / RFC 7539 zero-key keystream
-    assert g["chacha20_zero_key_block0"].startswith("76b8e0ada0f13d90405d6ae55386bd28")
+    # published zero-key, zero-nonce keystreams (djb / RFC 7539 for 20 rounds; the 12- and 8-round ones of the ChaCha test-vector
+    # drafts): literals here, so that StdRng's ChaCha12 — the generator behind every draw of the prover — is pinned from outside
+    assert g["chacha20_zero_key_block0"].startswith("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7")
+    assert g["chacha12_zero_key_block0"].startswith("9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f")
+    assert g["chacha8_zero_key_block0"].startswith("3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e")
 
 
 def test_test_rng_stream(lib):
