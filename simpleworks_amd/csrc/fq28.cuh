@@ -118,6 +118,38 @@ __device__ __forceinline__ Fq28 fq28_mul(const Fq28& a, const Fq28& b) {
     r.l[13] = (uint32_t)acc;
     return r;
 }
+// The same product as ONE hand-ordered asm statement (r04; text generated by tools/gen_mul28_asm.py).  Written in plain C++
+// the compiler re-associates every column sum: it starts each column from zero (to shorten a dependency chain that costs
+// nothing on this in-order SIMD with three resident waves — tools/ubench/valu_rates: a dependent v_mad_u64_u32 chain issues
+// at the rate of independent ones), adds the carry of the previous column with a 64-bit addition of its own, widens m_k to
+// 64 bits with a move and adds it with another one: 515 instructions for the 378 multiply-adds of a product.  Here:
+//   * the 64-bit accumulator is the column sum itself: the carry of the previous column is what it holds when the column starts;
+//   * low columns: acc + m_k with m_k = -acc mod 2^28 is the next multiple of 2^28, so carry = (acc + (2^28 - 1)) >> 28 and
+//     m_k = ~(acc + (2^28 - 1)) mod 2^28: one 64-bit add, one v_bfi_b32, one 64-bit shift (no widening move, no negation);
+//     acc + 2^28 - 1 < 2^64 by the column bound above (margin 2^60);
+//   * high columns: a mask and a shift.
+// 378 + 14 x 3 + 13 x 2 + 1 = 447 instructions, the same limbs as fq28_mul bit for bit (tools/ubench/te28_bench.hip compares
+// them on the GPU; tools/check_te28.py emulates the carry rule).  One statement, not one per instruction: after an asm
+// statement that defines a VGPR the compiler inserts an s_nop before the next reader (it must assume a dst_sel hazard).
+#include "fq28_mul_asm.inc"
+__device__ __forceinline__ Fq28 fq28_mul_asm(const Fq28& a, const Fq28& b) {
+    Fq28 r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13;
+    constexpr const uint32_t (&P)[14] = Fq28Consts::P;
+    asm(SWM_FQ28_MUL_ASM_TEXT
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]),
+          "=&v"(r.l[8]), "=&v"(r.l[9]), "=&v"(r.l[10]), "=&v"(r.l[11]), "=&v"(r.l[12]), "=&v"(r.l[13]),
+          "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5), "=&v"(m6), "=&v"(m7), "=&v"(m8), "=&v"(m9),
+          "=&v"(m10), "=&v"(m11), "=&v"(m12), "=&v"(m13)
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]),
+          "v"(a.l[9]), "v"(a.l[10]), "v"(a.l[11]), "v"(a.l[12]), "v"(a.l[13]),
+          "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(b.l[8]),
+          "v"(b.l[9]), "v"(b.l[10]), "v"(b.l[11]), "v"(b.l[12]), "v"(b.l[13]),
+          "s"(P[1]), "s"(P[2]), "s"(P[3]), "s"(P[4]), "s"(P[5]), "s"(P[6]), "s"(P[7]), "s"(P[8]), "s"(P[9]), "s"(P[10]),
+          "s"(P[11]), "s"(P[12]), "s"(P[13]), "s"(M28), "s"((uint64_t)M28)
+        : "v0", "v1", "vcc");
+    return r;
+}
 // (a b + c d) 2^-392 mod p with ONE Montgomery reduction: 2 x 196 + 182 multiply-adds instead of 2 x 378.  The
 // group formulas end in Y3 = R V - Y1 PPP; with c = k p - Y1 that is exactly this shape.
 // Bounds: limbs(a), limbs(b) < 1.5 * 2^29 (normalised + one "_1" spread), limbs(c) < 2^29, limbs(d) < 2^28:
@@ -212,6 +244,15 @@ struct MulFenced {
         Fq28 r = fq28_mul2(a, b, c, d);
         __builtin_amdgcn_sched_barrier(0);
         return r;
+    }
+};
+
+// the asm multiplier: one statement per product is its own fence
+struct MulAsm {
+    static __device__ __forceinline__ Fq28 mul(const Fq28& a, const Fq28& b) { return fq28_mul_asm(a, b); }
+    static __device__ __forceinline__ Fq28 sqr(const Fq28& a) { return fq28_mul_asm(a, a); }
+    static __device__ __forceinline__ Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+        return MulFenced::mul2(a, b, c, d);
     }
 };
 
@@ -388,35 +429,46 @@ struct Fq28TeConsts {
 struct T28 {
     Fq28 x, y, t, z;
 };
+// one coordinate of a table row (G1TE: fourteen limbs in a 64-byte sector): three 16-byte loads and an 8-byte one
+__device__ __forceinline__ Fq28 te28_load_coord(const uint32_t* __restrict__ p) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(p), v1 = *reinterpret_cast<const uint4*>(p + 4),
+                v2 = *reinterpret_cast<const uint4*>(p + 8);
+    const uint2 v3 = *reinterpret_cast<const uint2*>(p + 12);
+    Fq28 r;
+    r.l[0] = v0.x, r.l[1] = v0.y, r.l[2] = v0.z, r.l[3] = v0.w;
+    r.l[4] = v1.x, r.l[5] = v1.y, r.l[6] = v1.z, r.l[7] = v1.w;
+    r.l[8] = v2.x, r.l[9] = v2.y, r.l[10] = v2.z, r.l[11] = v2.w;
+    r.l[12] = v3.x, r.l[13] = v3.y;
+    return r;
+}
 // acc += +-P for the table row (m2, s2, k2) = (y2 - x2, y2 + x2, 2 d x2 y2) of P: EFD madd-2008-hwcd-3 with the row
-// precomputed, 7 multiplications.  A NEGATIVE digit is taken on the accumulator side, -(P1) + P2 = -(P1 - P2): negating P1
-// swaps Y1 - X1 with Y1 + X1 and the sign of C, negating the sum swaps the sign of E — so the row is consumed as loaded
-// (each coordinate unpacked right before the multiplication that reads it) and the sign costs 6 x 14 selects.
+// precomputed, 7 multiplications.  The row of -P is (s2, m2, -k2): a NEGATIVE digit loads the first two coordinates from each
+// other's address (no select on limbs) and takes the sign of C = T1 k2 in the choice between D - C and D + C.
 // Bounds (N: limbs < 2^28, value < 2p; the row: canonical):
 //   Y1 - X1 + 4p: limbs < 2^30, < 6p  |  Y1 + X1 < 4p  |  A, B, C = products: N  |  D = 2 Z1: limbs < 2^29, < 4p
-//   +-(B - A) + 4p, D - C + 4p: limbs < 2^30, < 8p  |  D + C: limbs < 3 2^28, < 6p  |  H = B + A: limbs < 2^29, < 4p
+//   B - A + 4p, D - C + 4p: limbs < 2^30, < 8p  |  D + C: limbs < 3 2^28, < 6p  |  H = B + A: limbs < 2^29, < 4p
 //   X3 = E F, Y3 = G H, T3 = E H, Z3 = F G: operands within what fq28_mul accepts (limbs < 2^30, value < 128p) -> N.
 // The same bounds hold for the first point of a segment (te28_from_row: X1 normalised, in (p, 3p); a SPREADk subtraction
 // needs the top limb of what it subtracts below the top limb of k p: 13.8 k for an N value, 27.5 k for 4p).
-// The empty asm statements at the end pin the new coordinates as 32-bit values: without them the compiler carries the
-// unmasked 64-bit column sums of the last multiplications around the loop and spills ~100 registers.
-template <class M = MulFenced>
+// (r03 took the sign on the accumulator side — the same seven products, hence the same limbs — with four 14-limb selects.)
+template <class M = MulAsm>
 __device__ __forceinline__ void te28_madd_row(T28& a, const G1TE* __restrict__ rp, bool neg) {
-    Fq28 a1, b1;
+    const uint32_t* pa = neg ? rp->ypx : rp->ymx;
+    const uint32_t* pb = neg ? rp->ymx : rp->ypx;
+    Fq28 d, s;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
-        const uint32_t d = a.y.l[i] + Fq28Consts::SPREAD4[i] - a.x.l[i], s = a.y.l[i] + a.x.l[i];
-        a1.l[i] = neg ? s : d;
-        b1.l[i] = neg ? d : s;
+        d.l[i] = a.y.l[i] + Fq28Consts::SPREAD4[i] - a.x.l[i];
+        s.l[i] = a.y.l[i] + a.x.l[i];
     }
-    Fq28 A = M::mul(a1, fq28_unpack(rp->ymx));
-    Fq28 B = M::mul(b1, fq28_unpack(rp->ypx));
-    Fq28 C = M::mul(a.t, fq28_unpack(rp->kt));
+    const Fq28 A = M::mul(d, te28_load_coord(pa));
+    const Fq28 B = M::mul(s, te28_load_coord(pb));
+    const Fq28 C = M::mul(a.t, te28_load_coord(rp->kt));
     Fq28 E, H, F, G;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
         const uint32_t sp = Fq28Consts::SPREAD4[i];
-        E.l[i] = neg ? A.l[i] + sp - B.l[i] : B.l[i] + sp - A.l[i];
+        E.l[i] = B.l[i] + sp - A.l[i];
         H.l[i] = A.l[i] + B.l[i];
         const uint32_t D = a.z.l[i] + a.z.l[i];
         const uint32_t dm = D + sp - C.l[i], dp = D + C.l[i];
@@ -427,13 +479,6 @@ __device__ __forceinline__ void te28_madd_row(T28& a, const G1TE* __restrict__ r
     a.y = M::mul(G, H);
     a.t = M::mul(E, H);
     a.z = M::mul(F, G);
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        asm volatile("" : "+v"(a.x.l[i]));
-        asm volatile("" : "+v"(a.y.l[i]));
-        asm volatile("" : "+v"(a.t.l[i]));
-        asm volatile("" : "+v"(a.z.l[i]));
-    }
 }
 // the point a row stands for, as an accumulator: (X : Y : T : Z) = (2x : 2y : 2xy : 2) — one multiplication (by 1/d)
 // instead of an addition to the identity.  neg: the row of -P is (s2, m2, -k2).
@@ -462,7 +507,7 @@ __device__ __forceinline__ void te28_store_identity(G1XYZZ& m) {
 }
 // *dst = *pa + *pq, operands in memory (LDS slots or HBM), streamed like p28_slot_add: 9 multiplications, four field
 // elements live at the peak.  dst may be pa or pq: every load precedes the first store.
-template <class M = MulFenced>
+template <class M = MulAsm>
 __device__ __forceinline__ void te28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) {
     Fq28 A, B;
     {

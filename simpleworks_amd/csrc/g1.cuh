@@ -200,8 +200,14 @@ SWM_HD bool g1_is_on_curve(const G1Affine& p) {
 // among points of odd order (doubling, cancellation and the identity (0, 1) go through the same formulas), so it is used
 // only for base sets known to lie in the prime-order subgroup (msm_table_build_te); it is what the precomputed-table
 // MSM accumulates and reduces in.  A TE point travels in a G1XYZZ-sized slot: x -> X, y -> Y, zz -> T, zzz -> Z.
-struct alignas(16) G1TE {  // one table row: affine, already in the form the mixed addition consumes
-    Fq ymx, ypx, kt;       // y - x, y + x, 2 d x y
+// One table row: affine, already in the form the mixed addition consumes — (y - x, y + x, 2 d x y), each coordinate times
+// 2^8 (Montgomery radix 2^392) as the FOURTEEN 28-BIT LIMBS the accumulation multiplies (fq28.cuh), in a 64-byte sector of
+// its own (limbs 14 and 15 are padding).  r04; r03 kept the coordinates packed (3 x 48 B): every row then cost 84
+// shift / mask instructions to unpack and straddled 64-byte sectors (144-B rows: 25 % over-fetch), and the sign of a digit
+// cost two 14-limb selects where it now costs the choice of the ADDRESS the first two coordinates are loaded from.
+// 192 B per row instead of 144 B: 13 x 3 M rows = 7.5 GB per 2^20 key (5.6 GB before) of the 288 GB.
+struct alignas(64) G1TE {
+    uint32_t ymx[16], ypx[16], kt[16];
 };
 struct TeParams {
     static constexpr uint32_t S[12] = SWM_TE_S_MONT;

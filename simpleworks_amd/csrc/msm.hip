@@ -642,22 +642,36 @@ __global__ void __launch_bounds__(256) msm_te_convert(const G1Affine* __restrict
     one256 = fp_mul(one, c256);
     for (size_t i = hi; i-- > lo;) {
         G1Affine p = in[i];
-        G1TE r;
+        Fq ymx, ypx, kt;
         Fq x1 = fp_add(p.x, one), u = fp_mul(cs, x1), up1 = fp_add(u, one), den = fp_mul(p.y, up1);
         if (g1_is_inf(p) || fp_is_zero(den)) {
-            r.ymx = one256;
-            r.ypx = one256;
-            r.kt = fp_zero<Fq>();
+            ymx = one256;
+            ypx = one256;
+            kt = fp_zero<Fq>();
         } else {
             Fq di = fp_mul(inv, pref[i]);
             inv = fp_mul(inv, den);
             Fq xt = fp_mul(fp_mul(fq_const(TeParams::F), x1), fp_mul(di, up1));  // f (x_w + 1) / y_w
             Fq yt = fp_mul(fp_sub(u, one), fp_mul(di, p.y));                       // (u - 1) / (u + 1)
-            r.ymx = fp_mul(fp_sub(yt, xt), c256);
-            r.ypx = fp_mul(fp_add(yt, xt), c256);
-            r.kt = fp_mul(fp_mul(fq_const(TeParams::K2D), fp_mul(xt, yt)), c256);
+            ymx = fp_mul(fp_sub(yt, xt), c256);
+            ypx = fp_mul(fp_add(yt, xt), c256);
+            kt = fp_mul(fp_mul(fq_const(TeParams::K2D), fp_mul(xt, yt)), c256);
         }
-        out[i] = r;
+        // canonical values split into the 28-bit limbs the accumulation multiplies, one 64-byte sector per coordinate
+        const Fq28 l0 = fq28_unpack(ymx), l1 = fq28_unpack(ypx), l2 = fq28_unpack(kt);
+        uint4* o = reinterpret_cast<uint4*>(&out[i]);
+        o[0] = make_uint4(l0.l[0], l0.l[1], l0.l[2], l0.l[3]);
+        o[1] = make_uint4(l0.l[4], l0.l[5], l0.l[6], l0.l[7]);
+        o[2] = make_uint4(l0.l[8], l0.l[9], l0.l[10], l0.l[11]);
+        o[3] = make_uint4(l0.l[12], l0.l[13], 0u, 0u);
+        o[4] = make_uint4(l1.l[0], l1.l[1], l1.l[2], l1.l[3]);
+        o[5] = make_uint4(l1.l[4], l1.l[5], l1.l[6], l1.l[7]);
+        o[6] = make_uint4(l1.l[8], l1.l[9], l1.l[10], l1.l[11]);
+        o[7] = make_uint4(l1.l[12], l1.l[13], 0u, 0u);
+        o[8] = make_uint4(l2.l[0], l2.l[1], l2.l[2], l2.l[3]);
+        o[9] = make_uint4(l2.l[4], l2.l[5], l2.l[6], l2.l[7]);
+        o[10] = make_uint4(l2.l[8], l2.l[9], l2.l[10], l2.l[11]);
+        o[11] = make_uint4(l2.l[12], l2.l[13], 0u, 0u);
     }
 }
 // [r]P = O and P on the curve, for every point that is not the identity (0, 0): double-and-add over the 253 bits of r
@@ -1004,7 +1018,7 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
 // cancellation test, no cold path, 2 646 instead of 3 598 multiply-adds per addition (3 890 instead of 4 817 instructions in
 // the loop, 148 VGPRs, no scratch).  Partial sums leave as extended points (X, Y, T, Z in the four slots of a G1XYZZ).
 // Algorithmic bytes per point are unchanged (96 B base + 32 B scalar); a table row is 144 B instead of 96 B.
-__global__ void __launch_bounds__(256, 3) msm_accumulate_te(const G1TE* __restrict__ rows,
+__global__ void __launch_bounds__(256, 4) msm_accumulate_te(const G1TE* __restrict__ rows,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ seg_start,
                                                            const uint32_t* __restrict__ seg_len,
@@ -1022,8 +1036,8 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate_te(const G1TE* __restri
         T28 acc;
         {
             const uint32_t ent = sorted[k0];
-            const G1TE row = rows[ent & 0x7fffffffu];
-            acc = te28_from_row(fq28_unpack(row.ymx), fq28_unpack(row.ypx), fq28_unpack(row.kt), (ent >> 31) != 0);
+            const G1TE* row = rows + (ent & 0x7fffffffu);
+            acc = te28_from_row(te28_load_coord(row->ymx), te28_load_coord(row->ypx), te28_load_coord(row->kt), (ent >> 31) != 0);
         }
         for (uint32_t k = k0 + 1; k < e; k++) {
             const uint32_t ent = sorted[k];

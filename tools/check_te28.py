@@ -49,6 +49,9 @@ def mul(a, b):
             acc += m[i] * P28[k - i]
         assert acc < 1 << 64
         m[k] = (-acc) & M28
+        # the carry rule of the asm multiplier (fq28_mul_asm): one 64-bit add, one bit-select, one shift
+        t = acc + M28
+        assert t < 1 << 64 and (~t) & M28 == m[k] and t >> 28 == (acc + m[k]) >> 28
         acc = (acc + m[k]) >> 28
     for k in range(14, 27):
         for i in range(k - 13, 14):
@@ -125,9 +128,9 @@ def madd_row(a, row, neg):
     x, y, t, z = a
     d = [u32(y[i] + SPREAD4[i] - x[i]) for i in range(14)]
     s = add(y, x)
-    a1_, b1_ = (s, d) if neg else (d, s)
-    A, B, C = mul(a1_, row[0]), mul(b1_, row[1]), mul(t, row[2])
-    E = sub(A, B, SPREAD4) if neg else sub(B, A, SPREAD4)
+    # r04: the row of -P is (y + x, y - x, -k): the first two coordinates are LOADED from each other's address
+    A, B, C = mul(d, row[1] if neg else row[0]), mul(s, row[0] if neg else row[1]), mul(t, row[2])
+    E = sub(B, A, SPREAD4)
     H = add(A, B)
     D = add(z, z)
     dm, dp = sub(D, C, SPREAD4), add(D, C)
