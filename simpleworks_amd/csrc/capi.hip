@@ -47,6 +47,7 @@ void drain_streams(swm_ctx* ctx) {
         if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
     for (int i = 0; i < swm_ctx::MSM_SLOTS; i++) ctx->slot_busy[i] = false;
     ctx->pending_tails.clear();
+    ctx->lazy_tail = nullptr;
     for (auto& e : ctx->set_acc_event) e = nullptr;
 }
 
@@ -335,7 +336,7 @@ int swm_init(int device, swm_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SWM_ERR_NO_DEVICE;  // code objects are gfx950 only
     swm_ctx* ctx = new swm_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (msm_create_stream(&ctx->own_stream, "SWM_PRIO_MAIN") != hipSuccess) {
         delete ctx;
         return SWM_ERR_HIP;
     }

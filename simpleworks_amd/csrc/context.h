@@ -61,6 +61,7 @@ struct swm_ctx {
     hipEvent_t sort_event[MSM_SLOTS] = {nullptr};  // "sorted" per slot (stage S -> stage A)
     hipEvent_t set_acc_event[4] = {nullptr, nullptr, nullptr, nullptr};  // accumulation that last read each per-lane scratch set (not owned)
     std::vector<swm::MsmJob*> pending_tails;      // jobs whose bucket stage waits for msm_flush_tails
+    swm::MsmJob* lazy_tail = nullptr;             // large job whose bucket stage is shaped by what follows it (msm.hip, msm_tail_shape)
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)

@@ -117,10 +117,23 @@ __device__ __forceinline__ Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
     r.l[8] = (uint32_t)acc;
     return r;
 }
+// The same product as one hand-ordered asm statement (r04; text from tools/gen_mul28_asm.py fr29, reasoning in fq28.cuh at
+// fq28_mul_asm): the 153 multiply-adds in one chain through v[0:1], low columns closed by add (2^29 - 1) / v_bfi_b32 / shift,
+// high columns by mask / shift: 197 instructions where the compiler's schedule of fr29_mul takes ~238.  Same limbs bit for bit
+// (tools/check_ntt29.py asserts the carry rule; every NTT test compares with the oracle).  A statement is its own fence.
+#include "fr29_mul_asm.inc"
 __device__ __forceinline__ Fr29 fr29_mul_fenced(const Fr29& a, const Fr29& b) {
-    __builtin_amdgcn_sched_barrier(0);
-    Fr29 r = fr29_mul(a, b);
-    __builtin_amdgcn_sched_barrier(0);
+    Fr29 r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    constexpr const uint32_t (&P)[9] = Fr29Consts::P;
+    static_assert(P[0] == 1u, "the carry rule needs r = 1 mod 2^29");
+    asm(SWM_FR29_MUL_ASM_TEXT
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]),
+          "=&v"(r.l[8]), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5), "=&v"(m6), "=&v"(m7), "=&v"(m8)
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]),
+          "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(b.l[8]),
+          "s"(P[1]), "s"(P[2]), "s"(P[3]), "s"(P[4]), "s"(P[5]), "s"(P[6]), "s"(P[7]), "s"(P[8]), "s"(M29), "s"((uint64_t)M29)
+        : "v0", "v1", "vcc");
     return r;
 }
 // normalised value < 4r -> canonical (< r): subtract 2r, then r, each kept when it does not borrow

@@ -69,6 +69,8 @@ bool msm_te_enabled();
 // HBM left for a table of `bytes` bytes? (hipMemGetInfo, keeping a quarter of the free memory for the prover's temporaries)
 bool msm_table_fits(size_t bytes);
 
+// a non-blocking stream for one role of the prover (SWM_PRIO_* experiment switches: msm.hip)
+hipError_t msm_create_stream(hipStream_t* out, const char* role_env);
 // does msm_enqueue run the precomputed-window ("flat") schedule for n points on this table?  (callers that hand over a
 // strided layout have to know: only that schedule maps scalars to bases through MsmTable::blk_log / bstride)
 bool msm_flat_applies(const MsmTable& tab, size_t n);
@@ -88,7 +90,8 @@ struct MsmJob {
     hipStream_t stream = nullptr;
     hipEvent_t acc_done = nullptr;
     G1XYZZ *d_partial = nullptr, *d_wpart = nullptr;
-    const uint32_t *d_seg_off = nullptr, *d_status = nullptr, *d_entries = nullptr;
+    const uint32_t *d_seg_off = nullptr, *d_hist = nullptr, *d_status = nullptr, *d_entries = nullptr;
+    uint32_t seg = 0;  // segment bound of the accumulation: bucket b owns the partial sums d_seg_off[b] .. + ceil(d_hist[b] / seg)
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs
     G1XYZZ* host_dev = nullptr;          // the same slot as the device addresses it (the bucket stage writes there)
     uint32_t* host_flags_dev = nullptr;
@@ -113,6 +116,7 @@ struct MsmInfMask {
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
                 int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false, MsmTable tab = MsmTable());
 int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k);
+int msm_launch_lazy_tail(swm_ctx* ctx, bool wide);  // the held-back bucket stage of ctx->lazy_tail, if any
 int msm_flush_tails(swm_ctx* ctx);
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result);
 int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results);  // a round's jobs: one wait, folds side by side

@@ -412,32 +412,47 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint3
         if (v) atomicAdd(&bin_count[b], v);
     }
 }
-// exclusive scan of <= 4096 bin counts by one workgroup: bin_off[0 .. nbins]
+// exclusive scan of <= 4096 bin counts by one workgroup: bin_off[0 .. nbins]; and of the bins' SEGMENT capacities
+// 2^fb + count / SEG (an upper bound of sum over the bin's buckets of ceil(count_b / SEG)): bin_seg_off[0 .. nbins] — the
+// segment indices a bin's workgroup of msm_flat_bin_sort hands out without knowing what the other bins need
 __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins,
-                                                           uint32_t* __restrict__ bin_off) {
-    __shared__ uint32_t sm[1024];
+                                                           uint32_t* __restrict__ bin_off, unsigned fb, uint32_t SEG,
+                                                           uint32_t* __restrict__ bin_seg_off) {
+    __shared__ uint32_t sm[1024], sg[1024];
     const uint32_t t = threadIdx.x;
-    uint32_t v[4], s = 0;
+    uint32_t v[4], g[4], s = 0, q = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        v[u] = 4 * t + u < nbins ? bin_count[4 * t + u] : 0u;
+        const bool in = 4 * t + u < nbins;
+        v[u] = in ? bin_count[4 * t + u] : 0u;
+        g[u] = in ? (1u << fb) + v[u] / SEG : 0u;
         s += v[u];
+        q += g[u];
     }
     sm[t] = s;
+    sg[t] = q;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = t >= d ? sm[t - d] : 0u;
+        uint32_t x = t >= d ? sm[t - d] : 0u, y = t >= d ? sg[t - d] : 0u;
         __syncthreads();
         sm[t] += x;
+        sg[t] += y;
         __syncthreads();
     }
-    uint32_t run = sm[t] - s;
+    uint32_t run = sm[t] - s, rung = sg[t] - q;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        if (4 * t + u < nbins) bin_off[4 * t + u] = run;
+        if (4 * t + u < nbins) {
+            bin_off[4 * t + u] = run;
+            bin_seg_off[4 * t + u] = rung;
+        }
         run += v[u];
+        rung += g[u];
     }
-    if (t == 1023) bin_off[nbins] = sm[1023];
+    if (t == 1023) {
+        bin_off[nbins] = sm[1023];
+        bin_seg_off[nbins] = sg[1023];
+    }
 }
 // (entry, bucket) pairs grouped by coarse bin; grid (tiles over the points, windows).  entry = table row of the point:
 // w * tstride + toff + i, with the sign of the digit in bit 31.
@@ -520,45 +535,95 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         tmp[gpos[b] + (i - start[b])] = e;
     }
 }
-// one workgroup per bin: bucket histogram of the bin (written out: hist[first bucket + f]), then placement by bucket
+// One workgroup per bin: bucket histogram of the bin, placement by bucket — and everything the accumulation and the bucket
+// stage need to know about the bin's buckets (r04; four launches — three scans over the histogram and a binary search per
+// segment — did this before): a bin is a contiguous bucket range whose first entry (bin_off) and first segment index
+// (bin_seg_off, a capacity: see msm_flat_scan_bins) are known, so with the bin's fine counts in LDS the workgroup writes
+//   hist[b], bucket_off[b], seg_off[b]           count, first entry and first segment of bucket b
+//   seg_start[s], seg_len[s]                     the balanced segments (<= SEG entries) of its buckets; the unused tail of the
+//                                                bin's segment indices gets length 0 (msm_seg_order skips those)
+//   len_hist                                     segments per length (for the ordering by length that follows)
+//   big_list                                     buckets with more than big_nseg segments (folded ahead of the bucket stage)
+struct FlatSegOut {
+    uint32_t *hist, *bucket_off, *seg_off, *seg_start, *seg_len, *len_hist, *big_count, *big_list;
+    uint32_t SEG, big_nseg;
+};
+static constexpr uint32_t LEN_STRIDE = 32;  // the SEG + 1 length counters sit one per 128-byte line (see FLAT_CUR_STRIDE)
+__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
 __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
                                                                  const uint32_t* __restrict__ bin_off,
-                                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+                                                                 const uint32_t* __restrict__ bin_seg_off, FlatSegOut o,
+                                                                 uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t stage32[];  // fc[nf] | fo[nf] | FLAT_BIN_CAP entries
+    __shared__ uint32_t wsum[2][BIN_THREADS / 64];
+    __shared__ uint32_t lh[SEG_MAX + 1];
     uint32_t* fc = stage32;
     uint32_t* fo = fc + (1u << fb);
     uint32_t* stage = fo + (1u << fb);
-    const uint32_t bin = blockIdx.x, nf = 1u << fb, first = bin << fb, fmask = nf - 1;
+    const uint32_t bin = blockIdx.x, nf = 1u << fb, first = bin << fb, fmask = nf - 1, t = threadIdx.x;
     const uint32_t lo = bin_off[bin], cnt = bin_off[bin + 1] - lo;
-    for (uint32_t f = threadIdx.x; f < nf; f += BIN_THREADS) fc[f] = 0;
+    const uint32_t seg_lo = bin_seg_off[bin], seg_hi = bin_seg_off[bin + 1];
+    for (uint32_t f = t; f < nf; f += BIN_THREADS) fc[f] = 0;
+    for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS) lh[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
+    for (uint32_t i = t; i < cnt; i += BIN_THREADS) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
     __syncthreads();
-    {   // exclusive prefix of the fine counts (nf <= 2048): chunk per lane, then a scan over the 1024 lane totals
-        __shared__ uint32_t lt[BIN_THREADS];
-        const uint32_t per = (nf + BIN_THREADS - 1) / BIN_THREADS, f0 = threadIdx.x * per, f1 = min(f0 + per, nf);
-        uint32_t sum = 0;
-        for (uint32_t f = f0; f < f1; f++) sum += fc[f];
-        lt[threadIdx.x] = sum;
-        __syncthreads();
-        for (uint32_t d = 1; d < BIN_THREADS; d <<= 1) {
-            uint32_t x = threadIdx.x >= d ? lt[threadIdx.x - d] : 0u;
-            __syncthreads();
-            lt[threadIdx.x] += x;
-            __syncthreads();
-        }
-        uint32_t run = lt[threadIdx.x] - sum;
-        for (uint32_t f = f0; f < f1; f++) {
-            fo[f] = run;
-            run += fc[f];
+    // exclusive prefixes of the fine counts and of the segments per bucket (nf <= 2048): a chunk per lane, shuffles inside
+    // a wave, the 16 wave totals through LDS
+    const uint32_t per = (nf + BIN_THREADS - 1) / BIN_THREADS, f0 = t * per, f1 = min(f0 + per, nf);
+    uint32_t sum = 0, sums = 0;
+    for (uint32_t f = f0; f < f1; f++) {
+        sum += fc[f];
+        sums += nseg_of(fc[f], o.SEG);
+    }
+    uint32_t inc = sum, incs = sums;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d, 64), y = __shfl_up(incs, d, 64);
+        if ((t & 63) >= (uint32_t)d) {
+            inc += x;
+            incs += y;
         }
     }
+    if ((t & 63) == 63) {
+        wsum[0][t >> 6] = inc;
+        wsum[1][t >> 6] = incs;
+    }
     __syncthreads();
-    for (uint32_t f = threadIdx.x; f < nf; f += BIN_THREADS)
-        if (first + f < NB) hist[first + f] = fc[f];
+    uint32_t run = inc - sum, runs = incs - sums, used = 0;
+#pragma unroll
+    for (uint32_t wv = 0; wv < BIN_THREADS / 64; wv++) {
+        if (wv < (t >> 6)) {
+            run += wsum[0][wv];
+            runs += wsum[1][wv];
+        }
+        used += wsum[1][wv];
+    }
+    for (uint32_t f = f0; f < f1; f++) {
+        const uint32_t c = fc[f], ns = nseg_of(c, o.SEG);
+        fo[f] = run;
+        if (first + f < NB) {
+            const uint32_t b = first + f, ent = lo + run, s0 = seg_lo + runs;
+            o.hist[b] = c;
+            o.bucket_off[b] = ent;
+            o.seg_off[b] = s0;
+            for (uint32_t k = 0; k < ns; k++) {  // balanced split, as msm_seg_desc: one segment per bucket unless c > SEG
+                const uint32_t ks = (uint32_t)(((uint64_t)c * k) / ns), ke = (uint32_t)(((uint64_t)c * (k + 1)) / ns);
+                o.seg_start[s0 + k] = ent + ks;
+                o.seg_len[s0 + k] = ke - ks;
+                atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
+            }
+            if (ns > o.big_nseg) o.big_list[atomicAdd(o.big_count, 1u)] = b;
+        }
+        run += c;
+        runs += ns;
+    }
+    for (uint32_t k = seg_lo + used + t; k < seg_hi; k += BIN_THREADS) o.seg_len[k] = 0;  // indices the bin did not need
     __syncthreads();
+    for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS)
+        if (lh[i]) atomicAdd(&o.len_hist[i * LEN_STRIDE], lh[i]);
     if (cnt <= FLAT_BIN_CAP) {
-        for (uint32_t i = threadIdx.x; i < cnt; i += 4 * BIN_THREADS) {
+        for (uint32_t i = t; i < cnt; i += 4 * BIN_THREADS) {
             uint2 e[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
@@ -567,9 +632,9 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
                 if (i + u * BIN_THREADS < cnt) stage[atomicAdd(&fo[e[u].y & fmask], 1u)] = e[u].x;
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage[i];
+        for (uint32_t i = t; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage[i];
     } else {  // oversized bin (many equal digits): scattered 4-byte stores, correct for any size
-        for (uint32_t i = threadIdx.x; i < cnt; i += BIN_THREADS) {
+        for (uint32_t i = t; i < cnt; i += BIN_THREADS) {
             uint2 e = tmp[lo + i];
             sorted[lo + atomicAdd(&fo[e.y & fmask], 1u)] = e.x;
         }
@@ -697,8 +762,6 @@ __global__ void __launch_bounds__(256) msm_subgroup_kernel(const G1Affine* __res
     if (!g1_is_inf(acc)) atomicOr(bad, 2u);
 }
 
-__device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
-
 // Exclusive scans of the bucket counts and of the per-bucket segment counts, in three launches:
 // per-workgroup totals, a single-workgroup scan of those totals, per-workgroup scan + offset.
 static constexpr int SCAN_BLOCK = 256;
@@ -814,9 +877,8 @@ __device__ __forceinline__ uint32_t bucket_of_segment(const uint32_t* __restrict
 // longest segment; bucket sizes are Poisson-spread (a wave of 64 unsorted segments idles ~25 % of its lane-cycles).
 // Segments are therefore counting-sorted by length (longest first) and handed to lanes in that order.
 static constexpr int ORD_THREADS = 256;
-// the SEG + 1 length counters / cursors sit one per 128-byte line (every workgroup of msm_seg_desc and msm_seg_order
-// updates most of them; packed, those atomics queue up behind one another — see FLAT_CUR_STRIDE)
-static constexpr uint32_t LEN_STRIDE = 32;
+// (the SEG + 1 length counters / cursors sit one per 128-byte line, LEN_STRIDE: every workgroup of msm_seg_desc and
+// msm_seg_order updates most of them; packed, those atomics queue up behind one another — see FLAT_CUR_STRIDE)
 __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __restrict__ bucket_off,
                                                             const uint32_t* __restrict__ seg_off, uint32_t NB,
                                                             uint32_t SEG, uint32_t* __restrict__ seg_start,
@@ -839,7 +901,8 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __re
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS)
         if (lh[i]) atomicAdd(&len_hist[i * LEN_STRIDE], lh[i]);
 }
-__global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG) {
+__global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG,
+                                                       uint32_t* __restrict__ nseg_live) {
     // one wave, three consecutive counters per lane (SEG <= SEG_MAX = 128: 129 counters at most), shuffle scan across the lanes
     static_assert(SEG_MAX + 1 <= 3 * 64, "three counters per lane");
     if (blockIdx.x) return;
@@ -862,6 +925,7 @@ __global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG
     for (int u = 0; u < 3; u++) {
         const uint32_t i = 3 * l + u;
         if (i <= SEG) len_hist[i * LEN_STRIDE] = run;
+        if (i == SEG) *nseg_live = run;  // class SEG holds the empty segments: everything ordered before it has entries
         run += c[u];
     }
 }
@@ -873,7 +937,9 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __r
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
     __syncthreads();
     uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
-    bool live = seg < *nseg_ptr;
+    // *nseg_ptr bounds the segment INDICES in use; the flat schedule leaves indices without entries between the bins
+    // (msm_flat_bin_sort): those are not handed to a lane
+    bool live = seg < *nseg_ptr && seg_len[seg] != 0;
     uint32_t bin = 0;
     if (live) {
         bin = SEG - seg_len[seg];
@@ -1163,6 +1229,7 @@ struct FormTE {
 template <class Form>
 __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restrict__ partial,
                                                                 const uint32_t* __restrict__ seg_off,
+                                                                const uint32_t* __restrict__ hist, uint32_t SEG,
                                                                 const uint32_t* __restrict__ big_count,
                                                                 const uint32_t* __restrict__ big_list, unsigned log_g) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1177,7 +1244,7 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
         if (j < nbig) {
             uint32_t b = big_list[j];
             s = seg_off[b];
-            e = seg_off[b + 1];
+            e = s + nseg_of(hist[b], SEG);
         }
         Form::store_identity(sm[threadIdx.x]);
 #pragma unroll 1
@@ -1215,7 +1282,8 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
 static constexpr int TAIL_MAX = 4;
 struct TailJob {
     const G1XYZZ* partial;
-    const uint32_t* seg_off;
+    const uint32_t *seg_off, *hist;  // first segment and entry count of every bucket: its segments are seg_off[b] .. + ceil(hist[b] / seg)
+    uint32_t seg;
     G1XYZZ* out;
     unsigned log_m, red_blocks, big_nseg;
     unsigned blk_lo, blk_hi, blk_low;   // workgroups of this rank's bucket share (MsmJob); the others only emit the identity
@@ -1271,7 +1339,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     if (walking) {
         b--;
         s = seg_off[base + b];
-        e = seg_off[base + b + 1];
+        e = s + nseg_of(job.hist[base + b], job.seg);
         if (e - s > job.big_nseg) e = s + 1;  // already folded into the first partial
     }
     enum { WALK = 0, SCAN = 1, SHIFT = 2, FOLD = 3, TREE = 4 };
@@ -1302,7 +1370,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
                     } else {
                         b--;
                         s = seg_off[base + b];
-                        e = seg_off[base + b + 1];
+                        e = s + nseg_of(job.hist[base + b], job.seg);
                         if (e - s > job.big_nseg) e = s + 1;
                     }
                 }
@@ -1613,6 +1681,17 @@ static int streams_concurrent(swm_ctx* ctx, hipStream_t x, hipStream_t y, bool* 
 // The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
+// Stream of one of the roles main / sort / accumulation / tail.  SWM_PRIO_MAIN, _SORT, _ACC, _TAIL (experiment switches):
+// -1 = the device's highest stream priority, 1 = its lowest, unset / 0 = the default — the hardware scheduler then prefers the
+// waves of the higher-priority queue whenever a CU has room.
+hipError_t msm_create_stream(hipStream_t* out, const char* role_env) {
+    int lo = 0, hi = 0;  // lo: least priority (numerically largest), hi: greatest
+    const char* e = getenv(role_env);
+    const int want = e ? atoi(e) : 0;
+    if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, want < 0 ? hi : lo);
+}
 bool msm_flat_applies(const MsmTable& tab, size_t n) {
     static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
     return tab.any() && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
@@ -1628,6 +1707,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stat_msm_calls++;
     ctx->stat_msm_points += n;
     ctx->log_call('m', n);
+    // the job before this one waited to learn whether anything follows it: something does, so its bucket stage takes the
+    // thin shape that runs BESIDE this job's sort and accumulation (msm_tail_shape)
+    SWM_TRY(msm_launch_lazy_tail(ctx, false));
     // flat schedule: the base set comes with its precomputed window multiples and the MSM is large enough to populate the
     // shared bucket set (below ~2^(c-4) points the per-window schedule with its small windows wins)
     const bool flat = msm_flat_applies(tab, n);
@@ -1692,7 +1774,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // all four commitments of a prover round proceed side by side; sets 0 and 1 are shared with the pipelined form,
         // whose accumulations run on the same streams 1 and 2 (stream order covers the reuse)
         static const int small_lanes = getenv("SWM_MSM_SMALL_LANES") ? std::min(4, std::max(1, atoi(getenv("SWM_MSM_SMALL_LANES")))) : 4;
-        lane %= one_stream ? small_lanes : 2;
+        // scratch sets of the pipelined form: with two, the sort of job k + 2 waits for the accumulation of job k; with more
+        // (SWM_MSM_SETS, up to 4) the sorts of a round run further ahead of its accumulations (memory: ~110 B per digit and set)
+        static const int sets = getenv("SWM_MSM_SETS") ? std::min(4, std::max(2, atoi(getenv("SWM_MSM_SETS")))) : 2;
+        lane %= one_stream ? small_lanes : sets;
         if (!ctx->aux_stream[0]) {
             // Hardware-queue placement.  ROCm 7 hands its hardware queues (four by default) to streams in creation order,
             // bouncing: 1, 2, 3, 4, 4, 3, 2, 1, ... (rocprofv3 Queue_Id, r02).  With the context's stream and the null stream
@@ -1710,13 +1795,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             // would skip this block and silently run its tail on the legacy default stream).
             hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
             auto setup = [&]() -> int {
-                for (int i = 0; i < 3; i++) SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+                static const char* role_env[swm_ctx::MSM_LANES] = {"SWM_PRIO_SORT", "SWM_PRIO_ACC", "SWM_PRIO_ACC", "SWM_PRIO_TAIL"};
+                for (int i = 0; i < 3; i++) SWM_HIP(ctx, msm_create_stream(&aux[i], role_env[i]));
                 if (steer) {
                     hipStream_t ph = nullptr;
                     SWM_HIP(ctx, hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
                     ctx->spare_streams.push_back(ph);
                 }
-                SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[3], hipStreamNonBlocking));
+                SWM_HIP(ctx, msm_create_stream(&aux[3], role_env[3]));
                 if (steer) {
                     SWM_HIP(ctx, hipStreamSynchronize(main_stream));
                     const int roles[3] = {0, 1, 3};  // sort, accumulation 0, tail
@@ -1736,7 +1822,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                             if (!clash || budget-- <= 0) break;
                             ctx->spare_streams.push_back(aux[r]);  // kept alive: destroying it would free its slot
                             aux[r] = nullptr;
-                            SWM_HIP(ctx, hipStreamCreateWithFlags(&aux[r], hipStreamNonBlocking));
+                            SWM_HIP(ctx, msm_create_stream(&aux[r], role_env[r]));
                         }
                         fixed.push_back(aux[r]);
                     }
@@ -1758,7 +1844,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             st_sort = st_acc = st_tail = ctx->aux_stream[lane_stream[lane]];
         } else {
             st_sort = ctx->aux_stream[0];
-            st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + lane];
+            st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + (lane & 1)];
             st_tail = ctx->aux_stream[3];
         }
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
@@ -1861,7 +1947,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (const char* e = getenv("SWM_MSM_LOGG")) log_g = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("SWM_MSM_BIG_NSEG")) big_nseg = (uint32_t)std::max(1, atoi(e));
     job->big_nseg = big_nseg;
-    const size_t nseg_max = total / SEG + pl.NB + 1;  // every bucket adds at most one short segment
+    // every bucket adds at most one short segment; the flat schedule hands out segment indices per coarse bin with the bin's
+    // capacity (msm_flat_scan_bins): at most one more per bucket slot of the (padded) bins
+    const size_t nseg_max = total / SEG + pl.NB + 1 + (flat ? FLAT_MAX_FINE + FLAT_MAX_BINS : 0);
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
     // two-level scatter for large MSMs (see msm_partition): bins of ~8 k entries, sized per window
@@ -1919,7 +2007,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
     const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
-                              (flat ? (2 + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 2 : 0);
+                              (flat ? (3 + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 : 0);
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
@@ -1928,7 +2016,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
     uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;  // [bins] counts | [bins + 1] offsets | [bins] cursors, one per line
     uint32_t* flat_off = flat_cnt + FLAT_MAX_BINS;
-    uint32_t* flat_cur = flat_off + FLAT_MAX_BINS + 2;
+    uint32_t* flat_seg_off = flat_off + FLAT_MAX_BINS + 2;  // [bins + 1] first segment index of every bin
+    uint32_t* flat_cur = flat_seg_off + FLAT_MAX_BINS + 2;
     uint2* pairs = nullptr;
     if (two_level || flat) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
@@ -1952,7 +2041,6 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
                big_count + 1 /* zeroed with the histogram */, dshard, tab.scalar_stride);
-    const unsigned scan_tiles_ = scan_tiles;
     if (flat) {
         // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the
         // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
@@ -1964,16 +2052,16 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((total + ctile - 1) / ctile)), dim3(SORT_THREADS), 0,
                    digits, total, flat_fb, flat_bins, ctile, flat_cnt);
-        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off);
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off, flat_fb, SEG,
+                   flat_seg_off);
         SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
                    flat_bins, flat_off, flat_cur, pairs);
+        // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
+        // the bin sort: no scans over the bucket histogram, no msm_seg_desc)
+        const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg};
         SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
-                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, hist, sorted);
-        SWM_LAUNCH(ctx, "msm_scan", msm_scan_totals, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg);
-        SWM_LAUNCH(ctx, "msm_scan", msm_scan_mid, dim3(1), dim3(SCAN_BLOCK), 0, tot_cnt, tot_seg, scan_tiles_);
-        SWM_LAUNCH(ctx, "msm_scan", msm_scan_final, dim3(scan_tiles_), dim3(SCAN_BLOCK), 0, hist, pl.NB, SEG, tot_cnt, tot_seg,
-                   scan_tiles_, bucket_off, seg_off, big_count, big_list, big_nseg);
+                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
     } else {
         // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
         uint32_t SORT_TILE = SORT_TILE_MIN;
@@ -2007,33 +2095,42 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         ctx->stream = st_acc;
     }
     unsigned grid_s = (unsigned)((nseg_max + ORD_THREADS - 1) / ORD_THREADS);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
-               SEG, seg_start, seg_len, len_hist);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_off + pl.NB, SEG,
+    // segment indices in use (a device word): the flat schedule's bins hand them out by capacity, the per-window schedule densely
+    const uint32_t* seg_space = flat ? flat_seg_off + flat_bins : seg_off + pl.NB;
+    uint32_t* nseg_live = big_count + 3;  // segments that hold entries = lanes of work for the accumulation
+    if (!flat)
+        SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
+                   SEG, seg_start, seg_len, len_hist);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG, nseg_live);
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_space, SEG,
                len_hist, order);
     unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
     static const unsigned acc_cap = getenv("SWM_ACC_WGS") ? (unsigned)atoi(getenv("SWM_ACC_WGS")) : 0u;
     if (acc_cap && lane >= 0) acc_grid = std::min(acc_grid, acc_cap);
     const dim3 big_grid(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512));
     if (te) {
-        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), 0, tab.te, sorted, seg_start, seg_len,
-                   order, seg_off + pl.NB, partial);
+        // SWM_ACC_LDS: dynamic LDS bytes per accumulation workgroup — an occupancy cap for experiments (54 000: three
+        // workgroups per CU instead of the four its 121 VGPRs allow)
+        static const size_t acc_lds = getenv("SWM_ACC_LDS") ? (size_t)atol(getenv("SWM_ACC_LDS")) : 0;
+        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), acc_lds, tab.te, sorted, seg_start, seg_len,
+                   order, nseg_live, partial);
         SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormTE>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
-                   partial, seg_off, big_count, big_list, log_g);
+                   partial, seg_off, hist, SEG, big_count, big_list, log_g);
     } else {
         SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate, dim3(acc_grid), dim3(256), 0,
                    flat ? (const G1Affine*)nullptr : d_bases, flat ? tab.t28 : d_bases28, sorted, seg_start, seg_len, order,
-                   seg_off + pl.NB, partial);
+                   nseg_live, partial);
         SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormXYZZ>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
-                   partial, seg_off, big_count, big_list, log_g);
+                   partial, seg_off, hist, SEG, big_count, big_list, log_g);
     }
     job->needs_acc_wait = st_tail != ctx->stream || defer_tail;  // the tail runs on another stream (or later, with others)
     job->d_partial = partial;
     job->d_wpart = wpart;
     job->d_seg_off = seg_off;
+    job->d_hist = hist;
+    job->seg = SEG;
     job->d_status = big_count + 1;
-    job->d_entries = bucket_off + pl.NB;
+    job->d_entries = flat ? flat_off + flat_bins : bucket_off + pl.NB;  // entries the sort placed
     job->active = true;
     job->tail_pending = true;
     ctx->slot_busy[slot] = true;
@@ -2046,7 +2143,36 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         ctx->pending_tails.push_back(job);
         return SWM_OK;
     }
+    static const bool lazy_on = !(getenv("SWM_MSM_LAZY_TAIL") && atoi(getenv("SWM_MSM_LAZY_TAIL")) == 0);
+    if (lazy_on && flat && !lat && lane >= 0 && rb == 256 && tab.shard_world <= 1 && !getenv("SWM_MSM_LOGM")) {
+        ctx->lazy_tail = job;  // shaped and launched by the next msm_enqueue (thin) or by the flush of the round (wide)
+        return SWM_OK;
+    }
     MsmJob* one[1] = {job};
+    return msm_launch_tails(ctx, one, 1);
+}
+
+// Shape of the bucket stage of a large flat job (r04).  The stage is a dependent chain of group operations — 2 m for the walk
+// over the m buckets of a lane plus ~20 across the workgroup — on (2^(c-1) / m) / 256 workgroups of 144 KB of LDS each.  With
+// m = 8 that is one workgroup on EVERY CU for ~0.5 ms: nothing that needs LDS (the partition and the bin sort of the next
+// job) runs beside it, and the r04 timeline showed exactly that serialisation between consecutive accumulations.  With
+// m = 32 the chain is ~84 steps (~1 ms) on a quarter of the CUs: as CU-time half the cost, and the rest of the chip goes
+// on with the next job.  So: WIDE (m = 8, shortest chain) when the stage is exposed — the last job before a flush, i.e. of
+// a prover round —, THIN (m = 32) when another job follows.  The job's result slot takes up to 256 workgroup results either way.
+static void msm_tail_shape(MsmJob* j, bool wide) {
+    static const unsigned thin_log_m = getenv("SWM_MSM_LOGM_THIN") ? (unsigned)std::min(8, std::max(2, atoi(getenv("SWM_MSM_LOGM_THIN")))) : 5u;
+    unsigned log_m = wide ? 2u : thin_log_m;
+    while (((j->pl.maxB >> log_m) + j->rb - 1) / j->rb > 256u) log_m++;
+    j->log_m = log_m;
+    j->red_blocks = std::max(1u, ((j->pl.maxB >> log_m) + j->rb - 1) / j->rb);
+    j->blk_hi = j->red_blocks;  // (no bucket-range share on this path: blk_lo = 0, blk_low = 0)
+}
+int msm_launch_lazy_tail(swm_ctx* ctx, bool wide) {
+    MsmJob* j = ctx->lazy_tail;
+    if (!j) return SWM_OK;
+    ctx->lazy_tail = nullptr;
+    msm_tail_shape(j, wide);
+    MsmJob* one[1] = {j};
     return msm_launch_tails(ctx, one, 1);
 }
 
@@ -2068,6 +2194,8 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         if (j->acc_done && j->stream != nullptr && j->needs_acc_wait) SWM_HIP(ctx, hipStreamWaitEvent(st, j->acc_done, 0));
         batch.j[i].partial = j->d_partial;
         batch.j[i].seg_off = j->d_seg_off;
+        batch.j[i].hist = j->d_hist;
+        batch.j[i].seg = j->seg;
         batch.j[i].out = j->zero_copy ? j->host_dev : j->d_wpart;
         batch.j[i].status = j->d_status;
         batch.j[i].entries = j->d_entries;
@@ -2117,6 +2245,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
 
 // Launches the deferred bucket stages (all jobs enqueued with defer_tail since the last flush), TAIL_MAX per launch.
 int msm_flush_tails(swm_ctx* ctx) {
+    SWM_TRY(msm_launch_lazy_tail(ctx, true));  // nothing follows it before the round's results are awaited
     std::vector<MsmJob*> jobs;
     jobs.swap(ctx->pending_tails);
     for (size_t i = 0; i < jobs.size();) {  // one launch per run of up to TAIL_MAX jobs of the same workgroup width

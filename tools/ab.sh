@@ -1,11 +1,13 @@
-# A/B of a compile-time variant of msm.hip on the GPU box: usage ab.sh "<flags A>" "<flags B>"
-for flag in "$1" "$2" "$1" "$2"; do
-  touch simpleworks_amd/csrc/msm.hip
-  make -C simpleworks_amd/csrc EXTRA="$flag" > /dev/null 2>&1
-  python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "msm" 2>&1 | tail -1
-  for ln in 20 22; do
-  python bench.py --workload msm --log-n $ln --steps 10 --warmup 2 --no-cpu-baseline --profile-all 2>/dev/null | python -c "
+#!/bin/bash
+# A/B of two builds of the library on ONE box, alternating (box-to-box spread is +-3 %, more than most changes):
+#   bash tools/ab.sh <libA.so> <libB.so> [rounds] [bench.py arguments ...]      prints ms per step of every run
+a=$1; b=$2; rounds=${3:-2}; shift 3 2>/dev/null
+args=${@:---steps 10 --warmup 3 --no-cpu-baseline --no-drop-in}
+for r in $(seq $rounds); do
+  for lib in $a $b; do
+    SWM_LIB_PATH=$PWD/$lib python3 bench.py $args 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print('flag [$flag] msm 2^$ln', round(d['ms_per_step'],3), 'acc', k['msm_accumulate'], 'red', k['msm_bucket_reduce'])"
+d=json.loads(sys.stdin.read())
+print('$lib', round(d['ms_per_step'],3), {k: round(v,3) for k,v in (d.get('kernels_ms_per_step') or {}).items() if 'spmv' not in k}, d['roofline'].get('avg_launch_ms'))"
   done
 done

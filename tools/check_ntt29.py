@@ -51,6 +51,8 @@ def mul(a, b):
             acc += m[i] * P29[k - i]
         assert acc < 1 << 64, "column sum wraps"
         m[k] = (-acc) & M29
+        t = acc + M29  # the carry rule of fr29_mul_asm: one 64-bit add, one bit-select, one shift
+        assert t < 1 << 64 and (~t) & M29 == m[k] and t >> 29 == (acc + m[k]) >> 29, "asm carry rule"
         acc = (acc + m[k]) >> 29
     for k in range(9, 17):
         for i in range(k - 8, 9):
