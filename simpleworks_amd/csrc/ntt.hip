@@ -12,6 +12,7 @@
 // (2 x 32 B x n HBM bytes per pass; algorithmic bytes 64 B per element per transform).
 // Twiddles are not streamed from HBM: w^e is rebuilt from two small L2-resident tables (w^(e mod 1024),
 // w^(1024 (e div 1024))) with one extra multiply.
+#include <atomic>
 #include "context.h"
 #include "ff.cuh"
 #include "fr29.cuh"
@@ -170,8 +171,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
 // tools/check_ntt29.py emulates plan + arithmetic bit by bit and compares whole transforms with a direct DFT.
 struct LazyPlan {
     Spread29 r2;        // radix-2 level: 2 B0 r, one borrow
-    Spread29 s1[5];     // per radix-4 step: 2 B r, one borrow
-    Spread29 s2[5];     //                   4 B r, two borrows (the subtrahend is a lazy sum of two)
+    Spread29 s1[6];     // per radix-4 step: 2 B r, one borrow (six steps: tiles of up to 2^12 elements, SWM_NTT_MAXR)
+    Spread29 s2[6];     //                   4 B r, two borrows (the subtrahend is a lazy sum of two)
     Spread29 s4;        //                   4 r, one borrow (difference of two products)
     uint32_t reduce;    // bit s: y0 of step s is multiplied by one
     uint32_t out_below_2r;  // every value leaving the tile is < 2r (else < 4r)
@@ -456,7 +457,7 @@ static LazyPlan lazy_plan(unsigned log_r, unsigned b_in) {
     P.r2 = lazy_spread(2 * B, 1);
     if (log_r & 1) B = std::max(2 * B, 2u);
     const unsigned nsteps = log_r / 2;
-    for (unsigned st = 0; st < nsteps && st < 5; st++) {
+    for (unsigned st = 0; st < nsteps && st < 6; st++) {
         P.s1[st] = lazy_spread(2 * B, 1);
         P.s2[st] = lazy_spread(4 * B, 2);
         const bool red = 4 * B > 64 || st + 1 == nsteps;
@@ -489,7 +490,8 @@ int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int co
     if (const char* e = getenv("SWM_NTT_MAXR")) maxr = (unsigned)atoi(e);
     // arithmetic: lazy 29-bit limbs (fr29.cuh, ntt_pass_lazy) unless SWM_NTT_LAZY=0 asks for the 32-bit-limb kernel of r01 / r02
     static const bool lazy_env = !(getenv("SWM_NTT_LAZY") && atoi(getenv("SWM_NTT_LAZY")) == 0);
-    const bool lazy = lazy_env && maxr <= 10;
+    // (tiles of 2^11 / 2^12 elements — 76 / 152 KB of LDS, SWM_NTT_MAXR=11 / 12 — make 2^22 / 2^24 two passes: measured r04)
+    const bool lazy = lazy_env && maxr <= 12;
     NttTables *rt = nullptr, *ct = nullptr;
     SWM_TRY(get_root_tables_form(ctx, log_n, inverse, lazy, &rt));
     if (coset) SWM_TRY(get_coset_tables(ctx, log_n, inverse, &ct, lazy));
@@ -556,6 +558,14 @@ int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int co
             size_t shmem = (elems + (elems >> 5) + 1) * 36;  // tile_slot: one slot of padding per 32 elements
             if (shmem < 64) shmem = 64;
             dim3 grid((unsigned)(cols / J)), block(NTT_THREADS);
+            if (shmem > 64 * 1024) {  // only the experimental tile sizes: J = 1
+                static std::atomic<size_t> granted[64];
+                if (J != 1 || shmem > 160 * 1024) return set_err(ctx, SWM_ERR_INVALID_ARG, "ntt: tile does not fit LDS");
+                if (granted[ctx->device & 63].load() < shmem) {
+                    SWM_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_lazy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                    granted[ctx->device & 63].store(shmem);
+                }
+            }
             switch (J) {
                 case 1: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass_lazy<1>, grid, block, shmem, la); break;
                 case 2: SWM_LAUNCH(ctx, "ntt_pass", ntt_pass_lazy<2>, grid, block, shmem, la); break;

@@ -241,7 +241,7 @@ def main():
     big = [min((5 << 29) - 1, (1 << 32) - 1)] * 8 + [0]
     big[8] = ((1 << 261) - 1 - val(big)) >> 232
     mul(big, limbs(R - 1))
-    for log_r in range(1, 11):                       # every tile size, random data at the bound of the plan
+    for log_r in range(1, 13):                       # every tile size (11, 12: SWM_NTT_MAXR), random data at the bound of the plan
         for b0 in (1, 2):
             tw = [limbs(pow(root(log_r, False), e, R) * R261 % R) for e in range(max((1 << log_r) >> 1, 1))]
             xs = [limbs(random.randrange(b0 * R)) for _ in range(1 << log_r)]
