@@ -384,6 +384,37 @@ G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeff
     rc_check(ctx, msm_run(ctx, b, b28, coeffs, n, 1, &r, MsmInfMask(), tab));
     return r;
 }
+// One proof over G ranks only works when every rank takes the SAME decisions about how commitments are split and which
+// rounds run on a rank's share: those depend on state that is local to a rank — whether its key has window tables (decided
+// by the free HBM the rank saw, msm_install_bases), their widths, the experiment switches of its process.  A rank that
+// goes cyclic while another splits by range leaves coefficients uncovered (the proof silently fails to verify); ranks that
+// disagree on a sharded round stop matching their exchanges (the job hangs).  So that state is all-gathered once per
+// call (one 32-byte record per rank) and any difference is an error here, before anything is computed.  
+void shard_agree(swm_ctx* ctx, const swm_pk& pk) {
+    if (ctx->shard_world <= 1) return;
+    struct Rec {
+        uint32_t tab_c, shtab_c, te, switches, n_powers_lo, n_shifted_lo, world, pad;
+    } mine;
+    auto on = [](const char* name) { return getenv(name) && atoi(getenv(name)) != 0 ? 1u : 0u; };
+    mine.tab_c = pk.tab_c;
+    mine.shtab_c = pk.shtab_c;
+    mine.te = (pk.d_powers_te ? 1u : 0u) | (pk.d_shifted_te ? 2u : 0u);
+    mine.switches = on("SWM_SHARD_BUCKETS") | on("SWM_SHARD_RANGE") << 1 | (getenv("SWM_SHARD_R1_OFF") ? 4u : 0u) |
+                    (getenv("SWM_SHARD_R2_OFF") ? 8u : 0u) | (getenv("SWM_MSM_NO_TABLE") ? 16u : 0u);
+    mine.n_powers_lo = (uint32_t)pk.n_powers;
+    mine.n_shifted_lo = (uint32_t)pk.n_shifted;
+    mine.world = ctx->shard_world;
+    mine.pad = 0;
+    std::vector<Rec> all(ctx->shard_world);
+    rc_check(ctx, shard_exchange(ctx, &mine, sizeof(Rec), all.data()));
+    for (unsigned g = 0; g < ctx->shard_world; g++)
+        if (memcmp(&all[g], &all[0], sizeof(Rec)) != 0)
+            throw MarlinError(SWM_ERR_MISMATCH,
+                              "sharded proving: rank " + std::to_string(g) + " and rank 0 disagree on the key's window tables (widths " +
+                                  std::to_string(all[g].tab_c) + "/" + std::to_string(all[g].shtab_c) + " vs " + std::to_string(all[0].tab_c) + "/" +
+                                  std::to_string(all[0].shtab_c) + ", forms " + std::to_string(all[g].te) + " vs " + std::to_string(all[0].te) +
+                                  ") or on the sharding switches: every rank must build its key with the same free memory and environment");
+}
 // asynchronous form: alternates between the two MSM lanes of the context
 // With swm_set_msm_sharding active the context only takes its own point range of every MSM and the partial sums are
 // exchanged in commit_wait (all-gather of one point per rank + the same rank-ordered sum everywhere).
@@ -427,7 +458,10 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
         tab.blk_log = 0;
         tab.bstride = G;
         tab.scalar_stride = G;
-        if (count && !msm_flat_applies(tab, count)) {  // too few points for the table schedule: fall back to the range
+        // too few points for the table schedule: fall back to the range.  Decided on floor(n / G), the SMALLEST share, so that
+        // every rank takes the same branch (the ranks' own counts differ by one when G does not divide n: one rank cyclic
+        // and another by range would leave coefficients uncovered — ADVICE r03)
+        if (count && !msm_flat_applies(tab, std::max<size_t>(n / G, 1))) {
             tab = MsmTable();
             pk.bases_at(offset, n, &b, &b28, &tab);
             first = 0;
@@ -923,6 +957,7 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     vk.vk.max_degree = srs->max_degree;
     vk.vk.supported_degree = max_deg;
     // commit the 12 index polynomials (no hiding, no degree bounds)
+    shard_agree(ctx, *pk);
     int lane = 0;
     for (int i = 0; i < 3; i++) {
         const DVec* polys[4] = {&pk->ar[i].row, &pk->ar[i].col, &pk->ar[i].val, &pk->ar[i].row_col};
@@ -1004,6 +1039,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     if (pr.ncons != pk.info.num_constraints || pr.inst.size() + pr.nwit != pk.info.num_variables ||
         pr.inst.size() != pk.info.num_instance_variables)
         throw MarlinError(SWM_ERR_MISMATCH, "InstanceDoesNotMatchIndex");
+    shard_agree(ctx, pk);  // one proof over several ranks: all of them split the work the same way, or none starts
     const uint64_t H = pk.H, K = pk.K, X = pk.X, Bsz = pk.B;
     const uint64_t M = 4 * H;  // mul_domain = next_pow2(3|H| + 1)
     const unsigned logM = pk.logH + 2;

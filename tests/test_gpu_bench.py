@@ -1,0 +1,35 @@
+"""bench.py's N > 1 code path (process group, the library's RCCL communicator, ONE proof over all ranks, the `sharded` object of
+the JSON line) executed on a single-GPU box: a FRESH child process with SWM_BENCH_FORCE_DIST=1 and a world of one — so that the
+driver's pytest has run those lines before a multi-GPU SCALE run ever does."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_with_a_world_of_one():
+    env = dict(os.environ)
+    env.update({"SWM_BENCH_FORCE_DIST": "1", "SWM_SHARD_FORCE": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log-n", "16",
+                          "--no-cpu-baseline", "--no-drop-in"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    sh = line["sharded"]
+    assert sh and "error" not in sh, sh
+    assert sh["proof_bytes_identical_on_all_ranks"] is True
+    assert sh["ranks"] == 1 and sh["exchanges_per_proof"] >= 4   # the per-round all-gathers went through the library's communicator
+    assert sh["ms_per_proof"] > 0

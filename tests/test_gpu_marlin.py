@@ -845,3 +845,59 @@ def test_reference_test_circuit_example(M, S, W):
         M.MarlinInst.prove(pk, TestCircuit(1, 2), M.generate_rand())
     pk.free()
     srs.free()
+
+
+# ---- BASELINE configs[3] at its own size, sharded: one proof over several ranks with rounds 1 - 3 on a rank's share
+def test_sharded_prover_2p20_eight_ranks_golden_bytes(M, S, W):
+    """EIGHT thread ranks (the node size north_star names) prove the 2^20-constraint headline circuit, every rank with its own
+    key (narrower window tables: the width of a rank's share) and its share of rounds 1 - 3: the model's key and proof bytes
+    (tests/golden/marlin_large.json, synthetic_2p20) on every rank, and the exchanges of the sharded rounds did take place."""
+    case = golden("marlin_large.json")["synthetic_2p20"]
+    n = case["num_constraints"]
+    cs, public = W.synthetic_r1cs(n, h2i(case["a"]), h2i(case["b"]))
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        before = ctx.exchange_stats()[0]
+        proof = M.generate_proof(cs, pk, rng)
+        out = (S.serialize_verifying_key(vk).hex(), S.serialize_proof(proof).hex(), ctx.exchange_stats()[0] - before)
+        pk.free()
+        return out
+
+    for vk_hex, proof_hex, exchanges in _run_sharded(8, build):
+        assert vk_hex == case["vk"]
+        assert proof_hex == case["proof"]
+        assert exchanges >= 17, exchanges   # the rank-agreement record + rounds 1 - 3 sharded (all-to-alls, all-gathers) + the partial sums
+
+
+def test_sharded_prover_2p22_two_ranks_same_bytes_as_one_context(M, S, W):
+    """BASELINE configs[3] itself: 2^22 constraints (2 x ~43 GB of keys on the one 288-GB GPU of the test box), two thread ranks
+    with rounds 1 - 3 sharded — the proof and key bytes of the single-context proof of the same system."""
+    n = 1 << 22
+    cs, public = W.synthetic_r1cs(n, 0x22222222, 0x44444444)
+    seed = bytes([0x22] * 32)
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(n, n, n, rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        srs.free()
+        before = ctx.exchange_stats()[0]
+        proof = M.generate_proof(cs, pk, M.rng_from_seed(seed))
+        out = (S.serialize_verifying_key(vk), S.serialize_proof(proof), ctx.exchange_stats()[0] - before)
+        pk.free()
+        return out
+
+    from simpleworks_amd._lib import Context
+    single = Context(0)
+    vk1, proof1, ex1 = build(single)
+    single.close()
+    assert ex1 == 0
+    assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
+    for vk_b, proof_b, exchanges in _run_sharded(2, build):
+        assert vk_b == vk1
+        assert proof_b == proof1
+        assert exchanges >= 17, exchanges
