@@ -3,6 +3,10 @@
 use std::env;
 
 fn main() {
+    // the GPU-free pin kit (tests/pin_golden.rs) uses none of the library: nothing to link
+    if env::var_os("CARGO_FEATURE_PIN").is_some() {
+        return;
+    }
     println!("cargo:rerun-if-env-changed=SWMARLIN_LIB_DIR");
     println!("cargo:rerun-if-env-changed=ROCM_PATH");
     if let Ok(dir) = env::var("SWMARLIN_LIB_DIR") {

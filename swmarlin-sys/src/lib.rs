@@ -12,7 +12,12 @@
 //! the library (the reference's alias of arkworks' CPU prover is kept as `ArkMarlinInst`).
 //!
 //! EXPERIMENTAL: written without a Rust toolchain or the arkworks sources at hand; never compiled.  See INTEGRATION.md.
+// (feature `pin`: the GPU-free pin kit, tests/pin_golden.rs — arkworks only, nothing of the library is compiled or linked)
+#[cfg(not(feature = "pin"))]
 pub mod ffi;
+#[cfg(not(feature = "pin"))]
 pub mod marlin;
+#[cfg(not(feature = "pin"))]
 pub mod merkle;
+#[cfg(not(feature = "pin"))]
 mod convert;

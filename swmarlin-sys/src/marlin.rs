@@ -3,10 +3,11 @@
 //! (`anyhow!("{:?}", e)`), with the arithmetic running in libswmarlin.so on an MI355X.
 //!
 //! How arkworks values cross the boundary
-//! * `&mut StdRng`         -> by STATE: `swm_rng_from_chacha(seed, word position)`, position written back afterwards — the
-//!                            library produces the caller's ChaCha12 stream itself (on the GPU for the 3|H| mask coefficients),
-//!                            word for word as arkworks would draw it; any other `RngCore` goes through
-//!                            `swm_rng_from_callback` over a `fill_bytes` trampoline (same stream, at the caller's speed).
+//! * `&mut StdRng`         -> through `swm_rng_from_callback` over a `fill_bytes` trampoline (the caller's stream, word for
+//!                            word, at the caller's speed: 95 instead of 58 ms per 2^20 proof); with the cargo feature
+//!                            `adopt-std-rng` by STATE — `swm_rng_from_chacha(seed, word position)`, position written back
+//!                            afterwards: the library then produces the ChaCha12 stream itself (on the GPU for the 3|H| mask
+//!                            coefficients).  Opt-in because it views the StdRng through a layout rand does not guarantee.
 //! * `ConstraintSystemRef` -> `PackedR1cs::from_cs` (matrices + assignments as flat arrays).
 //! * `UniversalSRS`        -> `swm_srs_export` / `swm_srs_import` (the fields of kzg10::UniversalParams).
 //! * `ProvingKey`, `VerifyingKey`, `MarlinProof` -> their CanonicalSerialize bytes, which the library reads and writes
@@ -152,9 +153,11 @@ unsafe extern "C" fn fill_bytes_trampoline<R: RngCore>(user: *mut c_void, dest: 
 /// observes exactly what it would have observed through the callback.  The view below relies on the single-field tuple struct
 /// having its field's layout; `std_rng_view_is_sound` checks that once per process on a generator with a known stream
 /// (size, alignment, seed, position, next words) and the callback path is used if anything differs.
+#[cfg(feature = "adopt-std-rng")]
 fn std_rng_as_chacha(rng: &mut StdRng) -> &mut rand_chacha::ChaCha12Rng {
     unsafe { &mut *(rng as *mut StdRng as *mut rand_chacha::ChaCha12Rng) }
 }
+#[cfg(feature = "adopt-std-rng")]
 fn std_rng_view_is_sound() -> bool {
     use rand::SeedableRng;
     use std::sync::OnceLock;
@@ -187,6 +190,10 @@ fn std_rng_view_is_sound() -> bool {
 /// reference always passes its `StdRng`); the handle does not outlive the borrow.  A `StdRng` on stream 0 is handed over by
 /// state (see above), everything else through the `fill_bytes` callback.
 fn with_rng<R: RngCore + 'static, T>(rng: &mut R, f: impl FnOnce(*mut swm_rng) -> std::result::Result<T, SwmError>) -> std::result::Result<T, SwmError> {
+    // State adoption reads the StdRng through a pointer cast whose layout rand does not guarantee (a tuple struct without
+    // #[repr(transparent)]): formally undefined behaviour, so it is opt-in (cargo feature `adopt-std-rng`) until this crate
+    // has been built and tested against the rand version in use.  The default is the fill_bytes callback: the same stream.
+    #[cfg(feature = "adopt-std-rng")]
     if let Some(std_rng) = (rng as &mut dyn std::any::Any).downcast_mut::<StdRng>() {
         if std_rng_view_is_sound() {
             let inner = std_rng_as_chacha(std_rng);

@@ -1,0 +1,250 @@
+//! GPU-FREE PIN KIT: runs arkworks' OWN CPU implementation — the `MarlinInst = Marlin<Fr, MultiPC, FS>` of
+//! /root/reference/src/marlin/mod.rs:12-14, `ark_std::test_rng()` (`generate_rand`, :33-35), the ark-serialize codecs of
+//! src/marlin/serialization.rs:5-45, the Pedersen `CRH::setup` / `MerkleTree::new` of examples/merkle-tree/main.rs:103-121 — and
+//! asserts that what it emits equals, byte for byte, the golden files the MI355X library's GPU tests are checked against
+//! (tests/golden/{marlin,pk_bytes,rng,pedersen}.json of the library's repository).  Those files come from a Python restatement
+//! of arkworks 0.3; this test is what turns "HIP path == restatement" into "HIP path == arkworks".
+//!
+//! It needs a Rust toolchain and the network (crates.io + the Entropy1729 marlin fork) — neither exists where the library
+//! is developed — but NO GPU and NO libswmarlin.so: the `pin` feature leaves the FFI modules out and build.rs links nothing.
+//!
+//!     cargo test --manifest-path swmarlin-sys/Cargo.toml --features pin --test pin_golden --release -- --nocapture
+//!
+//! A failure names the case and the artefact (proof / verifying key / proving key / rng word / generator / root): that is
+//! the [U]-tagged detail of SURVEY.md Appendix A to fix in oracle/pyref (and then in the library).
+//!
+//! EXPERIMENTAL like the rest of this crate: written without a compiler at hand.
+#![cfg(feature = "pin")]
+
+use ark_bls12_377::{Bls12_377, Fq, Fr};
+use ark_crypto_primitives::crh::injective_map::{PedersenCRHCompressor, TECompressor};
+use ark_crypto_primitives::crh::{pedersen, TwoToOneCRH, CRH};
+use ark_crypto_primitives::merkle_tree::{Config, MerkleTree};
+use ark_ec::{AffineCurve, ProjectiveCurve};
+use ark_ed_on_bls12_377::EdwardsProjective;
+use ark_ff::{BigInteger, PrimeField, UniformRand};
+use ark_marlin::{Marlin, SimpleHashFiatShamirRng};
+use ark_poly::univariate::DensePolynomial;
+use ark_poly_commit::marlin_pc::MarlinKZG10;
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystemRef, LinearCombination, SynthesisError, Variable};
+use ark_serialize::CanonicalSerialize;
+use blake2::Blake2s;
+use rand::RngCore;
+use rand_chacha::ChaChaRng;
+use serde_json::Value;
+use sha2::{Digest, Sha256};
+use std::path::PathBuf;
+
+type MultiPC = MarlinKZG10<Bls12_377, DensePolynomial<Fr>>;
+type FS = SimpleHashFiatShamirRng<Blake2s, ChaChaRng>;
+/// `MarlinInst` of /root/reference/src/marlin/mod.rs:14
+type ArkMarlinInst = Marlin<Fr, MultiPC, FS>;
+
+fn golden(name: &str) -> Value {
+    let dir = std::env::var("SWM_GOLDEN_DIR").map(PathBuf::from).unwrap_or_else(|_| {
+        PathBuf::from(env!("CARGO_MANIFEST_DIR")).join("..").join("tests").join("golden")
+    });
+    let text = std::fs::read_to_string(dir.join(name)).unwrap_or_else(|e| panic!("{}: {}", name, e));
+    serde_json::from_str(&text).unwrap()
+}
+fn be_bytes(hex_str: &str) -> Vec<u8> {
+    let h = hex_str.trim_start_matches("0x");
+    let h = if h.len() % 2 == 1 { format!("0{}", h) } else { h.to_string() };
+    hex::decode(h).unwrap()
+}
+fn fr_of(v: &Value) -> Fr {
+    Fr::from_be_bytes_mod_order(&be_bytes(v.as_str().unwrap()))
+}
+/// big-endian hex without leading zeros, as the golden files write integers
+fn hex_int<F: PrimeField>(x: &F) -> String {
+    let s = hex::encode(x.into_repr().to_bytes_be());
+    let t = s.trim_start_matches('0');
+    format!("0x{}", if t.is_empty() { "0" } else { t })
+}
+fn ser<T: CanonicalSerialize>(x: &T) -> Vec<u8> {
+    let mut b = Vec::new();
+    x.serialize(&mut b).unwrap();
+    b
+}
+
+/// A circuit of tests/golden/pin_circuits.json replayed into ark-relations (the vocabulary the Python builders mirror)
+#[derive(Clone)]
+struct Replay {
+    instance: Vec<Fr>, // without the constant one
+    witness: Vec<Fr>,
+    rows: Vec<[Vec<(Fr, bool, usize)>; 3]>, // (coefficient, is_witness, index)
+}
+impl Replay {
+    fn load(v: &Value) -> Self {
+        let nums = |k: &str| v[k].as_array().unwrap().iter().map(fr_of).collect::<Vec<_>>();
+        let lc = |t: &Value| {
+            t.as_array().unwrap().iter().map(|e| {
+                    (fr_of(&e[0]), e[1][0].as_str().unwrap() == "w", e[1][1].as_u64().unwrap() as usize)
+                }).collect::<Vec<_>>()
+        };
+        let inst = nums("instance");
+        assert!(inst[0] == Fr::from(1u64));
+        Replay {
+            instance: inst[1..].to_vec(),
+            witness: nums("witness"),
+            rows: v["constraints"].as_array().unwrap().iter().map(|r| [lc(&r[0]), lc(&r[1]), lc(&r[2])]).collect(),
+        }
+    }
+    fn sizes(&self) -> (usize, usize, usize) {
+        // (constraints, variables, largest matrix) as gen_golden.py passes them for the cases without fixed SRS sizes
+        let nnz = (0..3).map(|m| self.rows.iter().map(|r| r[m].len()).sum::<usize>()).max().unwrap();
+        (self.rows.len(), 1 + self.instance.len() + self.witness.len(), nnz)
+    }
+}
+impl ConstraintSynthesizer<Fr> for Replay {
+    fn generate_constraints(self, cs: ConstraintSystemRef<Fr>) -> Result<(), SynthesisError> {
+        let mut iv = vec![Variable::One];
+        for v in &self.instance {
+            let v = *v;
+            iv.push(cs.new_input_variable(|| Ok(v))?);
+        }
+        let mut wv = Vec::new();
+        for v in &self.witness {
+            let v = *v;
+            wv.push(cs.new_witness_variable(|| Ok(v))?);
+        }
+        for row in &self.rows {
+            let mk = |terms: &Vec<(Fr, bool, usize)>| {
+                let mut l = LinearCombination::<Fr>::zero();
+                for (c, is_w, k) in terms {
+                    l = l + (*c, if *is_w { wv[*k] } else { iv[*k] });
+                }
+                l
+            };
+            cs.enforce_constraint(mk(&row[0]), mk(&row[1]), mk(&row[2]))?;
+        }
+        Ok(())
+    }
+}
+
+/// proof + verifying-key bytes: ONE test_rng for universal_setup and prove, as the reference's callers do
+/// (examples/manual-constraints.rs:86-100, src/merkle_tree/simple_merkle_tree.rs:39-127)
+#[test]
+fn marlin_proof_and_verifying_key_bytes() {
+    let cases = golden("marlin.json");
+    let circuits = golden("pin_circuits.json");
+    for (name, case) in cases.as_object().unwrap() {
+        let circuit = Replay::load(&circuits["marlin"][name]);
+        let s: Vec<usize> = case["srs"].as_array().unwrap().iter().map(|x| x.as_u64().unwrap() as usize).collect();
+        let mut rng = ark_std::test_rng();
+        let srs = ArkMarlinInst::universal_setup(s[0], s[1], s[2], &mut rng).unwrap();
+        let (pk, vk) = ArkMarlinInst::index(&srs, circuit.clone()).unwrap();
+        assert_eq!(hex::encode(ser(&vk)), case["vk"].as_str().unwrap(), "{}: verifying key bytes", name);
+        let proof = ArkMarlinInst::prove(&pk, circuit.clone(), &mut rng).unwrap();
+        assert_eq!(hex::encode(ser(&proof)), case["proof"].as_str().unwrap(), "{}: proof bytes", name);
+        assert!(ArkMarlinInst::verify(&vk, &circuit.instance, &proof, &mut rng).unwrap(), "{}: arkworks rejects its own proof", name);
+        println!("pinned {}: proof {} B, vk {} B", name, ser(&proof).len(), ser(&vk).len());
+    }
+}
+
+/// proving-key bytes (IndexProverKey's CanonicalSerialize: field order and nested layouts are [U] in the library)
+#[test]
+fn proving_key_bytes() {
+    let cases = golden("pk_bytes.json");
+    let circuits = golden("pin_circuits.json");
+    for (name, case) in cases.as_object().unwrap() {
+        let circuit = Replay::load(&circuits["pk_bytes"][name]);
+        let s: Vec<usize> = case["srs"].as_array().unwrap().iter().map(|x| x.as_u64().unwrap() as usize).collect();
+        assert_eq!((s[0], s[1], s[2]), if name == "random_sparse" { circuit.sizes() } else { (s[0], s[1], s[2]) });
+        let mut rng = ark_std::test_rng();
+        let srs = ArkMarlinInst::universal_setup(s[0], s[1], s[2], &mut rng).unwrap();
+        let (pk, _vk) = ArkMarlinInst::index(&srs, circuit).unwrap();
+        let b = ser(&pk);
+        assert_eq!(b.len() as u64, case["len"].as_u64().unwrap(), "{}: proving key length", name);
+        assert_eq!(hex::encode(&b[..64]), case["head"].as_str().unwrap(), "{}: proving key, first 64 bytes", name);
+        assert_eq!(hex::encode(Sha256::digest(&b)), case["sha256"].as_str().unwrap(), "{}: proving key sha256", name);
+    }
+}
+
+/// generate_rand() = ark_std::test_rng(): the keystream and what ark-ff makes of it
+#[test]
+fn test_rng_stream_and_field_draws() {
+    let g = golden("rng.json");
+    let mut r = ark_std::test_rng();
+    for (i, w) in g["test_rng_u64"].as_array().unwrap().iter().enumerate() {
+        let want = u64::from_str_radix(w.as_str().unwrap().trim_start_matches("0x"), 16).unwrap();
+        assert_eq!(r.next_u64(), want, "test_rng word {}", i);
+    }
+    let mut r = ark_std::test_rng();
+    for (i, w) in g["test_rng_fr"].as_array().unwrap().iter().enumerate() {
+        assert_eq!(hex_int(&Fr::rand(&mut r)), w.as_str().unwrap(), "Fr::rand draw {}", i);
+    }
+    assert_eq!(hex_int(&Fq::rand(&mut r)), g["test_rng_then_fq"].as_str().unwrap(), "Fq::rand after five Fr draws");
+    assert_eq!(bool::rand(&mut r), g["test_rng_then_bool"].as_bool().unwrap(), "bool::rand");
+    assert_eq!(format!("{:#x}", u128::rand(&mut r)), g["test_rng_then_u128"].as_str().unwrap(), "u128::rand");
+}
+
+// ---- the Pedersen hash and Merkle tree of BASELINE config #5 (/root/reference/src/merkle_tree/common.rs:11-30, merkle_tree.rs:10-18)
+#[derive(Clone, PartialEq, Eq, Hash)]
+struct TwoToOneWindow;
+impl pedersen::Window for TwoToOneWindow {
+    const WINDOW_SIZE: usize = 4;
+    const NUM_WINDOWS: usize = 128;
+}
+#[derive(Clone, PartialEq, Eq, Hash)]
+struct LeafWindow;
+impl pedersen::Window for LeafWindow {
+    const WINDOW_SIZE: usize = 4;
+    const NUM_WINDOWS: usize = 144;
+}
+type TwoToOneHash = PedersenCRHCompressor<EdwardsProjective, TECompressor, TwoToOneWindow>;
+type LeafHash = PedersenCRHCompressor<EdwardsProjective, TECompressor, LeafWindow>;
+#[derive(Clone)]
+struct MerkleConfig;
+impl Config for MerkleConfig {
+    type LeafHash = LeafHash;
+    type TwoToOneHash = TwoToOneHash;
+}
+fn generators_sha256(gens: &[Vec<EdwardsProjective>]) -> String {
+    // x then y of every generator, 32 little-endian bytes each (tests/golden/gen_golden_pedersen.py gen_bytes)
+    let mut h = Sha256::new();
+    for row in gens {
+        for p in row {
+            let a = p.into_affine();
+            h.update(a.x.into_repr().to_bytes_le());
+            h.update(a.y.into_repr().to_bytes_le());
+        }
+    }
+    hex::encode(h.finalize())
+}
+#[test]
+fn pedersen_parameters_hashes_and_the_eight_leaf_tree() {
+    let g = golden("pedersen.json");
+    // examples/merkle-tree/main.rs:103-109: a fresh test_rng, LeafHash::setup then TwoToOneHash::setup
+    let mut rng = ark_std::test_rng();
+    let leaf_params = <LeafHash as CRH>::setup(&mut rng).unwrap();
+    let two_params = <TwoToOneHash as TwoToOneCRH>::setup(&mut rng).unwrap();
+    assert_eq!(generators_sha256(&leaf_params.generators), g["leaf_generators_sha256"].as_str().unwrap(), "LeafHash generators");
+    assert_eq!(generators_sha256(&two_params.generators), g["two_to_one_generators_sha256"].as_str().unwrap(), "TwoToOneHash generators");
+    let pt = |p: &EdwardsProjective| {
+        let a = p.into_affine();
+        vec![hex_int(&a.x), hex_int(&a.y)]
+    };
+    let want = |k: &str| g[k].as_array().unwrap().iter().map(|v| v.as_str().unwrap().to_string()).collect::<Vec<_>>();
+    assert_eq!(pt(&leaf_params.generators[0][0]), want("leaf_generator_0_0"));
+    assert_eq!(pt(&leaf_params.generators[143][3]), want("leaf_generator_143_3"));
+    assert_eq!(pt(&two_params.generators[0][0]), want("two_to_one_generator_0_0"));
+    assert_eq!(pt(&two_params.generators[127][3]), want("two_to_one_generator_127_3"));
+    // src/hash/mod.rs:23-28 pedersen_hash(input): CRH::evaluate + TECompressor
+    for case in g["pedersen_hash"].as_array().unwrap() {
+        let input = hex::decode(case["input"].as_str().unwrap()).unwrap();
+        let d = <LeafHash as CRH>::evaluate(&leaf_params, &input).unwrap();
+        assert_eq!(hex_int(&d), case["digest"].as_str().unwrap(), "pedersen_hash({})", case["input"]);
+    }
+    for case in g["two_to_one_hash"].as_array().unwrap() {
+        let input = hex::decode(case["input"].as_str().unwrap()).unwrap();
+        let d = <TwoToOneHash as CRH>::evaluate(&two_params, &input).unwrap();
+        assert_eq!(hex_int(&d), case["digest"].as_str().unwrap(), "two-to-one hash of {}", case["input"]);
+    }
+    // examples/merkle-tree/main.rs:111-121: the tree over [1, 2, 3, 10, 9, 17, 70, 45], the path of leaf 4
+    let leaves: Vec<[u8; 1]> = g["tree"]["leaves"].as_array().unwrap().iter().map(|v| [v.as_u64().unwrap() as u8]).collect();
+    let tree = MerkleTree::<MerkleConfig>::new(&leaf_params, &two_params, &leaves).unwrap();
+    assert_eq!(hex_int(&tree.root()), g["tree"]["root"].as_str().unwrap(), "root of the eight-leaf tree");
+    let path = tree.generate_proof(g["tree"]["index"].as_u64().unwrap() as usize).unwrap();
+    assert!(path.verify(&leaf_params, &two_params, &tree.root(), &leaves[4]).unwrap());
+}
