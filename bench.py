@@ -16,6 +16,7 @@ all ranks: every commitment MSM split by point range, partial sums all-gathered,
 (simpleworks_amd.dist.enable_sharded_prover).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import re
@@ -437,13 +438,28 @@ def main():
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need their own rocprofv3 invocation,
         # MI355X_MICROARCH.md); taken from the newest committed PMC summary under profiles/ and scaled per point.
-        traffic, traffic_source = None, None
+        def source_sha16(files):
+            """identity of a kernel's source files (tools/pmc_summaries.py stores it with every counter summary): a summary whose
+            sources have changed since is reported as stale — the figure is from another kernel than the one timed here"""
+            h = hashlib.sha256()
+            try:
+                for f in files:
+                    h.update(open(os.path.join(ROOT, "simpleworks_amd", "csrc", f), "rb").read())
+            except OSError:
+                return None
+            return h.hexdigest()[:16]
+
+        def stale(summary, files):
+            return None if summary is None else summary.get("source_sha16") != source_sha16(files)
+        ACC_SOURCES = ("msm.hip", "fq28.cuh", "fq28_mul_asm.inc", "g1.cuh")
+        traffic, traffic_source, traffic_stale = None, None, None
         try:
             pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc_msm_accumulate\.json", f)),
                           key=lambda f: int(f[1:f.index("_")]))
             if pmcs:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
                 traffic = pmc["hbm_bytes_per_point"] * (alg_bytes / 128.0)
+                traffic_stale = stale(pmc, ACC_SOURCES)
                 traffic_source = "profiles/" + pmcs[-1] + " (separate rocprofv3 --pmc passes; bytes per point scaled to this launch size)"
         except Exception:
             traffic = None
@@ -470,6 +486,7 @@ def main():
                               "frac": a / HBM_PEAK_GBS,
                               "traffic": ntt_pmc["hbm_bytes_per_element_per_transform"] * work["ntt_elements"] / args.steps if ntt_pmc else None,
                               "traffic_source": ntt_src and ntt_src + " (separate --pmc passes on the stand-alone transform, bytes per element scaled to this step)",
+                              "traffic_stale": stale(ntt_pmc, ("ntt.hip", "fr29.cuh", "fr29_mul_asm.inc")),
                               "algorithmic_bytes": "64 B x %d elements over %d transforms (%d launches)"
                                                    % (work["ntt_elements"] / args.steps, work["ntt_calls"] / args.steps,
                                                       prof["ntt_pass"]["calls"] / args.steps),
@@ -485,6 +502,7 @@ def main():
                               "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                               "traffic": spmv_pmc["hbm_bytes_per_nnz"] * work["spmv_nnz"] / args.steps if spmv_pmc else None,
                               "traffic_source": spmv_src and spmv_src + " (separate --pmc passes on the stand-alone mat-vec, bytes per non-zero scaled to this step)",
+                              "traffic_stale": stale(spmv_pmc, ("spmv.hip",)),
                               "algorithmic_bytes": "68 B x %d non-zeros + 36 B x %d rows over %d mat-vecs"
                                                    % (work["spmv_nnz"] / args.steps, work["spmv_rows"] / args.steps,
                                                       work["spmv_calls"] / args.steps),
@@ -501,7 +519,7 @@ def main():
                                                       "192-B partials all-gathered, transforms replicated",
                                      "msm": "point-range shards, all-gather of 144-B partials"}[args.workload]},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "zero_scalar_points_per_launch": zero_pts / work["msm_calls"],
@@ -511,7 +529,8 @@ def main():
                          # device) against the rate at which every wave-cycle would issue a vector instruction, from the
                          # committed SQ counters of the same kernel (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
                          "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
-                         "issue_ceiling_mixed_adds_per_s": ceiling, "issue_ceiling_source": sq_src},
+                         "issue_ceiling_mixed_adds_per_s": ceiling, "issue_ceiling_source": sq_src,
+                         "issue_ceiling_stale": stale(sq, ACC_SOURCES)},
             "roofline_secondary": secondary,
             "sharded": sharded_info,
             "verify_ms_host": verify_ms if args.workload != "msm" else None,

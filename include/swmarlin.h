@@ -317,6 +317,11 @@ int swm_selftest_mul_throughput(swm_ctx *ctx, int which, size_t threads, int ite
  * e(P, Q) != 1; 5 e(P, Q) e(-P, Q) == 1 and e(P, Q)^2 != 1 through product_of_pairings_is_one; 6 the shared Miller
  * accumulator of two pairs == the product of two single loops. */
 int swm_selftest_pairing(unsigned *failed);
+/* Host-side self-test of the single-element Fr inversion the device kernels use (frinv.cuh, fr_inv_bingcd: binary GCD on
+ * 64-bit approximations; tail of ark_ff::batch_inversion's one field inversion): out = a^-1 for n Montgomery-form elements
+ * a != 0, computed on the CPU by the same function the GPU lanes run; *fallbacks counts inputs whose 17 rounds did not end
+ * in (0, 1) (the kernels then use the exact loop; expected 0). */
+int swm_selftest_fr_inv(const uint64_t *a_mont, uint64_t *out_mont, size_t n, unsigned *fallbacks);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,7 @@ ABI = {
     "swm_selftest_g1_add": (_int, [_vp, _u64p, _u64p, _u64p, _sz]),
     "swm_selftest_mul_throughput": (_int, [_vp, _int, _sz, _int, ctypes.POINTER(ctypes.c_float)]),
     "swm_selftest_pairing": (_int, [ctypes.POINTER(ctypes.c_uint)]),
+    "swm_selftest_fr_inv": (_int, [_u64p, _u64p, _sz, ctypes.POINTER(ctypes.c_uint)]),
 }
 
 

@@ -358,6 +358,7 @@ void swm_destroy(swm_ctx* ctx) {
     }
     for (auto& kv : ctx->ntt_small) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+    if (ctx->h2d_stage) (void)hipHostFree(ctx->h2d_stage);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < swm_ctx::MSM_LANES; i++)
         if (ctx->aux_stream[i]) {

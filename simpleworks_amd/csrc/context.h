@@ -55,6 +55,8 @@ struct swm_ctx {
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
     void* pinned_dev = nullptr;  // device address of `pinned`
+    void* h2d_stage = nullptr;   // small pinned staging area for the witness upload of small proofs (marlin.hip, upload_small)
+    size_t h2d_stage_used = 0;
     hipEvent_t slot_event[MSM_SLOTS] = {nullptr};
     bool slot_busy[MSM_SLOTS] = {false};  // enqueued and not yet collected by msm_finish
     hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (stage A -> stage T, deferred bucket stages)

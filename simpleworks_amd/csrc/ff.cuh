@@ -24,6 +24,7 @@ struct FrParams {
     static constexpr uint32_t P[8] = SWM_FR_MODULUS;
     static constexpr uint32_t R1[8] = SWM_FR_R1;
     static constexpr uint32_t R2[8] = SWM_FR_R2;
+    static constexpr uint32_t R3[8] = SWM_FR_R3;
     static constexpr uint32_t PM2[8] = SWM_FR_PM2;
     static constexpr int BITS = 253;
 };

@@ -1016,6 +1016,24 @@ struct PhaseTrace {
     }
 };
 
+// Host -> device copy of the caller's (pageable) instance / witness buffers.  hipMemcpyAsync from pageable memory locks the
+// pages first: ~0.3 ms before anything moves, whatever the size — a tenth of a 2^12-constraint proof (r04 trace: the first
+// kernel that needs z started 0.37 ms into the proof).  Up to H2D_STAGE_BYTES per proof go through a pinned staging area of
+// the context instead (a host memcpy of a few hundred KB, then a truly asynchronous copy); larger buffers keep the direct
+// path, where the one-off lock is small against the transfer and a host-side copy of tens of MB would not be.
+static constexpr size_t H2D_STAGE_BYTES = 1u << 20;
+void upload_small(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return;
+    if (bytes <= H2D_STAGE_BYTES - ctx->h2d_stage_used) {
+        if (!ctx->h2d_stage) hip_check(ctx, hipHostMalloc(&ctx->h2d_stage, H2D_STAGE_BYTES, hipHostMallocDefault), "pinned staging");
+        char* at = (char*)ctx->h2d_stage + ctx->h2d_stage_used;
+        memcpy(at, src, bytes);
+        ctx->h2d_stage_used += (bytes + 255) & ~(size_t)255;
+        hip_check(ctx, hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, ctx->stream), "h2d");
+        return;
+    }
+    hip_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "h2d");
+}
 std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk) {
     PhaseTrace tr(ctx);
     // padded shape (pad_input_for_indexer_and_prover + make_matrices_square); the witness itself is uploaded straight
@@ -1104,9 +1122,10 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
 
     // ---- z on the device, z_A = A z, z_B = B z  (K3)
     DVec z(ctx, nvars);
-    hip_check(ctx, hipMemcpyAsync(z.p, pr.inst.data(), ninst * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
-    if (pr.nwit_orig)
-        hip_check(ctx, hipMemcpyAsync(z.p + ninst, cs->witness, pr.nwit_orig * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream), "h2d");
+    // (the staging area is free again: whatever the previous proof of this context staged was consumed before that proof returned)
+    ctx->h2d_stage_used = 0;
+    upload_small(ctx, z.p, pr.inst.data(), ninst * sizeof(Fr));
+    if (pr.nwit_orig) upload_small(ctx, z.p + ninst, cs->witness, pr.nwit_orig * sizeof(Fr));
     if (pr.nwit > pr.nwit_orig) {  // dummy unconstrained variables have the value one
         Fr* zp = z.p + ninst + pr.nwit_orig;
         ew(ctx, "z_pad", pr.nwit - pr.nwit_orig, [=] __device__(size_t i) { zp[i] = fp_one<Fr>(); });

@@ -4,6 +4,7 @@
 // (K3, the R1CS mat-vec, lives in spmv.hip.)  K4 replaces ark_ff::batch_inversion and the cfg_iter pointwise loops of ark-marlin's prover rounds.
 // All of it is HBM-bound integer work: one lane per row / element, 16-B vector loads, no LDS, no MFMA.
 // Algorithmic bytes: vec_mul 96 B per element; batch inverse 64 B per element.
+#include <string.h>
 #include "context.h"
 #include "fq28.cuh"
 #include "frinv.cuh"
@@ -217,3 +218,20 @@ int selftest_g1_add_run(swm_ctx* ctx, const void* a, const void* b, void* out, s
 }
 
 }  // namespace swm
+
+// ---------------------------------------------------------------------------------------------- host self-test of the single-element inversion
+extern "C" int swm_selftest_fr_inv(const uint64_t* a_mont, uint64_t* out_mont, size_t n, unsigned* fallbacks) {
+    using namespace swm;
+    if ((n && (!a_mont || !out_mont)) || !fallbacks) return SWM_ERR_INVALID_ARG;
+    *fallbacks = 0;
+    for (size_t i = 0; i < n; i++) {
+        Fr a;
+        memcpy(a.v, a_mont + 4 * i, 32);
+        if (fp_is_zero(a)) return SWM_ERR_INVALID_ARG;
+        bool ok = false;
+        const Fr r = fr_inv_bingcd(a, &ok);
+        if (!ok) (*fallbacks)++;
+        memcpy(out_mont + 4 * i, r.v, 32);
+    }
+    return SWM_OK;
+}

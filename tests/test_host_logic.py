@@ -267,3 +267,29 @@ def test_host_pairing_identities():
     failed = ctypes.c_uint(0xFFFF)
     assert L.load_library().swm_selftest_pairing(ctypes.byref(failed)) == 0
     assert failed.value == 0, bin(failed.value)
+
+
+def test_single_element_inversion_on_the_host():
+    """frinv.cuh fr_inv_bingcd (binary GCD on 64-bit approximations: the one field inversion behind every batch inversion and
+    every Pedersen digest) compiled for the host: a^-1 for edge values and random elements against Python's pow, and the 17
+    rounds always end in (0, 1) — no input needs the exact fall-back loop."""
+    import ctypes
+    import random
+    import numpy as np
+    import simpleworks_amd._lib as L
+    lib = L.load_library()
+    R = 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001
+    RM = (1 << 256) % R
+    rnd = random.Random(2026)
+    vals = [1, 2, 3, R - 1, R - 2, (R + 1) // 2, 1 << 252, (1 << 252) - 1, (1 << 31) - 1, 1 << 31, (1 << 64) + 1]
+    vals += [rnd.randrange(1, R) for _ in range(4000)] + [rnd.randrange(1, 1 << rnd.randrange(1, 253)) for _ in range(1000)]
+    a = np.array([[(v * RM % R >> (64 * i)) & (2 ** 64 - 1) for i in range(4)] for v in vals], dtype=np.uint64)
+    out = np.zeros_like(a)
+    fallbacks = ctypes.c_uint(99)
+    p64 = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    assert lib.swm_selftest_fr_inv(p64(a), p64(out), len(vals), ctypes.byref(fallbacks)) == 0
+    assert fallbacks.value == 0
+    for v, o in zip(vals, out):
+        assert sum(int(o[i]) << (64 * i) for i in range(4)) == pow(v, -1, R) * RM % R, hex(v)
+    zero = np.zeros((1, 4), dtype=np.uint64)
+    assert lib.swm_selftest_fr_inv(p64(zero), p64(out), 1, ctypes.byref(fallbacks)) == -1   # SWM_ERR_INVALID_ARG: zero has no inverse

@@ -13,6 +13,7 @@ python3 bench.py --circuit merkle --steps 10 --warmup 2 > $out/bench_merkle.json
 python3 bench.py --workload msm --steps 12 --warmup 2 > $out/bench_msm.json 2> $out/bench_msm.err
 python3 bench.py --workload msm --log-n 22 --steps 8 --warmup 2 --cpu-log-n 18 > $out/bench_msm_2p22.json 2> $out/bench_msm22.err
 rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_prove.log 2>&1
+python3 tools/trace_share.py $out/prof_prove/run_kernel_trace.csv > $out/timeline_share.txt 2>&1 || python3 tools/trace_share.py $(ls $out/prof_prove/*/run_kernel_trace.csv | head -1) > $out/timeline_share.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $out/prof_merkle -o run --output-format csv -- python3 bench.py --circuit merkle --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_merkle.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/prof_msm -o run --output-format csv -- python3 bench.py --workload msm --steps 12 --warmup 2 --no-cpu-baseline > $out/prof_msm.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_fetch -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
@@ -20,6 +21,13 @@ rocprofv3 --pmc WRITE_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_wri
 # SQ issue counters of the dominant kernel (8 SQ slots = one pass), then FETCH / WRITE of the two secondary kernels alone
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-include-regex msm_accumulate -d $out/pmc_sq -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-include-regex msm_accumulate -d $out/pmc_grbm -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_grbm.log 2>&1
+# r04: the SQ issue counters of the kernels beside the dominant one — the transform alone on the chip, and the
+# bucket stage + sort kernels of a stand-alone MSM — each with a GRBM pass for the clock
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+rocprofv3 --pmc $SQ --kernel-include-regex ntt_pass -d $out/pmc_sq_ntt -o run --output-format csv -- python3 tools/ubench/ntt_one.py 22 5 > $out/pmc_sq_ntt.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-include-regex ntt_pass -d $out/pmc_grbm_ntt -o run --output-format csv -- python3 tools/ubench/ntt_one.py 22 5 > $out/pmc_grbm_ntt.log 2>&1
+rocprofv3 --pmc $SQ --kernel-include-regex 'msm_bucket_reduce|msm_flat_partition|msm_flat_bin_sort|msm_digits' -d $out/pmc_sq_msm_other -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_sq_msm_other.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-include-regex 'msm_bucket_reduce|msm_flat_partition|msm_flat_bin_sort|msm_digits' -d $out/pmc_grbm_msm_other -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_grbm_msm_other.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex ntt_pass -d $out/pmc_ntt_fetch -o run --output-format csv -- python3 tools/ubench/ntt_one.py 22 5 > $out/pmc_ntt_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex ntt_pass -d $out/pmc_ntt_write -o run --output-format csv -- python3 tools/ubench/ntt_one.py 22 5 > $out/pmc_ntt_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex spmv -d $out/pmc_spmv_fetch -o run --output-format csv -- python3 tools/ubench/spmv_one.py 20 5 > $out/pmc_spmv_fetch.log 2>&1
