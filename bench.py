@@ -374,7 +374,6 @@ def main():
     # reported as the `sharded` sub-object.  Runs in a watchdog thread: a stuck collective must not cost the headline line.
     sharded_info = None
     if use_dist and args.workload == "prove" and not os.environ.get("SWM_BENCH_NO_SHARDED"):
-        import hashlib
         import threading
         box = {}
 

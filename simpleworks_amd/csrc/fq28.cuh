@@ -429,6 +429,9 @@ struct Fq28TeConsts {
 struct T28 {
     Fq28 x, y, t, z;
 };
+#ifndef SWM_TE_EARLY_LOADS
+#define SWM_TE_EARLY_LOADS 1
+#endif
 // one coordinate of a table row (G1TE: fourteen limbs in a 64-byte sector): three 16-byte loads and an 8-byte one
 __device__ __forceinline__ Fq28 te28_load_coord(const uint32_t* __restrict__ p) {
     const uint4 v0 = *reinterpret_cast<const uint4*>(p), v1 = *reinterpret_cast<const uint4*>(p + 4),
@@ -461,9 +464,20 @@ __device__ __forceinline__ void te28_madd_row(T28& a, const G1TE* __restrict__ r
         d.l[i] = a.y.l[i] + Fq28Consts::SPREAD4[i] - a.x.l[i];
         s.l[i] = a.y.l[i] + a.x.l[i];
     }
+#if SWM_TE_EARLY_LOADS
+    // all three coordinates of the row are requested before the first product: one exposed memory round trip per addition
+    // instead of three (the compiler otherwise sinks each coordinate's loads to the product that consumes it, and with tables
+    // of tens of GB — 2^22-constraint keys — every round trip is a TLB miss and a DRAM page miss: measured r04)
+    const Fq28 ra = te28_load_coord(pa), rb = te28_load_coord(pb), rk = te28_load_coord(rp->kt);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fq28 A = M::mul(d, ra);
+    const Fq28 B = M::mul(s, rb);
+    const Fq28 C = M::mul(a.t, rk);
+#else
     const Fq28 A = M::mul(d, te28_load_coord(pa));
     const Fq28 B = M::mul(s, te28_load_coord(pb));
     const Fq28 C = M::mul(a.t, te28_load_coord(rp->kt));
+#endif
     Fq28 E, H, F, G;
 #pragma unroll
     for (int i = 0; i < 14; i++) {

@@ -391,17 +391,21 @@ static constexpr uint32_t FLAT_BIN_CAP = 32768;  // entries a bin may hold to be
 // The per-bin cursors of msm_flat_partition sit one per 128-byte line: every workgroup of the launch reserves its runs with
 // one returning atomic per bin, and packed (32 cursors to a line) those atomics queued up behind one another at the
 // memory side — 135 of the kernel's 191 us at 2^20 points (measured by replacing the atomic with arithmetic).
-static constexpr uint32_t FLAT_CUR_STRIDE = 32;
-__global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t total, unsigned fb,
+static constexpr uint32_t FLAT_CUR_STRIDE = 32;   // = the most windows a table can have (msm_flat_applies): one cursor per (bin, window)
+// grid (tiles over the points, windows): counts per (window, coarse bin), bin_count[w * nbins + b] — the partition places a
+// bin's entries WINDOW BY WINDOW (see msm_flat_scan_bins), for which it needs the bin's count of every window
+__global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t n, unsigned fb,
                                                                      uint32_t nbins, uint32_t tile, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t lh[FLAT_MAX_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += SORT_THREADS) lh[b] = 0;
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * tile, hi = min(lo + (size_t)tile, total);
+    const uint32_t w = blockIdx.y;
+    const uint32_t* d = digits + (size_t)w * n;
+    const size_t lo = (size_t)blockIdx.x * tile, hi = min(lo + (size_t)tile, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += 4 * SORT_THREADS) {
         uint32_t c[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? digits[i + u * SORT_THREADS] : 0u;
+        for (int u = 0; u < 4; u++) c[u] = i + u * SORT_THREADS < hi ? d[i + u * SORT_THREADS] : 0u;
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (c[u]) atomicAdd(&lh[((c[u] - 1) >> 1) >> fb], 1u);
@@ -409,22 +413,28 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint3
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbins; b += SORT_THREADS) {
         uint32_t v = lh[b];
-        if (v) atomicAdd(&bin_count[b], v);
+        if (v) atomicAdd(&bin_count[(size_t)w * nbins + b], v);
     }
 }
-// exclusive scan of <= 4096 bin counts by one workgroup: bin_off[0 .. nbins]; and of the bins' SEGMENT capacities
-// 2^fb + count / SEG (an upper bound of sum over the bin's buckets of ceil(count_b / SEG)): bin_seg_off[0 .. nbins] — the
-// segment indices a bin's workgroup of msm_flat_bin_sort hands out without knowing what the other bins need
-__global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins,
-                                                           uint32_t* __restrict__ bin_off, unsigned fb, uint32_t SEG,
-                                                           uint32_t* __restrict__ bin_seg_off) {
+// Exclusive scan of <= 4096 bin totals (summed over the windows) by one workgroup: bin_off[0 .. nbins]; the offsets of every
+// (bin, window) inside that, win_off[b * nwin + w] — a bin's entries are laid out WINDOW BY WINDOW, so that a bucket's entries
+// reach the accumulation window by window too: all lanes of the chip then gather from the table rows of the same one or two
+// windows at a time (1 / 13 of a multi-GB table: TLB reach and Infinity Cache, r04 — DESIGN.md §3.1) instead of from all of it;
+// and the bins' SEGMENT capacities 2^fb + count / SEG (an upper bound of sum over the bin's buckets of ceil(count_b / SEG)):
+// bin_seg_off[0 .. nbins] — the segment indices a bin's workgroup of msm_flat_bin_sort hands out without knowing what the
+// other bins need.
+__global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins, uint32_t nwin,
+                                                           uint32_t* __restrict__ bin_off, uint32_t* __restrict__ win_off, unsigned fb,
+                                                           uint32_t SEG, uint32_t* __restrict__ bin_seg_off) {
     __shared__ uint32_t sm[1024], sg[1024];
     const uint32_t t = threadIdx.x;
     uint32_t v[4], g[4], s = 0, q = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const bool in = 4 * t + u < nbins;
-        v[u] = in ? bin_count[4 * t + u] : 0u;
+        v[u] = 0;
+        if (in)
+            for (uint32_t w = 0; w < nwin; w++) v[u] += bin_count[(size_t)w * nbins + 4 * t + u];
         g[u] = in ? (1u << fb) + v[u] / SEG : 0u;
         s += v[u];
         q += g[u];
@@ -442,9 +452,15 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
     uint32_t run = sm[t] - s, rung = sg[t] - q;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        if (4 * t + u < nbins) {
-            bin_off[4 * t + u] = run;
-            bin_seg_off[4 * t + u] = rung;
+        const uint32_t b = 4 * t + u;
+        if (b < nbins) {
+            bin_off[b] = run;
+            bin_seg_off[b] = rung;
+            uint32_t at = run;
+            for (uint32_t w = 0; w < nwin; w++) {
+                win_off[(size_t)b * nwin + w] = at;
+                at += bin_count[(size_t)w * nbins + b];
+            }
         }
         run += v[u];
         rung += g[u];
@@ -458,8 +474,8 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
 // w * tstride + toff + i, with the sign of the digit in bit 31.
 __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
                                                            uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb, uint32_t nbins,
-                                                           const uint32_t* __restrict__ bin_off, uint32_t* __restrict__ bin_cursor,
-                                                           uint2* __restrict__ tmp) {
+                                                           const uint32_t* __restrict__ win_off, uint32_t nwin,
+                                                           uint32_t* __restrict__ bin_cursor, uint2* __restrict__ tmp) {
     // LDS: PART_TILE pairs | cnt, start, gpos (nbins words each, rounded up to a multiple of 4) | 1024 scan words: sized by
     // the bin count of the call (74 KB at 512 bins: two workgroups per CU; the fixed 4096-bin arrays allowed one)
     extern __shared__ uint2 stage[];  // PART_TILE pairs
@@ -514,7 +530,8 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         if (b < nbins) {
             start[b] = run;
             cnt[b] = run;  // running cursor of the bin inside the staged tile
-            gpos[b] = v[u] ? bin_off[b] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE], v[u]) : 0u;
+            // the run of this (tile, bin) inside the bin's range of window w; the cursors of a bin's windows share one line
+            gpos[b] = v[u] ? win_off[(size_t)b * nwin + w] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE + w], v[u]) : 0u;
         }
         run += v[u];
     }
@@ -547,7 +564,15 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
 struct FlatSegOut {
     uint32_t *hist, *bucket_off, *seg_off, *seg_start, *seg_len, *len_hist, *big_count, *big_list;
     uint32_t SEG, big_nseg;
+    // the ns segments of a bucket with more than SEG entries take its entries ROUND-ROBIN (segment k: entries k, k + ns, ...;
+    // seg_len = length | ns << 8) instead of as consecutive ranges: a bucket's entries lie window by window, and every lane
+    // should walk the windows in the same order (the locality of the accumulation's gathers).  TE jobs only.
+    uint32_t interleave;
 };
+#ifndef SWM_PLACE_U
+#define SWM_PLACE_U 4
+#endif
+static constexpr int PLACE_U = SWM_PLACE_U;
 static constexpr uint32_t LEN_STRIDE = 32;  // the SEG + 1 length counters sit one per 128-byte line (see FLAT_CUR_STRIDE)
 __device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
 __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
@@ -608,10 +633,17 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
             o.bucket_off[b] = ent;
             o.seg_off[b] = s0;
             for (uint32_t k = 0; k < ns; k++) {  // balanced split, as msm_seg_desc: one segment per bucket unless c > SEG
-                const uint32_t ks = (uint32_t)(((uint64_t)c * k) / ns), ke = (uint32_t)(((uint64_t)c * (k + 1)) / ns);
-                o.seg_start[s0 + k] = ent + ks;
-                o.seg_len[s0 + k] = ke - ks;
-                atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
+                if (o.interleave && ns > 1) {
+                    const uint32_t len = (c - k + ns - 1) / ns;
+                    o.seg_start[s0 + k] = ent + k;
+                    o.seg_len[s0 + k] = len | (ns << 8);
+                    atomicAdd(&lh[o.SEG - len], 1u);
+                } else {
+                    const uint32_t ks = (uint32_t)(((uint64_t)c * k) / ns), ke = (uint32_t)(((uint64_t)c * (k + 1)) / ns);
+                    o.seg_start[s0 + k] = ent + ks;
+                    o.seg_len[s0 + k] = ke - ks;
+                    atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
+                }
             }
             if (ns > o.big_nseg) o.big_list[atomicAdd(o.big_count, 1u)] = b;
         }
@@ -623,12 +655,14 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
     for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS)
         if (lh[i]) atomicAdd(&o.len_hist[i * LEN_STRIDE], lh[i]);
     if (cnt <= FLAT_BIN_CAP) {
-        for (uint32_t i = t; i < cnt; i += 4 * BIN_THREADS) {
-            uint2 e[4];
+        // the bin's entries lie window by window (msm_flat_scan_bins); they are placed in chunks of PLACE_U x 1024 consecutive
+        // entries, so a bucket's entries keep that order up to the chunk size — what the accumulation's locality rests on
+        for (uint32_t i = t; i < cnt; i += PLACE_U * BIN_THREADS) {
+            uint2 e[PLACE_U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
+            for (int u = 0; u < PLACE_U; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < PLACE_U; u++)
                 if (i + u * BIN_THREADS < cnt) stage[atomicAdd(&fo[e[u].y & fmask], 1u)] = e[u].x;
         }
         __syncthreads();
@@ -939,10 +973,10 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __r
     uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
     // *nseg_ptr bounds the segment INDICES in use; the flat schedule leaves indices without entries between the bins
     // (msm_flat_bin_sort): those are not handed to a lane
-    bool live = seg < *nseg_ptr && seg_len[seg] != 0;
+    bool live = seg < *nseg_ptr && (seg_len[seg] & 0xffu) != 0;  // (bits 8 ..: the stride of an interleaved segment)
     uint32_t bin = 0;
     if (live) {
-        bin = SEG - seg_len[seg];
+        bin = SEG - (seg_len[seg] & 0xffu);
         atomicAdd(&lh[bin], 1u);
     }
     __syncthreads();
@@ -1084,7 +1118,7 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
 // cancellation test, no cold path, 2 646 instead of 3 598 multiply-adds per addition (3 890 instead of 4 817 instructions in
 // the loop, 148 VGPRs, no scratch).  Partial sums leave as extended points (X, Y, T, Z in the four slots of a G1XYZZ).
 // Algorithmic bytes per point are unchanged (96 B base + 32 B scalar); a table row is 144 B instead of 96 B.
-__global__ void __launch_bounds__(256, 4) msm_accumulate_te(const G1TE* __restrict__ rows,
+__global__ void __launch_bounds__(256, SWM_TE_EARLY_LOADS ? 3 : 4) msm_accumulate_te(const G1TE* __restrict__ rows,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ seg_start,
                                                            const uint32_t* __restrict__ seg_len,
@@ -1094,8 +1128,9 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate_te(const G1TE* __restri
     const uint32_t nseg_total = *nseg_ptr;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nseg_total; t += gridDim.x * blockDim.x) {
         const uint32_t seg = order[t];
-        const uint32_t k0 = seg_start[seg], e = k0 + seg_len[seg];
-        if (k0 >= e) {
+        // entries of the segment: sorted[k0 + j * stride], j < len (stride 1 unless the bucket's segments interleave)
+        const uint32_t k0 = seg_start[seg], sl = seg_len[seg], len = sl & 0xffu, stride = max(1u, sl >> 8);
+        if (len == 0) {
             te28_store_identity(partial[seg]);
             continue;
         }
@@ -1105,9 +1140,13 @@ __global__ void __launch_bounds__(256, 4) msm_accumulate_te(const G1TE* __restri
             const G1TE* row = rows + (ent & 0x7fffffffu);
             acc = te28_from_row(te28_load_coord(row->ymx), te28_load_coord(row->ypx), te28_load_coord(row->kt), (ent >> 31) != 0);
         }
-        for (uint32_t k = k0 + 1; k < e; k++) {
-            const uint32_t ent = sorted[k];
+        // the entry of the NEXT addition is read while this one computes (index clamped to the segment: no branch), so that an
+        // addition waits for one memory round trip — its row — and not for two in a row
+        uint32_t ent = sorted[k0 + min(1u, len - 1) * stride];
+        for (uint32_t j = 1; j < len; j++) {
+            const uint32_t next = sorted[k0 + min(j + 1, len - 1) * stride];
             te28_madd_row(acc, rows + (ent & 0x7fffffffu), (ent >> 31) != 0);
+            ent = next;
         }
         partial[seg].x = fq28_pack(acc.x);
         partial[seg].y = fq28_pack(acc.y);
@@ -2007,17 +2046,19 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
     const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
-                              (flat ? (3 + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 : 0);
+                              (flat ? (2 + 2 * (size_t)pl.nwin + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 : 0);
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
     uint32_t* two_level_bad = len_hist + (SEG_MAX + 1) * LEN_STRIDE;  // one flag per window, then the per-(window, bin) cursors
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
-    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;  // [bins] counts | [bins + 1] offsets | [bins] cursors, one per line
-    uint32_t* flat_off = flat_cnt + FLAT_MAX_BINS;
+    // [windows x bins] counts | [bins + 1] offsets | [bins + 1] first segment index | [bins x windows] offsets | [bins] cursor lines
+    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;
+    uint32_t* flat_off = flat_cnt + (size_t)pl.nwin * FLAT_MAX_BINS;
     uint32_t* flat_seg_off = flat_off + FLAT_MAX_BINS + 2;  // [bins + 1] first segment index of every bin
-    uint32_t* flat_cur = flat_seg_off + FLAT_MAX_BINS + 2;
+    uint32_t* flat_win_off = flat_seg_off + FLAT_MAX_BINS + 2;
+    uint32_t* flat_cur = flat_win_off + (size_t)pl.nwin * FLAT_MAX_BINS;
     uint2* pairs = nullptr;
     if (two_level || flat) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
@@ -2046,20 +2087,21 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
         uint32_t ctile = 65536;  // digits per workgroup of the coarse histogram: at least ~256 workgroups
         while (ctile > 4096 && (size_t)ctile * 256 > total) ctile >>= 1;
+        if (pl.nwin > FLAT_CUR_STRIDE) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many windows for the flat sort");
         const size_t lds_part = (size_t)PART_TILE * sizeof(uint2) + (3 * (size_t)((flat_bins + 3) & ~3u) + 1024) * 4;
         SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, lds_part));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
-        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((total + ctile - 1) / ctile)), dim3(SORT_THREADS), 0,
-                   digits, total, flat_fb, flat_bins, ctile, flat_cnt);
-        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, flat_off, flat_fb, SEG,
-                   flat_seg_off);
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
+                   digits, n, flat_fb, flat_bins, ctile, flat_cnt);
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
+                   flat_fb, SEG, flat_seg_off);
         SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
-                   flat_bins, flat_off, flat_cur, pairs);
+                   flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
         // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
         // the bin sort: no scans over the bucket histogram, no msm_seg_desc)
-        const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg};
+        const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg, te ? 1u : 0u};
         SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
                    (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
     } else {
