@@ -13,9 +13,14 @@ python3 bench.py --circuit merkle --steps 10 --warmup 2 > $out/bench_merkle.json
 python3 bench.py --workload msm --steps 12 --warmup 2 > $out/bench_msm.json 2> $out/bench_msm.err
 python3 bench.py --workload msm --log-n 22 --steps 8 --warmup 2 --cpu-log-n 18 > $out/bench_msm_2p22.json 2> $out/bench_msm22.err
 rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_prove.log 2>&1
-python3 tools/trace_share.py $out/prof_prove/run_kernel_trace.csv > $out/timeline_share.txt 2>&1 || python3 tools/trace_share.py $(ls $out/prof_prove/*/run_kernel_trace.csv | head -1) > $out/timeline_share.txt 2>&1
+python3 tools/trace_share.py $out/prof_prove/run_kernel_trace.csv > $out/timeline_share.txt 2>&1
+python3 tools/trace_dump.py $out/prof_prove/run_kernel_trace.csv 15 > $out/trace_dump.txt 2>&1
+python3 tools/rocprof_region.py $out/prof_prove/run_kernel_trace.csv msm_accumulate 75 > $out/region_prove.json
 rocprofv3 --kernel-trace --stats -d $out/prof_merkle -o run --output-format csv -- python3 bench.py --circuit merkle --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_merkle.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/prof_msm -o run --output-format csv -- python3 bench.py --workload msm --steps 12 --warmup 2 --no-cpu-baseline > $out/prof_msm.log 2>&1
+python3 tools/rocprof_region.py $out/prof_msm/run_kernel_trace.csv msm_accumulate 12 > $out/region_msm.json
+# (the kernel traces themselves are tens of MB: summarised above, not kept)
+rm -f $out/prof_prove/run_kernel_trace.csv $out/prof_merkle/run_kernel_trace.csv $out/prof_msm/run_kernel_trace.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_fetch -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex msm_accumulate -d $out/pmc_write -o run --output-format csv -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
 # SQ issue counters of the dominant kernel (8 SQ slots = one pass), then FETCH / WRITE of the two secondary kernels alone
@@ -39,6 +44,7 @@ python3 tools/small_proofs.py 10 12 14 16 18 > $out/small_proofs.log 2>&1
 # the Pedersen Merkle tree of config #5 (2^18 leaves) beside the CPU oracle on 2^14 leaves, and its kernel stats
 python3 tools/ubench/merkle_build.py 18 5 14 > $out/merkle_build.json 2> $out/merkle_build.err
 rocprofv3 --kernel-trace --stats -d $out/prof_merkle_build -o run --output-format csv -- python3 tools/ubench/merkle_build.py 18 3 0 > $out/prof_merkle_build.log 2>&1
+rm -f $out/prof_merkle_build/run_kernel_trace.csv
 # what ONE rank of a proof split over G = 1, 2, 4, 8 ranks computes (exchange emulated on the host): strong-scaling bound, DESIGN.md section 6
 for lg in "20 8" "22 3"; do
   SWM_SHARD_R1_OFF=1 python3 tools/ubench/shard_emulate.py $lg 2>> $out/shard_emulate.err | grep "^{" >> $out/shard_emulate.jsonl
