@@ -446,18 +446,28 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     const bool by_bucket = getenv("SWM_SHARD_BUCKETS") && atoi(getenv("SWM_SHARD_BUCKETS")) != 0;
     const bool by_range = getenv("SWM_SHARD_RANGE") && atoi(getenv("SWM_SHARD_RANGE")) != 0;
     const bool table_split = out->sharded && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous();
-    size_t first = 0, count = n;   // scalars coeffs[first + i * stride], i < count
+    size_t first = 0, count = n;   // scalars coeffs[first + map(i)], i < count (map: the table's block map when the scalars are strided)
     if (table_split && by_bucket) {
         tab.shard_rank = ctx->shard_rank;
         tab.shard_world = ctx->shard_world;
     } else if (table_split && !by_range) {
+        // BLOCK-cyclic (r04): rank g takes the blocks g, g + G, ... of 2^L consecutive coefficients (L = 12, less when the
+        // polynomial is short: every rank gets at least ~8 blocks; SWM_SHARD_BLOCK_LOG=0 is the plain cyclic split of r03).  As
+        // balanced as the cyclic split — the zero padding at the top is spread over the ranks block by block — but a rank's
+        // table rows are runs of 2^L x 192 B instead of every G-th row: the accumulation's gathers are sensitive to that
+        // (per rank at 2^22 and G = 8: 5.4 G additions/s cyclic, 7 - 8 G/s for contiguous ranges: profiles/r04_shard_emulate.jsonl)
         const size_t G = ctx->shard_world, g = ctx->shard_rank;
-        first = g;
-        count = n > g ? (n - g + G - 1) / G : 0;
-        tab.offset += g;
-        tab.blk_log = 0;
-        tab.bstride = G;
-        tab.scalar_stride = G;
+        unsigned L = getenv("SWM_SHARD_BLOCK_LOG") ? (unsigned)std::min(20, std::max(0, atoi(getenv("SWM_SHARD_BLOCK_LOG")))) : 12u;
+        while (L > 0 && ((size_t)8 * G << L) > n) L--;
+        const size_t B = (size_t)1 << L, nblocks = (n + B - 1) / B;
+        const size_t mine = nblocks > g ? (nblocks - g + G - 1) / G : 0;            // blocks g, g + G, ... below nblocks
+        const bool owns_last = mine && (g + (mine - 1) * G) == nblocks - 1;
+        first = g << L;
+        count = mine * B - (owns_last ? nblocks * B - n : 0);                        // the polynomial's last block may be short
+        tab.offset += g << L;
+        tab.blk_log = L;
+        tab.bstride = G << L;
+        tab.scalar_stride = G;  // != 1: the scalars follow the same block map as the bases (msm_digits)
         // too few points for the table schedule: fall back to the range.  Decided on floor(n / G), the SMALLEST share, so that
         // every rank takes the same branch (the ranks' own counts differ by one when G does not divide n: one rank cyclic
         // and another by range would leave coefficients uncovered — ADVICE r03)

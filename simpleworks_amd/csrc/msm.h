@@ -35,8 +35,10 @@ struct MsmTable {
     // commits to them where they are (flat schedule only).
     unsigned blk_log = 31;
     size_t bstride = 0;
-    // scalar i of the MSM is d_scalars[i * scalar_stride] (a rank of a sharded proof that takes every G-th coefficient of a
-    // polynomial all ranks hold: scalar_stride = bstride = G, blk_log = 0, both offsets = rank; flat schedule only)
+    // scalar_stride != 1: the SCALARS follow the block map of the bases too — scalar i of the MSM is
+    // d_scalars[(i >> blk_log) * bstride + (i & (2^blk_log - 1))] (a rank of a sharded proof that takes the blocks g, g + G, ... of a
+    // polynomial all ranks hold: bstride = G << blk_log, offset = g << blk_log, the scalar pointer advanced likewise; blk_log = 0 is
+    // the plain cyclic split; flat schedule only)
     size_t scalar_stride = 1;
     // One proof over G ranks, split by BUCKET range (flat schedule, every rank holds all n scalars): the MSM takes all its
     // points but keeps only the digits whose bucket lies in the rank's share of the bucket-stage workgroups — windows

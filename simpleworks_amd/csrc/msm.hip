@@ -147,9 +147,13 @@ struct DigitShard {
 };
 __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars, size_t n, int mont, WinLayout L,
                                                   uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
-                                                  size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh, size_t sstride) {
+                                                  size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh, unsigned sblk_log,
+                                                  size_t sbstride) {
+    // scalar i sits at scalars[(i >> sblk_log) * sbstride + (i & (2^sblk_log - 1))]: contiguous by default (sblk_log = 31), the
+    // blocks a rank of a sharded proof takes of a polynomial every rank holds otherwise (MsmTable::scalar_stride, blk_log, bstride)
+    const size_t smask = ((size_t)1 << sblk_log) - 1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = scalars[i * sstride];
+        Fr s = scalars[(i >> sblk_log) * sbstride + (i & smask)];
         bool ge = true;  // s >= r ?
 #pragma unroll
         for (int k = 7; k >= 0; k--) {
@@ -2081,7 +2085,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
-               big_count + 1 /* zeroed with the histogram */, dshard, tab.scalar_stride);
+               big_count + 1 /* zeroed with the histogram */, dshard, tab.scalar_stride != 1 ? tab.blk_log : 31u,
+               tab.scalar_stride != 1 ? tab.bstride : (size_t)0);
     if (flat) {
         // two-level counting sort over the shared bucket set; the fine counts written by msm_flat_bin_sort are the
         // histogram the scans consume, and the bins are contiguous bucket ranges, so `sorted` is in bucket order
