@@ -539,6 +539,63 @@ __device__ __forceinline__ void te28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, con
     dst->y = fq28_pack(M::mul(G, H));
     dst->zzz = fq28_pack(M::mul(F, G));
 }
+// The same addition by FOUR lanes (a quad of one wave; `q` = the lane's index in it): the nine multiplications of
+// te28_slot_add as three rounds of one product per lane — (A, B, T1 T2, Z1 Z2), then 2d (T1 T2) on lane 2, then (X3, Y3, T3,
+// Z3) — with the four intermediate values passed around the quad by DPP moves and every lane storing one coordinate of the
+// result.  Same formulas, same limbs.  For the bucket stage of SMALL MSMs (r04): that stage is a dependent chain of group
+// operations on a chip that is mostly idle, and a lone wave issues an instruction every ~5.5 cycles whatever it computes —
+// three products per step instead of nine is a step of ~4.5 us instead of ~12.  (For large MSMs every CU already has its
+// 256 chains: there the quad form would only add instructions.)  Every lane of the quad is handed the same pointers; all loads
+// precede the stores (one wave: lock step), so dst may be pa or pq.
+template <int SRC>
+__device__ __forceinline__ Fq28 te28_quad_get(const Fq28& v) {  // every lane of the quad: the value held by its lane SRC
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++)  // DPP quad_perm [SRC, SRC, SRC, SRC]: a VALU move, no LDS traffic
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], SRC * 0x55, 0xf, 0xf, true);
+    return r;
+}
+template <class M = MulAsm>
+__device__ __forceinline__ void te28_quad_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned q) {
+    // round 1 operands: lane 0: (Y1 - X1)(Y2 - X2), lane 1: (Y1 + X1)(Y2 + X2), lane 2: T1 T2, lane 3: Z1 Z2 — written as
+    // a + s b with (a, b) = (y, x), (y, x), (zz, -), (zzz, -) so that the four lanes run the same instructions
+    const unsigned ia = q < 2 ? 1u : q;  // index of coordinate a among (x, y, zz, zzz)
+    const Fq* ca = reinterpret_cast<const Fq*>(pa);
+    const Fq* cq = reinterpret_cast<const Fq*>(pq);
+    const Fq28 a1 = fq28_unpack(ca[ia]), b1 = fq28_unpack(ca[0]), a2 = fq28_unpack(cq[ia]), b2 = fq28_unpack(cq[0]);
+    Fq28 u, v;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t sp = Fq28Consts::SPREAD4[i];
+        const uint32_t t1 = q == 0 ? sp - b1.l[i] : (q == 1 ? b1.l[i] : 0u), t2 = q == 0 ? sp - b2.l[i] : (q == 1 ? b2.l[i] : 0u);
+        u.l[i] = a1.l[i] + t1;
+        v.l[i] = a2.l[i] + t2;
+    }
+    Fq28 p1 = M::mul(u, v);
+    const Fq28 p2 = M::mul(p1, fq28_const(Fq28TeConsts::K2D));  // only lane 2 keeps it: C = 2d T1 T2
+#pragma unroll
+    for (int i = 0; i < 14; i++) p1.l[i] = q == 2 ? p2.l[i] : (q == 3 ? p1.l[i] + p1.l[i] : p1.l[i]);  // lane 3: D = 2 Z1 Z2
+    const Fq28 A = te28_quad_get<0>(p1), B = te28_quad_get<1>(p1), C = te28_quad_get<2>(p1), D = te28_quad_get<3>(p1);
+    Fq28 l, r;  // lane 0: E F, lane 1: G H, lane 2: E H, lane 3: F G
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t sp = Fq28Consts::SPREAD4[i];
+        const uint32_t E = B.l[i] + sp - A.l[i], H = B.l[i] + A.l[i], F = D.l[i] + sp - C.l[i], G = D.l[i] + C.l[i];
+        l.l[i] = q == 1 ? G : (q == 3 ? F : E);
+        r.l[i] = q == 0 ? F : (q == 3 ? G : H);
+    }
+    reinterpret_cast<Fq*>(dst)[q == 2 ? 2u : (q == 3 ? 3u : q)] = fq28_pack(M::mul(l, r));  // X3, Y3, T3 (slot zz), Z3 (slot zzz)
+}
+// one coordinate per lane of the quad
+__device__ __forceinline__ void te28_quad_copy(G1XYZZ* dst, const G1XYZZ* src, unsigned q) {
+    reinterpret_cast<Fq*>(dst)[q] = reinterpret_cast<const Fq*>(src)[q];
+}
+__device__ __forceinline__ void te28_quad_store_identity(G1XYZZ* dst, unsigned q) {
+    Fq28 z;
+#pragma unroll
+    for (int i = 0; i < 14; i++) z.l[i] = (q & 1u) ? Fq28Consts::ONE[i] : 0u;  // (0 : 1 : 0 : 1)
+    reinterpret_cast<Fq*>(dst)[q] = fq28_pack(z);
+}
 // 28-bit domain (x 2^392) -> radix 2^384, canonical; still a twisted Edwards point (the host folds in that form)
 __device__ __forceinline__ void te28_store_384(G1XYZZ& m, const G1XYZZ& slot) {
     Fq28 k = fq28_const(Fq28Consts::TO384);

@@ -82,6 +82,7 @@ struct MsmJob {
     size_t n = 0;
     WinLayout pl;
     unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
+    bool quad = false;  // bucket stage with four lanes per chain (small twisted Edwards jobs)
     unsigned red_blocks = 0, log_m = 0, rb = 256;  // bucket stage: workgroups per window, log2 buckets per lane, lanes per workgroup
     unsigned blk_lo = 0, blk_hi = 0, blk_low = 0;  // workgroups [blk_lo, blk_hi) and [0, blk_low) hold buckets of this rank (bucket-range split); the others emit the identity
     bool te = false;         // partial sums and workgroup results are twisted Edwards points (the host fold converts the total)

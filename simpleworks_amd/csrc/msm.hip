@@ -446,7 +446,8 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
     sm[t] = s;
     sg[t] = q;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t T = blockDim.x;  // a power of two >= nbins / 4 (a single wave for the few bins of a small MSM)
+    for (uint32_t d = 1; d < T; d <<= 1) {
         uint32_t x = t >= d ? sm[t - d] : 0u, y = t >= d ? sg[t - d] : 0u;
         __syncthreads();
         sm[t] += x;
@@ -469,9 +470,9 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
         run += v[u];
         rung += g[u];
     }
-    if (t == 1023) {
-        bin_off[nbins] = sm[1023];
-        bin_seg_off[nbins] = sg[1023];
+    if (t == T - 1) {
+        bin_off[nbins] = sm[T - 1];
+        bin_seg_off[nbins] = sg[T - 1];
     }
 }
 // (entry, bucket) pairs grouped by coarse bin; grid (tiles over the points, windows).  entry = table row of the point:
@@ -1254,16 +1255,31 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
 
 // The two point forms of the bucket stage: XYZZ on the Weierstrass curve (per-window schedule, XYZZ tables) and extended
 // twisted Edwards (TE tables).  Each kernel below is instantiated once per form; a launch handles jobs of one form.
+// LANES: hardware lanes that share one chain of the bucket stage (msm_bucket_reduce); `q` = the lane's index among them.
 struct FormXYZZ {
-    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) { p28_slot_add(dst, pa, pq); }
-    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa) { p28_slot_dbl(dst, pa); }
-    static __device__ __forceinline__ void store_identity(G1XYZZ& m) { p28_store(m, p28_identity()); }
+    static constexpr int LANES = 1;
+    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { p28_slot_add(dst, pa, pq); }
+    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned = 0) { p28_slot_dbl(dst, pa); }
+    static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned = 0) { *dst = *src; }
+    static __device__ __forceinline__ void store_identity(G1XYZZ& m, unsigned = 0) { p28_store(m, p28_identity()); }
     static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { p28_store_384(m, p28_load(slot)); }
 };
 struct FormTE {
-    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq) { te28_slot_add(dst, pa, pq); }
-    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa) { te28_slot_add(dst, pa, pa); }  // unified law
-    static __device__ __forceinline__ void store_identity(G1XYZZ& m) { te28_store_identity(m); }
+    static constexpr int LANES = 1;
+    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { te28_slot_add(dst, pa, pq); }
+    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned = 0) { te28_slot_add(dst, pa, pa); }  // unified law
+    static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned = 0) { *dst = *src; }
+    static __device__ __forceinline__ void store_identity(G1XYZZ& m, unsigned = 0) { te28_store_identity(m); }
+    static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { te28_store_384(m, slot); }
+};
+// Twisted Edwards with every chain worked by a quad of lanes (te28_quad_add: three products per lane and step instead of
+// nine): the bucket stage of SMALL MSMs, where the chain's latency is all there is.
+struct FormTEQuad {
+    static constexpr int LANES = 4;
+    static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned q) { te28_quad_add(dst, pa, pq, q); }
+    static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned q) { te28_quad_add(dst, pa, pa, q); }
+    static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned q) { te28_quad_copy(dst, src, q); }
+    static __device__ __forceinline__ void store_identity(G1XYZZ& m, unsigned q) { te28_quad_store_identity(&m, q); }
     static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { te28_store_384(m, slot); }
 };
 
@@ -1337,8 +1353,9 @@ struct TailJob {
 struct TailBatch {
     TailJob j[TAIL_MAX];
 };
+// (RB = chains per workgroup; a chain is one lane, or Form::LANES of them: RB x LANES threads)
 template <int RB, class Form>
-__global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
+__global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch batch) {
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
     const G1XYZZ* __restrict__ partial = job.partial;
@@ -1354,11 +1371,13 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     G1XYZZ* sm_alt = sm_run + RB;
     G1XYZZ* sm_acc = sm_alt + RB;
     G1XYZZ* sm_r = sm_acc + RB;
-    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    constexpr unsigned Q = Form::LANES;
+    const uint32_t w = blockIdx.y, t = threadIdx.x / Q, q = threadIdx.x % Q;
     if (!((blockIdx.x >= job.blk_lo && blockIdx.x < job.blk_hi) || blockIdx.x < job.blk_low)) {
         // not a workgroup of this rank's bucket share: its buckets are empty here, the host fold sees the identity
-        if (t == 0) {
-            Form::store_identity(sm_run[0]);
+        if (threadIdx.x < Q) Form::store_identity(sm_run[0], q);
+        __syncthreads();
+        if (threadIdx.x == 0) {
             size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
             Form::store_384(out[o], sm_run[0]);
             Form::store_384(out[o + 1], sm_run[0]);
@@ -1373,8 +1392,8 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
-    Form::store_identity(sm_run[t]);
-    Form::store_identity(sm_acc[t]);
+    Form::store_identity(sm_run[t], q);
+    Form::store_identity(sm_acc[t], q);
     // phase-1 sequencer of this lane: buckets b = hi-1 .. lo; per bucket "run += partial[s]" for its segments, then
     // "acc += run"
     uint32_t b = min(lo + m, B), s = 0, e = 0;
@@ -1429,11 +1448,11 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
             if (act) pq = &sm_run[t + d];
             d <<= 1;
         } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1} (into the other copy); R_blk = Suffix_0 is parked
-            if (t + 1 < RB) sm_alt[t] = sm_run[t + 1];
-            else Form::store_identity(sm_alt[t]);
-            if (t == 0) sm_r[0] = sm_run[0];
+            if (t + 1 < RB) Form::copy(&sm_alt[t], &sm_run[t + 1], q);
+            else Form::store_identity(sm_alt[t], q);
+            if (t == 0) Form::copy(&sm_r[0], &sm_run[0], q);
 #pragma unroll 1
-            for (unsigned i = 0; i < log_m; i++) Form::slot_dbl(&sm_alt[t], &sm_alt[t]);
+            for (unsigned i = 0; i < log_m; i++) Form::slot_dbl(&sm_alt[t], &sm_alt[t], q);
             __syncthreads();
             G1XYZZ* x = sm_run;
             sm_run = sm_alt;
@@ -1454,8 +1473,8 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
             if (act) pq = &sm_acc[t + d];  // the lanes t + d .. are idle in this step: nobody rewrites what is read
             d >>= 1;
         }
-        if (act) Form::slot_add(dst, pa, pq);
-        else if (copy) *dst = *pa;
+        if (act) Form::slot_add(dst, pa, pq, q);
+        else if (copy) Form::copy(dst, pa, q);
         __syncthreads();
         if (dst == &sm_alt[t]) {  // a scan step went from one copy of the running sums to the other (uniform per step)
             G1XYZZ* x = sm_run;
@@ -1463,7 +1482,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
             sm_alt = x;
         }
     }
-    if (t == 0) {
+    if (threadIdx.x == 0) {
         // `out` is the job's PINNED host slot (zero-copy: 384 B per workgroup over the fabric instead of three
         // stream-ordered copies per job after the kernel — ~25 us per job between a round's last kernel and its challenge)
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
@@ -1481,7 +1500,7 @@ __global__ void __launch_bounds__(RB) msm_bucket_reduce(TailBatch batch) {
 // Kernels that want more than 64 KB of dynamic LDS need the attribute raised once per device; `slot` names the kernel
 // (0 hist, 1 scatter, 2 bucket_reduce, 3 partition, 4 bin_sort) in a small process-wide cache so that the runtime call is not repeated per MSM.
 static int allow_big_lds(swm_ctx* ctx, int slot, const void* fn, size_t bytes) {
-    static std::atomic<size_t> granted[64][8];
+    static std::atomic<size_t> granted[64][12];
     if (bytes <= 64 * 1024) return SWM_OK;
     const int dev = ctx->device & 63;
     if (granted[dev][slot].load(std::memory_order_acquire) >= bytes) return SWM_OK;
@@ -1789,9 +1808,18 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // where the 256-lane form needs all four SIMDs of a CU at once — measured r02: the stage itself takes 1.00 instead of
     // 0.72 ms (1024 workgroup results to fold instead of 256) and a 2^20 proof 82.7 instead of 77.4 ms: not the default.
     static const unsigned flat_rb = getenv("SWM_RED_LANES") ? (unsigned)atoi(getenv("SWM_RED_LANES")) : 256u;
-    const unsigned rb = flat ? (flat_rb == 64 ? 64u : 256u) : 256u;
+    // Low-latency schedule on twisted Edwards rows: every chain of the bucket stage is worked by a quad of lanes (FormTEQuad;
+    // SWM_MSM_QUAD=0: one lane per chain as for large jobs).  SWM_MSM_QUAD_RB: chains per workgroup (64 / 128 / 256, i.e. 256 /
+    // 512 / 1024 threads), SWM_MSM_QUAD_BLOCKS: workgroups per job at most.
+    static const bool quad_on = !getenv("SWM_MSM_QUAD") || atoi(getenv("SWM_MSM_QUAD")) != 0;
+    static const unsigned quad_rb = getenv("SWM_MSM_QUAD_RB") ? (unsigned)atoi(getenv("SWM_MSM_QUAD_RB")) : 128u;
+    static const unsigned quad_blocks = getenv("SWM_MSM_QUAD_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_QUAD_BLOCKS"))) : 64u;
+    static const unsigned quad_maxb = getenv("SWM_MSM_QUAD_MAXB") ? (unsigned)atoi(getenv("SWM_MSM_QUAD_MAXB")) : 32768u;
+    const bool quad = lat && te && quad_on && flat_rb != 64 && pl.maxB <= quad_maxb;
+    const unsigned rb = quad ? (quad_rb == 256 ? 256u : (quad_rb == 128 ? 128u : 64u)) : (flat ? (flat_rb == 64 ? 64u : 256u) : 256u);
+    job->quad = quad;
     // (low-latency schedule: the bucket stages of a round's four MSMs run in one launch and have to be resident together)
-    const unsigned max_blocks = flat ? (rb == 64 ? 1024u : (lat && defer_tail ? 64u : 256u)) : 16u;
+    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (lat && defer_tail ? 64u : 256u)) : 16u);
     while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
     if (red_blocks == 0) red_blocks = 1;
@@ -2099,7 +2127,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
                    digits, n, flat_fb, flat_bins, ctile, flat_cnt);
-        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(1024), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
+        unsigned scan_threads = 64;
+        while (scan_threads * 4 < flat_bins) scan_threads <<= 1;
+        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
                    flat_fb, SEG, flat_seg_off);
         SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
@@ -2258,7 +2288,19 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_win = std::max(max_win, j->pl.nwin);
     }
     const bool te = jobs[0]->te;  // every job of a launch has the same point form (msm_flush_tails groups them)
-    if (jobs[0]->rb == 64) {
+    if (jobs[0]->quad) {
+        const size_t lds = (3 * (size_t)jobs[0]->rb + 1) * sizeof(G1XYZZ);
+        const dim3 grid(max_red, max_win, (unsigned)k);
+        if (jobs[0]->rb == 256) {
+            SWM_TRY(allow_big_lds(ctx, 8, (const void*)msm_bucket_reduce<256, FormTEQuad>, lds));
+            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormTEQuad>), grid, dim3(1024), lds, batch);
+        } else if (jobs[0]->rb == 128) {
+            SWM_TRY(allow_big_lds(ctx, 9, (const void*)msm_bucket_reduce<128, FormTEQuad>, lds));
+            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<128, FormTEQuad>), grid, dim3(512), lds, batch);
+        } else {
+            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormTEQuad>), grid, dim3(256), lds, batch);
+        }
+    } else if (jobs[0]->rb == 64) {
         if (te)
             SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(64),
                        (3 * 64 + 1) * sizeof(G1XYZZ), batch);
@@ -2297,7 +2339,9 @@ int msm_flush_tails(swm_ctx* ctx) {
     jobs.swap(ctx->pending_tails);
     for (size_t i = 0; i < jobs.size();) {  // one launch per run of up to TAIL_MAX jobs of the same workgroup width
         size_t k = 1;
-        while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb && jobs[i + k]->te == jobs[i]->te) k++;
+        while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb && jobs[i + k]->te == jobs[i]->te &&
+               jobs[i + k]->quad == jobs[i]->quad)
+            k++;
         SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)k));
         i += k;
     }

@@ -24,8 +24,11 @@ __global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, 
 // of its own chunk product as total^-1 x prefix x suffix before walking its chunk backwards.
 // (One inversion per lane made the inversion 89 % of the kernel's multiplications.)
 // (fr_inv_single: frinv.cuh)
-static constexpr int BINV_CHUNK = 16;
+// Small inputs (a few workgroups' worth: the proofs of small circuits, where the kernel is a chain of dependent products on an
+// idle chip) take 4 elements per lane instead of 16: 4 + 8 products on a lane's chain instead of 16 + 32.
+static constexpr int BINV_CHUNK = 16, BINV_CHUNK_SMALL = 4;
 static constexpr int BINV_THREADS = 256;
+template <int BINV_CHUNK>
 __global__ void __launch_bounds__(BINV_THREADS) batch_inverse_kernel(Fr* __restrict__ v, size_t n) {
     __shared__ Fr sp[BINV_THREADS], ss[BINV_THREADS];
     __shared__ Fr s_inv;
@@ -80,8 +83,15 @@ int vec_mul_run(swm_ctx* ctx, const void* a, const void* b, void* out, size_t n)
 }
 int batch_inverse_run(swm_ctx* ctx, void* d, size_t n) {
     if (n == 0) return SWM_OK;
-    size_t threads = (n + BINV_CHUNK - 1) / BINV_CHUNK;
-    SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel, dim3((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS)),
+    static const size_t small_below = getenv("SWM_BINV_SMALL") ? (size_t)atol(getenv("SWM_BINV_SMALL")) : 65536;
+    if (n <= small_below) {
+        const size_t threads = (n + BINV_CHUNK_SMALL - 1) / BINV_CHUNK_SMALL;
+        SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel<BINV_CHUNK_SMALL>,
+                   dim3((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS)), dim3(BINV_THREADS), 0, (Fr*)d, n);
+        return SWM_OK;
+    }
+    const size_t threads = (n + BINV_CHUNK - 1) / BINV_CHUNK;
+    SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel<BINV_CHUNK>, dim3((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS)),
                dim3(BINV_THREADS), 0, (Fr*)d, n);
     return SWM_OK;
 }

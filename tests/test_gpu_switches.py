@@ -54,5 +54,8 @@ def test_switches_select_equivalent_paths():
                 {"SWM_NTT_LAZY": "0"},        # 8 x 32-bit Comba transform instead of the 9 x 29-bit lazy one
                 {"SWM_NTT_PASS_TABLES": "0"},  # lazy transform with the two-level twiddle product on every pass
                 {"SWM_RALPHA_TRANSFORMS": "1"},  # r(alpha, X) on 4|H| by two transforms instead of the closed form
+                {"SWM_MSM_QUAD": "0", "SWM_BINV_SMALL": "0"},  # small MSMs: one lane per chain of the bucket stage; 16-element inversion chunks
+                {"SWM_MSM_QUAD_RB": "64", "SWM_MSM_QUAD_MAXB": "1048576"},   # quad bucket stage in its other shapes, also at 2^17
+                {"SWM_MSM_QUAD_RB": "256", "SWM_MSM_QUAD_BLOCKS": "16"},
                 {"SWM_MSM_TABLE_C": "15"}):      # narrower window tables (what a rank of a sharded proof takes)
         assert _run(env) == ref, env
