@@ -586,6 +586,54 @@ __device__ __forceinline__ void te28_quad_add(G1XYZZ* dst, const G1XYZZ* pa, con
     }
     reinterpret_cast<Fq*>(dst)[q == 2 ? 2u : (q == 3 ? 3u : q)] = fq28_pack(M::mul(l, r));  // X3, Y3, T3 (slot zz), Z3 (slot zzz)
 }
+// Mixed addition by a quad: the accumulator lives ONE COORDINATE PER LANE (`own`: X, Y, T, Z on lanes 0 .. 3), and the seven
+// products of te28_madd_row take two rounds — (A, B, C | D = 2 Z1 needs none), then (X3, Y3, T3, Z3).  Same formulas and limbs as
+// te28_madd_row.  For the accumulation of SMALL MSMs: a segment's chain of additions is 2 instead of 7 products per entry long.
+template <class M = MulAsm>
+__device__ __forceinline__ void te28_quad_madd_row(Fq28& own, const G1TE* __restrict__ rp, bool neg, unsigned q) {
+    // lane 0 multiplies by y - x of the row (y + x when the point is subtracted), lane 1 by the other one, lane 2 by 2dxy
+    const uint32_t* pr = q == 2 ? rp->kt : ((q == 0) != neg ? rp->ymx : rp->ypx);
+    const Fq28 v = te28_load_coord(pr);
+    Fq28 u;  // lane 0: Y1 - X1 + 4p, lane 1: Y1 + X1, lane 2: T1 (lane 3 idles through the product)
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        // the neighbour's coordinate: quad_perm [1, 0, 3, 2]
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.l[i], 0xB1, 0xf, 0xf, true);
+        u.l[i] = q == 0 ? other + Fq28Consts::SPREAD4[i] - own.l[i] : (q == 1 ? own.l[i] + other : own.l[i]);
+    }
+    Fq28 p1 = M::mul(u, v);
+#pragma unroll
+    for (int i = 0; i < 14; i++) p1.l[i] = q == 3 ? own.l[i] + own.l[i] : p1.l[i];  // D = 2 Z1
+    const Fq28 A = te28_quad_get<0>(p1), B = te28_quad_get<1>(p1), C = te28_quad_get<2>(p1), D = te28_quad_get<3>(p1);
+    Fq28 l, r;  // lane 0: E F, lane 1: G H, lane 2: E H, lane 3: F G
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t sp = Fq28Consts::SPREAD4[i];
+        const uint32_t E = B.l[i] + sp - A.l[i], H = A.l[i] + B.l[i];
+        const uint32_t dm = D.l[i] + sp - C.l[i], dp = D.l[i] + C.l[i];
+        const uint32_t F = neg ? dp : dm, G = neg ? dm : dp;
+        l.l[i] = q == 1 ? G : (q == 3 ? F : E);
+        r.l[i] = q == 0 ? F : (q == 3 ? G : H);
+    }
+    own = M::mul(l, r);
+}
+// the first point of a segment (te28_from_row), one coordinate per lane
+template <class M = MulAsm>
+__device__ __forceinline__ Fq28 te28_quad_from_row(const G1TE* __restrict__ rp, bool neg, unsigned q) {
+    const Fq28 a = te28_load_coord(q == 2 ? rp->kt : rp->ymx), s2 = te28_load_coord(rp->ypx);  // a: m2, or k2 on lane 2
+    Fq28 d, ks;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        d.l[i] = q == 0 ? Fq28Consts::SPREAD2[i] + (neg ? a.l[i] - s2.l[i] : s2.l[i] - a.l[i]) : s2.l[i] + a.l[i];
+        ks.l[i] = neg ? Fq28Consts::SPREAD4[i] - a.l[i] : a.l[i];
+    }
+    d = fq28_normalize(d);  // lane 0: +-2x in (p, 3p), lane 1: 2y
+    const Fq28 t = M::mul(ks, fq28_const(Fq28TeConsts::INVD));  // lane 2: 2 d x y / d
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = q < 2 ? d.l[i] : (q == 2 ? t.l[i] : Fq28TeConsts::TWO[i]);
+    return r;
+}
 // one coordinate per lane of the quad
 __device__ __forceinline__ void te28_quad_copy(G1XYZZ* dst, const G1XYZZ* src, unsigned q) {
     reinterpret_cast<Fq*>(dst)[q] = reinterpret_cast<const Fq*>(src)[q];

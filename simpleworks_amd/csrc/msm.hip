@@ -437,8 +437,11 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
     for (int u = 0; u < 4; u++) {
         const bool in = 4 * t + u < nbins;
         v[u] = 0;
-        if (in)
-            for (uint32_t w = 0; w < nwin; w++) v[u] += bin_count[(size_t)w * nbins + 4 * t + u];
+        // (unrolled to the most windows a table can have: the loads go out together — with a loop over nwin each one waited for
+        // the one before, ~17 round trips to L2 in a kernel that every small MSM waits for)
+#pragma unroll
+        for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++)
+            if (in && w < nwin) v[u] += bin_count[(size_t)w * nbins + 4 * t + u];
         g[u] = in ? (1u << fb) + v[u] / SEG : 0u;
         s += v[u];
         q += g[u];
@@ -461,10 +464,13 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
         if (b < nbins) {
             bin_off[b] = run;
             bin_seg_off[b] = rung;
-            uint32_t at = run;
-            for (uint32_t w = 0; w < nwin; w++) {
-                win_off[(size_t)b * nwin + w] = at;
-                at += bin_count[(size_t)w * nbins + b];
+            uint32_t at = run, cw[FLAT_CUR_STRIDE];
+#pragma unroll
+            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) cw[w] = w < nwin ? bin_count[(size_t)w * nbins + b] : 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
+                if (w < nwin) win_off[(size_t)b * nwin + w] = at;
+                at += cw[w];
             }
         }
         run += v[u];
@@ -1160,6 +1166,35 @@ __global__ void __launch_bounds__(256, SWM_TE_EARLY_LOADS ? 3 : 4) msm_accumulat
     }
 }
 
+// The accumulation of SMALL MSMs (low-latency schedule, r04): four lanes per segment, the accumulator one coordinate per lane
+// (te28_quad_madd_row): the chain of a segment of 8 entries is 16 products long instead of 50, on a chip that such a job
+// cannot fill anyway.  Same partial sums, bit for bit.
+__global__ void __launch_bounds__(256) msm_accumulate_te_quad(const G1TE* __restrict__ rows, const uint32_t* __restrict__ sorted,
+                                                              const uint32_t* __restrict__ seg_start,
+                                                              const uint32_t* __restrict__ seg_len,
+                                                              const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ nseg_ptr, G1XYZZ* __restrict__ partial) {
+    const uint32_t nseg_total = *nseg_ptr;
+    const unsigned q = threadIdx.x & 3u;
+    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; t < nseg_total; t += (gridDim.x * blockDim.x) >> 2) {
+        const uint32_t seg = order[t];
+        const uint32_t k0 = seg_start[seg], sl = seg_len[seg], len = sl & 0xffu, stride = max(1u, sl >> 8);
+        if (len == 0) {
+            te28_quad_store_identity(&partial[seg], q);
+            continue;
+        }
+        uint32_t ent = sorted[k0];
+        Fq28 own = te28_quad_from_row(rows + (ent & 0x7fffffffu), (ent >> 31) != 0, q);
+        ent = sorted[k0 + min(1u, len - 1) * stride];
+        for (uint32_t j = 1; j < len; j++) {
+            const uint32_t next = sorted[k0 + min(j + 1, len - 1) * stride];
+            te28_quad_madd_row(own, rows + (ent & 0x7fffffffu), (ent >> 31) != 0, q);
+            ent = next;
+        }
+        reinterpret_cast<Fq*>(&partial[seg])[q] = fq28_pack(own);  // X, Y, T (slot zz), Z (slot zzz)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- bucket stage (28-bit domain)
 // Register budget of the bucket stage: a general addition keeps two points (2 x 56 VGPRs) plus ~8 temporaries
 // (112 VGPRs) live; a third live point spills to scratch, i.e. to HBM-backed private memory with nothing to hide the
@@ -1258,6 +1293,7 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
 // LANES: hardware lanes that share one chain of the bucket stage (msm_bucket_reduce); `q` = the lane's index among them.
 struct FormXYZZ {
     static constexpr int LANES = 1;
+    static constexpr bool QUAD_TREE = false;
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { p28_slot_add(dst, pa, pq); }
     static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned = 0) { p28_slot_dbl(dst, pa); }
     static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned = 0) { *dst = *src; }
@@ -1266,6 +1302,7 @@ struct FormXYZZ {
 };
 struct FormTE {
     static constexpr int LANES = 1;
+    static constexpr bool QUAD_TREE = true;  // the narrow steps of the final tree switch to four lanes per sum
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { te28_slot_add(dst, pa, pq); }
     static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned = 0) { te28_slot_add(dst, pa, pa); }  // unified law
     static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned = 0) { *dst = *src; }
@@ -1276,6 +1313,7 @@ struct FormTE {
 // nine): the bucket stage of SMALL MSMs, where the chain's latency is all there is.
 struct FormTEQuad {
     static constexpr int LANES = 4;
+    static constexpr bool QUAD_TREE = false;
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned q) { te28_quad_add(dst, pa, pq, q); }
     static __device__ __forceinline__ void slot_dbl(G1XYZZ* dst, const G1XYZZ* pa, unsigned q) { te28_quad_add(dst, pa, pa, q); }
     static __device__ __forceinline__ void copy(G1XYZZ* dst, const G1XYZZ* src, unsigned q) { te28_quad_copy(dst, src, q); }
@@ -1467,6 +1505,16 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
             d = RB / 2;
         } else {
             if (d == 0) break;
+            if constexpr (Form::QUAD_TREE) {
+                // a tree step with at most RB / 4 sums left: four lanes per sum (te28_quad_add), a third of the step's latency
+                if (d <= RB / 4) {
+                    const uint32_t c = threadIdx.x >> 2;
+                    if (c < d) te28_quad_add(&sm_acc[c], &sm_acc[c], &sm_acc[c + d], threadIdx.x & 3u);
+                    __syncthreads();
+                    d >>= 1;
+                    continue;
+                }
+            }
             dst = &sm_acc[t];
             pa = &sm_acc[t];
             act = t < d;
@@ -2001,7 +2049,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // longer lanes in the accumulation; they pay once the buckets alone oversubscribe the chip (r01 sweep: 128 beats
     // 32 by 10 % at 2^20 and 2^22, loses at 2^16 where 45 k buckets cannot fill 196 k lane slots).
     uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;  // smaller bounds for small MSMs measured within run-to-run noise
-    if (lat) SEG = n < 65536 ? 8 : 16;
+    if (lat) SEG = 16;  // (8 below 2^16 points until r04: with four lanes per segment the chain per entry is 2 products, not 7)
     if (const char* e = getenv("SWM_MSM_SEG")) SEG = std::min<uint32_t>(SEG_MAX, std::max(1, atoi(e)));
     // segments per bucket above which a bucket is folded ahead of the bucket stage, and the lanes that fold one
     uint32_t big_nseg = BIG_NSEG;
@@ -2010,7 +2058,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // every bucket with more than two segments below 2^16 points; from there (16-point segments, 1 - 2 per bucket) only
         // the rare long ones: listing ~2 % of the buckets cost a ~120-us launch per MSM for a two-step shorter walk
         // (r02: 2^16 proofs 11.5 -> 10.8 ms)
-        big_nseg = n < 65536 ? 2 : 6;
+        big_nseg = n < 65536 ? 4 : 6;  // (2 with 8-point segments, until r04)
         const size_t per_bucket = total / ((size_t)pl.NB * SEG) + 1;  // expected segments per bucket
         log_g = 2;
         while (log_g < 6 && ((size_t)1 << log_g) < 2 * per_bucket) log_g++;
@@ -2077,8 +2125,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         flat_bins = (pl.NB + (1u << flat_fb) - 1) >> flat_fb;
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
-    const size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
+    size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
                               (flat ? (2 + 2 * (size_t)pl.nwin + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 : 0);
+    zero_words = (zero_words + 63) & ~(size_t)63;  // whole 256-byte lines: the runtime then clears them with one kernel, not two
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
@@ -2189,8 +2238,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // SWM_ACC_LDS: dynamic LDS bytes per accumulation workgroup — an occupancy cap for experiments (54 000: three
         // workgroups per CU instead of the four its 121 VGPRs allow)
         static const size_t acc_lds = getenv("SWM_ACC_LDS") ? (size_t)atol(getenv("SWM_ACC_LDS")) : 0;
-        SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), acc_lds, tab.te, sorted, seg_start, seg_len,
-                   order, nseg_live, partial);
+        // small jobs: four lanes per segment
+        // (SWM_MSM_QUAD_ACC: digits up to which a job takes it, 0 = never)
+        static const size_t quad_acc = getenv("SWM_MSM_QUAD_ACC") ? (size_t)atol(getenv("SWM_MSM_QUAD_ACC")) : 1048576;
+        if (lat && total <= quad_acc)
+            SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te_quad, dim3((unsigned)((nseg_max + 63) / 64)), dim3(256), 0, tab.te, sorted,
+                       seg_start, seg_len, order, nseg_live, partial);
+        else
+            SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), acc_lds, tab.te, sorted, seg_start,
+                       seg_len, order, nseg_live, partial);
         SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormTE>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
                    partial, seg_off, hist, SEG, big_count, big_list, log_g);
     } else {
