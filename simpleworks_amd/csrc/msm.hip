@@ -107,7 +107,7 @@ unsigned msm_table_width(size_t n_bases) {
     // than the accumulation shrinks)
     unsigned lg = 0;
     while (((size_t)2 << lg) <= n_bases) lg++;
-    return lg <= 15 ? lg + 2 : std::min(20u, lg + 1);
+    return lg <= 14 ? lg + 2 : std::min(20u, lg + 1);  // (lg = 15, the key of a 2^14-constraint circuit: 17 until r04; 16: 4.73 instead of 4.98 ms per proof)
 }
 
 // ---------------------------------------------------------------------------------------------- digits
@@ -439,9 +439,13 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
         v[u] = 0;
         // (unrolled to the most windows a table can have: the loads go out together — with a loop over nwin each one waited for
         // the one before, ~17 round trips to L2 in a kernel that every small MSM waits for)
+        // and unconditional, from a clamped index: a load under a divergent condition is a branch of its own)
+        const uint32_t bc = min(4 * t + u, nbins - 1);
 #pragma unroll
-        for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++)
-            if (in && w < nwin) v[u] += bin_count[(size_t)w * nbins + 4 * t + u];
+        for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
+            const uint32_t x = bin_count[(size_t)(w < nwin ? w : 0u) * nbins + bc];
+            v[u] += in && w < nwin ? x : 0u;
+        }
         g[u] = in ? (1u << fb) + v[u] / SEG : 0u;
         s += v[u];
         q += g[u];
@@ -466,7 +470,10 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
             bin_seg_off[b] = rung;
             uint32_t at = run, cw[FLAT_CUR_STRIDE];
 #pragma unroll
-            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) cw[w] = w < nwin ? bin_count[(size_t)w * nbins + b] : 0u;
+            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
+                const uint32_t x = bin_count[(size_t)(w < nwin ? w : 0u) * nbins + b];
+                cw[w] = w < nwin ? x : 0u;
+            }
 #pragma unroll
             for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
                 if (w < nwin) win_off[(size_t)b * nwin + w] = at;
@@ -2532,7 +2539,7 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1
 static HostPool* host_pool_of(swm_ctx* ctx) {
     if (!ctx->host_pool) {
         unsigned hw = std::thread::hardware_concurrency();
-        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, 7u) : 0u);
+        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, hw >= 32 ? 15u : 7u) : 0u);
     }
     return ctx->host_pool;
 }
@@ -2542,6 +2549,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     if (!job->active) return SWM_OK;
     static const bool trace = getenv("SWM_TRACE") != nullptr;
     auto tw0 = std::chrono::steady_clock::now();
+    host_pool_of(ctx)->arm(1500);  // the fold follows the wait at once: the workers poll for it meanwhile
     SWM_TRY(msm_finish_wait(ctx, job));
     auto tw1 = std::chrono::steady_clock::now();
     if (!msm_fold(job, host_pool_of(ctx), result)) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
@@ -2564,6 +2572,7 @@ int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
         if (jobs[i] && jobs[i]->active) live.push_back(i);
     }
     int rc = SWM_OK;
+    if (!live.empty()) host_pool_of(ctx)->arm(1500);  // the folds follow the wait at once: the workers poll for them meanwhile
     // Jobs with their own tail finish one after the other (the tail stream runs them in order): each is folded as soon as
     // its results are there, while the GPU is still busy with the tails of the later ones — only the last fold is exposed.
     // Jobs of one joint tail launch finish together: those are folded side by side below.
