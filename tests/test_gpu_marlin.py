@@ -817,6 +817,30 @@ def test_sharded_round1_golden_bytes_2p12(M, S, W, world):
         assert exchanges >= 4 + 4 + 6 + 3, exchanges   # + round 3: f into the 4|K| domain and back, the all-gather of h_2
 
 
+@pytest.mark.parametrize("split", ["SWM_SHARD_RANGE", "SWM_SHARD_BUCKETS"])
+def test_sharded_small_key_by_ranges_golden_bytes_2p12(M, S, W, split, monkeypatch):
+    """The other two splits of the commitments on a SMALL key (2^12 constraints: low-latency schedule, accumulation and bucket
+    stage with four lanes per chain): by point range and by bucket range — the bucket stage then runs with a rank's share of its
+    workgroups, the others emit the identity — on three uneven thread-ranks: the model's bytes."""
+    case = golden("marlin_large.json")["synthetic_2p12"]
+    cs, public = W.synthetic_r1cs(case["num_constraints"], h2i(case["a"]), h2i(case["b"]))
+    for k in ("SWM_SHARD_RANGE", "SWM_SHARD_BUCKETS"):
+        monkeypatch.setenv(k, "1" if k == split else "0")
+
+    def build(ctx):
+        rng = M.generate_rand()
+        srs = M.generate_universal_srs(*case["srs"], rng, ctx=ctx)
+        pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+        proof = M.generate_proof(cs, pk, rng)
+        out = S.serialize_proof(proof).hex()
+        pk.free()
+        srs.free()
+        return out
+
+    for proof_hex in _run_sharded(3, build):
+        assert proof_hex == case["proof"]
+
+
 def test_reference_test_circuit_example(M, S, W):
     """BASELINE configs[0], examples/test-circuit.rs: the UInt8 equality circuit (two private bytes, 24 constraints, NO public
     input) through MarlinInst::{universal_setup(100, 25, 300), index, prove, verify(&[])} with one test_rng (:72-81) — the
