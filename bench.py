@@ -146,8 +146,8 @@ def cpu_baseline_prove(calls, N, mats, z, log_shift_1t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # (the first two proofs after set-up run ~2 % slower: clocks, first-touch of scratch)
     ap.add_argument("--workload", default="prove", choices=["prove", "msm", "prove_sharded"])
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--circuit", default="synthetic", choices=["synthetic", "merkle"],
