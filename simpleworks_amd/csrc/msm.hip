@@ -490,31 +490,33 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
 }
 // (entry, bucket) pairs grouped by coarse bin; grid (tiles over the points, windows).  entry = table row of the point:
 // w * tstride + toff + i, with the sign of the digit in bit 31.
+template <int FLAT_PART_U>
 __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
                                                            uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb, uint32_t nbins,
                                                            const uint32_t* __restrict__ win_off, uint32_t nwin,
                                                            uint32_t* __restrict__ bin_cursor, uint2* __restrict__ tmp) {
     // LDS: PART_TILE pairs | cnt, start, gpos (nbins words each, rounded up to a multiple of 4) | 1024 scan words: sized by
     // the bin count of the call (74 KB at 512 bins: two workgroups per CU; the fixed 4096-bin arrays allowed one)
-    extern __shared__ uint2 stage[];  // PART_TILE pairs
+    constexpr uint32_t FLAT_PART_TILE = FLAT_PART_U * 1024u;
+    extern __shared__ uint2 stage[];  // FLAT_PART_TILE pairs
     const uint32_t nb4 = (nbins + 3) & ~3u;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PART_TILE);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + FLAT_PART_TILE);
     uint32_t* start = cnt + nb4;
     uint32_t* gpos = start + nb4;
     uint32_t* scan = gpos + nb4;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
-    const size_t lo = (size_t)blockIdx.x * PART_TILE;
+    const size_t lo = (size_t)blockIdx.x * FLAT_PART_TILE;
     for (uint32_t b = t; b < nbins; b += 1024) cnt[b] = 0;
     __syncthreads();
     const uint32_t* d = digits + (size_t)w * n;
-    uint32_t c[8];
+    uint32_t c[FLAT_PART_U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < FLAT_PART_U; u++) {
         size_t i = lo + t + (size_t)u * 1024;
         c[u] = i < n ? d[i] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < FLAT_PART_U; u++)
         if (c[u]) atomicAdd(&cnt[((c[u] - 1) >> 1) >> fb], 1u);
     __syncthreads();
     // exclusive scan of cnt over <= 4096 bins: four bins per lane
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < FLAT_PART_U; u++)
         if (c[u]) {
             const uint32_t bucket = (c[u] - 1) >> 1;
             const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
@@ -2177,8 +2179,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         uint32_t ctile = 65536;  // digits per workgroup of the coarse histogram: at least ~256 workgroups
         while (ctile > 4096 && (size_t)ctile * 256 > total) ctile >>= 1;
         if (pl.nwin > FLAT_CUR_STRIDE) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many windows for the flat sort");
-        const size_t lds_part = (size_t)PART_TILE * sizeof(uint2) + (3 * (size_t)((flat_bins + 3) & ~3u) + 1024) * 4;
-        SWM_TRY(allow_big_lds(ctx, 5, (const void*)msm_flat_partition, lds_part));
+        // digits per workgroup of the partition: 16 K (r04: half the (tile, bin) runs and reserving atomics of 8 K tiles, one
+        // workgroup per CU instead of two — prove 2^20 51.6 -> 51.0 ms, and the transforms beside it run a quarter faster) as long
+        // as the pairs and the three per-bin arrays fit the 160 KB of LDS (up to 2 048 bins); 8 K above (SWM_FLAT_PART_TILE=8192: always)
+        static const bool tile16_ok = !getenv("SWM_FLAT_PART_TILE") || atoi(getenv("SWM_FLAT_PART_TILE")) >= 16384;
+        const size_t lds_bins = (3 * (size_t)((flat_bins + 3) & ~3u) + 1024) * 4;
+        const bool tile16 = tile16_ok && 16384 * sizeof(uint2) + lds_bins <= 160 * 1024;
+        const uint32_t part_tile = tile16 ? 16384u : 8192u;
+        const size_t lds_part = (size_t)part_tile * sizeof(uint2) + lds_bins;
+        SWM_TRY(allow_big_lds(ctx, tile16 ? 10 : 5, tile16 ? (const void*)msm_flat_partition<16> : (const void*)msm_flat_partition<8>, lds_part));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
@@ -2187,7 +2196,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         while (scan_threads * 4 < flat_bins) scan_threads <<= 1;
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
                    flat_fb, SEG, flat_seg_off);
-        SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), pl.nwin),
+        if (tile16)
+            SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition<16>, dim3((unsigned)((n + part_tile - 1) / part_tile), pl.nwin),
+                   dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
+                   flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
+        else
+            SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition<8>, dim3((unsigned)((n + part_tile - 1) / part_tile), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
                    flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
         // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
