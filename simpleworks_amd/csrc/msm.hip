@@ -396,7 +396,8 @@ static constexpr uint32_t FLAT_BIN_CAP = 32768;  // entries a bin may hold to be
 // one returning atomic per bin, and packed (32 cursors to a line) those atomics queued up behind one another at the
 // memory side — 135 of the kernel's 191 us at 2^20 points (measured by replacing the atomic with arithmetic).
 static constexpr uint32_t FLAT_CUR_STRIDE = 32;   // = the most windows a table can have (msm_flat_applies): one cursor per (bin, window)
-// grid (tiles over the points, windows): counts per (window, coarse bin), bin_count[w * nbins + b] — the partition places a
+// grid (tiles over the points, windows): counts per (window, coarse bin), bin_count[w * nbins + b] (window-major: a workgroup's
+// atomics land on consecutive words; bin-major lines made this kernel 23 instead of 11 us) — the partition places a
 // bin's entries WINDOW BY WINDOW (see msm_flat_scan_bins), for which it needs the bin's count of every window
 __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t n, unsigned fb,
                                                                      uint32_t nbins, uint32_t tile, uint32_t* __restrict__ bin_count) {
@@ -421,31 +422,34 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint3
     }
 }
 // Exclusive scan of <= 4096 bin totals (summed over the windows) by one workgroup: bin_off[0 .. nbins]; the offsets of every
-// (bin, window) inside that, win_off[b * nwin + w] — a bin's entries are laid out WINDOW BY WINDOW, so that a bucket's entries
+// (bin, window) inside that, win_off[b * FLAT_CUR_STRIDE + w] — a bin's entries are laid out WINDOW BY WINDOW, so that a bucket's entries
 // reach the accumulation window by window too: all lanes of the chip then gather from the table rows of the same one or two
 // windows at a time (1 / 13 of a multi-GB table: TLB reach and Infinity Cache, r04 — DESIGN.md §3.1) instead of from all of it;
 // and the bins' SEGMENT capacities 2^fb + count / SEG (an upper bound of sum over the bin's buckets of ceil(count_b / SEG)):
 // bin_seg_off[0 .. nbins] — the segment indices a bin's workgroup of msm_flat_bin_sort hands out without knowing what the
 // other bins need.
+// BPT bins per lane: 1 up to 1024 bins (one lane per bin: its 2 x 32 loads are all the latency there is), 4 above
+template <int BPT>
 __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins, uint32_t nwin,
                                                            uint32_t* __restrict__ bin_off, uint32_t* __restrict__ win_off, unsigned fb,
                                                            uint32_t SEG, uint32_t* __restrict__ bin_seg_off) {
     __shared__ uint32_t sm[1024], sg[1024];
     const uint32_t t = threadIdx.x;
-    uint32_t v[4], g[4], s = 0, q = 0;
+    uint32_t v[BPT], g[BPT], s = 0, q = 0;
+    // a bin's counts of all windows.  No branches: every load is unconditional, from a clamped (window, bin), and masked afterwards;
+    // the offsets leave as whole 128-byte lines.  (r04's first form looped over the windows with a load per trip, each waiting for
+    // the one before; its second predicated every load and store: 392 branches and 35 us in a kernel every MSM waits for.)
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const bool in = 4 * t + u < nbins;
-        v[u] = 0;
-        // (unrolled to the most windows a table can have: the loads go out together — with a loop over nwin each one waited for
-        // the one before, ~17 round trips to L2 in a kernel that every small MSM waits for)
-        // and unconditional, from a clamped index: a load under a divergent condition is a branch of its own)
-        const uint32_t bc = min(4 * t + u, nbins - 1);
+    for (int u = 0; u < BPT; u++) {
+        const bool in = BPT * t + u < nbins;
+        const uint32_t bc = min(BPT * t + u, nbins - 1);
+        uint32_t sum = 0;
 #pragma unroll
         for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
-            const uint32_t x = bin_count[(size_t)(w < nwin ? w : 0u) * nbins + bc];
-            v[u] += in && w < nwin ? x : 0u;
+            const uint32_t x = bin_count[(size_t)min(w, nwin - 1) * nbins + bc];
+            sum += w < nwin ? x : 0u;
         }
+        v[u] = in ? sum : 0u;
         g[u] = in ? (1u << fb) + v[u] / SEG : 0u;
         s += v[u];
         q += g[u];
@@ -453,7 +457,7 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
     sm[t] = s;
     sg[t] = q;
     __syncthreads();
-    const uint32_t T = blockDim.x;  // a power of two >= nbins / 4 (a single wave for the few bins of a small MSM)
+    const uint32_t T = blockDim.x;  // a power of two >= nbins / BPT (a single wave for the few bins of a small MSM)
     for (uint32_t d = 1; d < T; d <<= 1) {
         uint32_t x = t >= d ? sm[t - d] : 0u, y = t >= d ? sg[t - d] : 0u;
         __syncthreads();
@@ -463,21 +467,27 @@ __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __res
     }
     uint32_t run = sm[t] - s, rung = sg[t] - q;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t b = 4 * t + u;
+    for (int u = 0; u < BPT; u++) {
+        const uint32_t b = BPT * t + u;
         if (b < nbins) {
             bin_off[b] = run;
             bin_seg_off[b] = rung;
-            uint32_t at = run, cw[FLAT_CUR_STRIDE];
+            uint4* o = reinterpret_cast<uint4*>(win_off + (size_t)b * FLAT_CUR_STRIDE);
+            uint32_t at = run;
 #pragma unroll
-            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
-                const uint32_t x = bin_count[(size_t)(w < nwin ? w : 0u) * nbins + b];
-                cw[w] = w < nwin ? x : 0u;
-            }
-#pragma unroll
-            for (uint32_t w = 0; w < FLAT_CUR_STRIDE; w++) {
-                if (w < nwin) win_off[(size_t)b * nwin + w] = at;
-                at += cw[w];
+            for (uint32_t k = 0; k < FLAT_CUR_STRIDE / 4; k++) {  // exclusive prefix over the windows (the words beyond nwin: unused)
+                uint4 c;
+                c.x = bin_count[(size_t)min(4 * k + 0, nwin - 1) * nbins + b];
+                c.y = bin_count[(size_t)min(4 * k + 1, nwin - 1) * nbins + b];
+                c.z = bin_count[(size_t)min(4 * k + 2, nwin - 1) * nbins + b];
+                c.w = bin_count[(size_t)min(4 * k + 3, nwin - 1) * nbins + b];
+                uint4 w4;
+                w4.x = at;
+                w4.y = w4.x + c.x;
+                w4.z = w4.y + c.y;
+                w4.w = w4.z + c.z;
+                at = w4.w + c.w;
+                o[k] = w4;
             }
         }
         run += v[u];
@@ -551,7 +561,7 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
             start[b] = run;
             cnt[b] = run;  // running cursor of the bin inside the staged tile
             // the run of this (tile, bin) inside the bin's range of window w; the cursors of a bin's windows share one line
-            gpos[b] = v[u] ? win_off[(size_t)b * nwin + w] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE + w], v[u]) : 0u;
+            gpos[b] = v[u] ? win_off[(size_t)b * FLAT_CUR_STRIDE + w] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE + w], v[u]) : 0u;
         }
         run += v[u];
     }
@@ -2135,7 +2145,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
     size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
-                              (flat ? (2 + 2 * (size_t)pl.nwin + (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 : 0);
+                              (flat ? (2 + 3 * (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 + 32 : 0);
     zero_words = (zero_words + 63) & ~(size_t)63;  // whole 256-byte lines: the runtime then clears them with one kernel, not two
     SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
     cursor = hist + pl.NB + 1;
@@ -2143,12 +2153,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     len_hist = big_count + 4;
     uint32_t* two_level_bad = len_hist + (SEG_MAX + 1) * LEN_STRIDE;  // one flag per window, then the per-(window, bin) cursors
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
-    // [windows x bins] counts | [bins + 1] offsets | [bins + 1] first segment index | [bins x windows] offsets | [bins] cursor lines
-    uint32_t* flat_cnt = bin_cursor + (size_t)pl.nwin * maxbins;
-    uint32_t* flat_off = flat_cnt + (size_t)pl.nwin * FLAT_MAX_BINS;
+    // [windows x bins] counts (room for 32 windows) | [bins x 32] offsets | [bins x 32] cursors (one 128-byte line per bin each) |
+    // [bins + 1] offsets | [bins + 1] first segment index
+    // (the [bins x 32] blocks start on 128-byte lines: vector loads / stores of a bin's windows)
+    uint32_t* flat_cnt = hist + ((((size_t)(bin_cursor - hist) + (size_t)pl.nwin * maxbins) + 31) & ~(size_t)31);
+    uint32_t* flat_win_off = flat_cnt + (size_t)FLAT_CUR_STRIDE * FLAT_MAX_BINS;
+    uint32_t* flat_cur = flat_win_off + (size_t)FLAT_CUR_STRIDE * FLAT_MAX_BINS;
+    uint32_t* flat_off = flat_cur + (size_t)FLAT_CUR_STRIDE * FLAT_MAX_BINS;
     uint32_t* flat_seg_off = flat_off + FLAT_MAX_BINS + 2;  // [bins + 1] first segment index of every bin
-    uint32_t* flat_win_off = flat_seg_off + FLAT_MAX_BINS + 2;
-    uint32_t* flat_cur = flat_win_off + (size_t)pl.nwin * FLAT_MAX_BINS;
     uint2* pairs = nullptr;
     if (two_level || flat) SWM_TRY(scratch(ctx, nm[9], total * sizeof(uint2), (void**)&pairs));
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
@@ -2193,8 +2205,13 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
                    digits, n, flat_fb, flat_bins, ctile, flat_cnt);
         unsigned scan_threads = 64;
-        while (scan_threads * 4 < flat_bins) scan_threads <<= 1;
-        SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
+        const bool one_bin_per_lane = flat_bins <= 1024;
+        while (scan_threads * (one_bin_per_lane ? 1 : 4) < flat_bins) scan_threads <<= 1;
+        if (one_bin_per_lane)
+            SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins<1>, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
+                   flat_fb, SEG, flat_seg_off);
+        else
+            SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins<4>, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
                    flat_fb, SEG, flat_seg_off);
         if (tile16)
             SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition<16>, dim3((unsigned)((n + part_tile - 1) / part_tile), pl.nwin),
