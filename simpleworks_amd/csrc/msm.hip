@@ -993,29 +993,38 @@ __global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG
         run += c[u];
     }
 }
-__global__ void __launch_bounds__(ORD_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
-                                                             const uint32_t* __restrict__ nseg_ptr, uint32_t SEG,
-                                                             uint32_t* __restrict__ len_cursor /* offsets, advanced */,
-                                                             uint32_t* __restrict__ order) {
+// (4096 segments per workgroup — r04; 256 before: every workgroup reserves a run per length class with a returning global atomic,
+// and ~230 k of those on 129 addresses were the kernel's 24 us at 2^20 points)
+static constexpr int ORD2_THREADS = 1024, ORD2_U = 4;
+__global__ void __launch_bounds__(ORD2_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
+                                                              const uint32_t* __restrict__ nseg_ptr, uint32_t SEG,
+                                                              uint32_t* __restrict__ len_cursor /* offsets, advanced */,
+                                                              uint32_t* __restrict__ order) {
     __shared__ uint32_t lh[SEG_MAX + 1];
-    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) lh[i] = 0;
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD2_THREADS) lh[i] = 0;
     __syncthreads();
-    uint32_t seg = blockIdx.x * ORD_THREADS + threadIdx.x;
     // *nseg_ptr bounds the segment INDICES in use; the flat schedule leaves indices without entries between the bins
     // (msm_flat_bin_sort): those are not handed to a lane
-    bool live = seg < *nseg_ptr && (seg_len[seg] & 0xffu) != 0;  // (bits 8 ..: the stride of an interleaved segment)
-    uint32_t bin = 0;
-    if (live) {
-        bin = SEG - (seg_len[seg] & 0xffu);
-        atomicAdd(&lh[bin], 1u);
+    const uint32_t nseg = *nseg_ptr;
+    uint32_t bin[ORD2_U];
+    bool live[ORD2_U];
+#pragma unroll
+    for (int u = 0; u < ORD2_U; u++) {
+        const uint32_t seg = (blockIdx.x * ORD2_U + u) * ORD2_THREADS + threadIdx.x;
+        const uint32_t len = seg < nseg ? seg_len[seg] & 0xffu : 0u;  // (bits 8 ..: the stride of an interleaved segment)
+        live[u] = len != 0;
+        bin[u] = SEG - len;
+        if (live[u]) atomicAdd(&lh[bin[u]], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS) {
+    for (uint32_t i = threadIdx.x; i <= SEG; i += ORD2_THREADS) {
         uint32_t v = lh[i];
         if (v) lh[i] = atomicAdd(&len_cursor[i * LEN_STRIDE], v);  // reserve a run; lh[i] = its start
     }
     __syncthreads();
-    if (live) order[atomicAdd(&lh[bin], 1u)] = seg;
+#pragma unroll
+    for (int u = 0; u < ORD2_U; u++)
+        if (live[u]) order[atomicAdd(&lh[bin[u]], 1u)] = (blockIdx.x * ORD2_U + u) * ORD2_THREADS + threadIdx.x;
 }
 
 // Dominant kernel: one lane per segment, XYZZ accumulator in registers, affine bases gathered from HBM/L2.
@@ -2266,7 +2275,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                    SEG, seg_start, seg_len, len_hist);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG, nseg_live);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3(grid_s), dim3(ORD_THREADS), 0, seg_len, seg_space, SEG,
+    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3((unsigned)((nseg_max + ORD2_THREADS * ORD2_U - 1) / (ORD2_THREADS * ORD2_U))),
+               dim3(ORD2_THREADS), 0, seg_len, seg_space, SEG,
                len_hist, order);
     unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
     static const unsigned acc_cap = getenv("SWM_ACC_WGS") ? (unsigned)atoi(getenv("SWM_ACC_WGS")) : 0u;
