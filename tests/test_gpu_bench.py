@@ -33,3 +33,25 @@ def test_bench_multi_rank_path_with_a_world_of_one():
     assert sh["proof_bytes_identical_on_all_ranks"] is True
     assert sh["ranks"] == 1 and sh["exchanges_per_proof"] >= 4   # the per-round all-gathers went through the library's communicator
     assert sh["ms_per_proof"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_through_the_drivers_launcher():
+    """The driver's N > 1 command line — python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 … — on a single-GPU box: both ranks on device 0, the collectives over gloo (the hooks
+    SWM_BENCH_BACKEND / SWM_BENCH_DEVICE), the sharded leg off (two ranks of one RCCL communicator cannot share a device).  Rank 0
+    must print ONE JSON line whose value is the whole job: both ranks' proofs over the max-over-ranks time."""
+    env = dict(os.environ)
+    env.update({"SWM_BENCH_BACKEND": "gloo", "SWM_BENCH_DEVICE": "0", "SWM_BENCH_NO_SHARDED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--log-n", "14", "--no-cpu-baseline", "--no-drop-in"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * (1 << 14) / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]   # whole-job units / max-over-ranks time
+    assert line["sharded"] is None
