@@ -57,5 +57,6 @@ def test_switches_select_equivalent_paths():
                 {"SWM_MSM_QUAD": "0", "SWM_BINV_SMALL": "0"},  # small MSMs: one lane per chain of the bucket stage; 16-element inversion chunks
                 {"SWM_MSM_QUAD_RB": "64", "SWM_MSM_QUAD_MAXB": "1048576"},   # quad bucket stage in its other shapes, also at 2^17
                 {"SWM_MSM_QUAD_RB": "256", "SWM_MSM_QUAD_BLOCKS": "16"},
+                {"SWM_MSM_QUAD_ACC": "0", "SWM_FLAT_PART_TILE": "8192"},  # one lane per segment in small accumulations; 8 K-digit partition tiles
                 {"SWM_MSM_TABLE_C": "15"}):      # narrower window tables (what a rank of a sharded proof takes)
         assert _run(env) == ref, env
