@@ -161,6 +161,10 @@ def main():
                          "ChaCha12 standing for StdRng), `adopt` = the caller's ChaCha state handed over with "
                          "swm_rng_from_chacha and written back after every proof.  Whatever is chosen, the line carries a "
                          "`drop_in_rng` object with the other modes measured over a few proofs.")
+    ap.add_argument("--sharded-log-n", default=None,
+                    help="N > 1, workload prove: sizes (comma-separated log2 of the constraint count) of the `sharded` leg — ONE proof "
+                         "over all ranks through the library's RCCL exchange.  Default: the --log-n size, then 2^22 (BASELINE "
+                         "configs[3]) when the headline size is 2^20")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in_rng proofs after the timed loop (profiling runs)")
     ap.add_argument("--cpu-log-n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,27 +376,38 @@ def main():
     # N > 1, workload prove: besides the replicas figure (value), ONE proof over all ranks through the library's own RCCL
     # exchange (swm_rccl_init; point-range sharded commitment MSMs, one ncclAllGather per prover round) is measured and
     # reported as the `sharded` sub-object.  Runs in a watchdog thread: a stuck collective must not cost the headline line.
-    sharded_info = None
+    sharded_info, sharded_more = None, []
     if use_dist and args.workload == "prove" and not os.environ.get("SWM_BENCH_NO_SHARDED"):
         import threading
-        box = {}
+        # sizes of the sharded leg: the headline size and BASELINE configs[3]'s 2^22 (the synthetic circuit only), each under
+        # its own watchdog; --sharded-log-n picks others.  The first size is `sharded`, the rest `sharded_more`.
+        if args.sharded_log_n:
+            sizes = [int(x) for x in args.sharded_log_n.split(",") if x]
+        else:
+            sizes = [args.log_n] + ([22] if args.circuit == "synthetic" and args.log_n == 20 and world > 1 else [])
+        state = {"comm": False}
 
-        def run_sharded():
+        def run_sharded(lg_s, box):
             try:
-                from simpleworks_amd._lib import rccl_unique_id
-                idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-                if rank == 0:
-                    idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
-                dist.broadcast(idt, 0)
-                ctx.rccl_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                if not state["comm"]:
+                    from simpleworks_amd._lib import rccl_unique_id
+                    idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+                    if rank == 0:
+                        idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
+                    dist.broadcast(idt, 0)
+                    ctx.rccl_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                    state["comm"] = True
                 rng_s = M.generate_rand()
                 if args.circuit == "merkle":
-                    scs = W.merkle_membership_circuit(leaf_u8=0xA7)[0].pack()
-                    srs_s = M.generate_universal_srs(scs.num_constraints, scs.instance.shape[0] + scs.witness.shape[0],
+                    mcs_s, pub_s, _ = W.merkle_membership_circuit(leaf_u8=0xA7)
+                    scs = mcs_s.pack()
+                    ns = scs.num_constraints
+                    srs_s = M.generate_universal_srs(ns, scs.instance.shape[0] + scs.witness.shape[0],
                                                      max(int(m[0][-1]) for m in scs.mats), rng_s)
                 else:
-                    srs_s = M.generate_universal_srs(n, n, n, rng_s)
-                    scs, _ = W.synthetic_r1cs(n, 0x1234567, 0x7654321)  # the SAME system on every rank
+                    ns = 1 << lg_s
+                    srs_s = M.generate_universal_srs(ns, ns, ns, rng_s)
+                    scs, pub_s = W.synthetic_r1cs(ns, 0x1234567, 0x7654321)  # the SAME system on every rank
                 pk_s, vk_s = M.generate_proving_and_verifying_keys(srs_s, scs)
                 srs_s.free()
                 M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
@@ -410,17 +425,24 @@ def main():
                 dist.all_gather(hs, h)
                 tt2 = torch.tensor([dts], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-                box["res"] = {"ms_per_proof": float(tt2.item()) / reps * 1e3, "constraints_per_s": n * reps / float(tt2.item()),
-                              "ranks": world, "exchange": "ncclAllGather inside libswmarlin (swm_rccl_init), one per prover round",
+                box["res"] = {"constraints": ns, "ms_per_proof": float(tt2.item()) / reps * 1e3, "constraints_per_s": ns * reps / float(tt2.item()),
+                              "ranks": world, "exchange": "ncclAllGather / grouped ncclSend+ncclRecv inside libswmarlin (swm_rccl_init)",
                               "exchanges_per_proof": (c1 - c0) / reps, "bytes_per_rank_per_proof": (b1 - b0) / reps,
-                              "proof_bytes_identical_on_all_ranks": all(bool((x == hs[0]).all()) for x in hs)}
+                              "proof_bytes_identical_on_all_ranks": all(bool((x == hs[0]).all()) for x in hs),
+                              "proof_verifies": bool(M.verify_proof(vk_s, pub_s, pr, M.generate_rand()))}
                 pk_s.free()
             except Exception as e:  # noqa: BLE001
                 box["res"] = {"error": repr(e)}
-        th = threading.Thread(target=run_sharded, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240")))
-        sharded_info = box.get("res", {"error": "timed out"})
+        results = []
+        for lg_s in sizes:
+            box = {}
+            th = threading.Thread(target=run_sharded, args=(lg_s, box), daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240" if lg_s <= 20 else "600")))
+            results.append(box.get("res", {"error": "timed out", "log_n": lg_s}))
+            if "error" in results[-1]:
+                break  # a rank that gave up cannot take part in the next size's collectives
+        sharded_info, sharded_more = results[0], results[1:]
 
     if rank == 0:
         dom = prof[dominant]
@@ -437,20 +459,14 @@ def main():
         achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC passes need their own rocprofv3 invocation,
         # MI355X_MICROARCH.md); taken from the newest committed PMC summary under profiles/ and scaled per point.
-        def source_sha16(files):
-            """identity of a kernel's source files (tools/pmc_summaries.py stores it with every counter summary): a summary whose
-            sources have changed since is reported as stale — the figure is from another kernel than the one timed here"""
-            h = hashlib.sha256()
-            try:
-                for f in files:
-                    h.update(open(os.path.join(ROOT, "simpleworks_amd", "csrc", f), "rb").read())
-            except OSError:
-                return None
-            return h.hexdigest()[:16]
+        # identity of a kernel's code = sha256 over every file its translation unit includes (tools/srchash.py; stored with
+        # every counter summary by tools/pmc_summaries.py): a summary whose sources have changed since is reported as stale —
+        # the figure is from another kernel, or another launch geometry, than the one timed here
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from srchash import unit_sha16
 
-        def stale(summary, files):
-            return None if summary is None else summary.get("source_sha16") != source_sha16(files)
-        ACC_SOURCES = ("msm.hip", "fq28.cuh", "fq28_mul_asm.inc", "g1.cuh")
+        def stale(summary, kernel):
+            return None if summary is None else summary.get("source_sha16") != unit_sha16(kernel)
         traffic, traffic_source, traffic_stale = None, None, None
         try:
             pmcs = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc_msm_accumulate\.json", f)),
@@ -458,7 +474,7 @@ def main():
             if pmcs:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
                 traffic = pmc["hbm_bytes_per_point"] * (alg_bytes / 128.0)
-                traffic_stale = stale(pmc, ACC_SOURCES)
+                traffic_stale = stale(pmc, "msm_accumulate")
                 traffic_source = "profiles/" + pmcs[-1] + " (separate rocprofv3 --pmc passes; bytes per point scaled to this launch size)"
         except Exception:
             traffic = None
@@ -485,7 +501,7 @@ def main():
                               "frac": a / HBM_PEAK_GBS,
                               "traffic": ntt_pmc["hbm_bytes_per_element_per_transform"] * work["ntt_elements"] / args.steps if ntt_pmc else None,
                               "traffic_source": ntt_src and ntt_src + " (separate --pmc passes on the stand-alone transform, bytes per element scaled to this step)",
-                              "traffic_stale": stale(ntt_pmc, ("ntt.hip", "fr29.cuh", "fr29_mul_asm.inc")),
+                              "traffic_stale": stale(ntt_pmc, "ntt_pass"),
                               "algorithmic_bytes": "64 B x %d elements over %d transforms (%d launches)"
                                                    % (work["ntt_elements"] / args.steps, work["ntt_calls"] / args.steps,
                                                       prof["ntt_pass"]["calls"] / args.steps),
@@ -501,7 +517,7 @@ def main():
                               "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                               "traffic": spmv_pmc["hbm_bytes_per_nnz"] * work["spmv_nnz"] / args.steps if spmv_pmc else None,
                               "traffic_source": spmv_src and spmv_src + " (separate --pmc passes on the stand-alone mat-vec, bytes per non-zero scaled to this step)",
-                              "traffic_stale": stale(spmv_pmc, ("spmv.hip",)),
+                              "traffic_stale": stale(spmv_pmc, "spmv"),
                               "algorithmic_bytes": "68 B x %d non-zeros + 36 B x %d rows over %d mat-vecs"
                                                    % (work["spmv_nnz"] / args.steps, work["spmv_rows"] / args.steps,
                                                       work["spmv_calls"] / args.steps),
@@ -529,9 +545,9 @@ def main():
                          # committed SQ counters of the same kernel (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
                          "mixed_adds_per_s": work["msm_adds"] / (dom["total_ms"] * 1e-3) if dom["total_ms"] else None,
                          "issue_ceiling_mixed_adds_per_s": ceiling, "issue_ceiling_source": sq_src,
-                         "issue_ceiling_stale": stale(sq, ACC_SOURCES)},
+                         "issue_ceiling_stale": stale(sq, "msm_accumulate")},
             "roofline_secondary": secondary,
-            "sharded": sharded_info,
+            "sharded": sharded_info, "sharded_more": sharded_more or None,
             "verify_ms_host": verify_ms if args.workload != "msm" else None,
             "rng": args.rng, "drop_in_rng": drop_in,
             "work_per_step": {k: v / args.steps for k, v in work.items()},
@@ -554,13 +570,15 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:
-        if sharded_info is not None and "error" in sharded_info:
-            # a watchdog-abandoned collective may never return: leave without the orderly teardown — the JSON line is out,
-            # but the failed leg must not look like success
+        failed = [r for r in [sharded_info] + sharded_more if r is not None and "error" in r]
+        if failed:
+            # The headline (replicas) measurement is valid and its line is out with `sharded: {"error": ...}` in it: a failed or
+            # timed-out sharded leg must not turn that into a failed run.  A watchdog-abandoned collective may never return,
+            # so leave without the orderly teardown (which would wait for it) — with exit code 0.
             sys.stdout.flush()
-            sys.stderr.write("bench: the sharded leg failed: %s\n" % sharded_info["error"])
+            sys.stderr.write("bench: the sharded leg failed (reported in the JSON line, exit code stays 0): %s\n" % failed[0]["error"])
             sys.stderr.flush()
-            os._exit(3)
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -122,7 +122,7 @@ struct ByteReader {
     size_t n, pos = 0;
     ByteReader(const uint8_t* d, size_t len) : p(d), n(len) {}
     const uint8_t* take(size_t k) {
-        if (pos + k > n) throw MarlinError(SWM_ERR_SERIALIZATION, "unexpected end of input");
+        if (k > n - pos) throw MarlinError(SWM_ERR_SERIALIZATION, "unexpected end of input");  // (pos <= n always: no wrap for a huge k)
         const uint8_t* r = p + pos;
         pos += k;
         return r;

@@ -9,6 +9,8 @@
 //   * round 3 forms (a - b f) in evaluation form on the 4|K| domain (1 FFT + 1 iFFT instead of 3 iFFT + 2 FFT + 1 iFFT);
 //   * only the three gamma-powers KZG hiding needs are generated at setup (arkworks generates max_degree + 2).
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>  // environ
 #include <algorithm>
 #include <chrono>
 #include <functional>
@@ -30,9 +32,8 @@ using namespace swm;
     } while (0)
 
 // ================================================================================================ handles
-struct swm_rng {
-    ChaChaRng r;
-};
+#include "host/pk_codec.h"      // HostCsr, the host-side prefix of the proving-key codec
+#include "host/host_handles.h"  // swm_rng, swm_vk: host-only handles (shared with the sanitizer harness, tests/native/host_fuzz.cpp)
 struct swm_srs {
     ~swm_srs() {
         if (d_powers) (void)hipFree(d_powers);
@@ -45,18 +46,9 @@ struct swm_srs {
     std::vector<G1Affine> gamma_powers;  // [beta^i] gamma_g, i < 3 (host)
     G2Affine h, beta_h;
 };
-struct swm_vk {
-    VerifyingKey vk;
-};
 
 namespace {
 
-struct HostCsr {
-    std::vector<uint32_t> rowptr, col;
-    std::vector<Fr> val;
-    size_t rows() const { return rowptr.size() - 1; }
-    size_t nnz() const { return col.size(); }
-};
 struct DevCsr {
     DBuf<uint32_t> rowptr, col;
     DVec val;
@@ -393,18 +385,33 @@ G1XYZZ commit_dev(swm_ctx* ctx, const swm_pk& pk, size_t offset, const Fr* coeff
 void shard_agree(swm_ctx* ctx, const swm_pk& pk) {
     if (ctx->shard_world <= 1) return;
     struct Rec {
-        uint32_t tab_c, shtab_c, te, switches, n_powers_lo, n_shifted_lo, world, pad;
+        uint32_t tab_c, shtab_c, te, switches, n_powers_lo, n_shifted_lo, world, env_hash;
     } mine;
     auto on = [](const char* name) { return getenv(name) && atoi(getenv(name)) != 0 ? 1u : 0u; };
     mine.tab_c = pk.tab_c;
     mine.shtab_c = pk.shtab_c;
     mine.te = (pk.d_powers_te ? 1u : 0u) | (pk.d_shifted_te ? 2u : 0u);
+    // bits 8 ..: the block size of the block-cyclic split as the process sets it (commit_enqueue clamps it by the polynomial's
+    // length, the same on every rank): two ranks with different blocks would cover some coefficients twice and others never
+    const unsigned blk = getenv("SWM_SHARD_BLOCK_LOG") ? (unsigned)std::min(20, std::max(0, atoi(getenv("SWM_SHARD_BLOCK_LOG")))) : 12u;
     mine.switches = on("SWM_SHARD_BUCKETS") | on("SWM_SHARD_RANGE") << 1 | (getenv("SWM_SHARD_R1_OFF") ? 4u : 0u) |
-                    (getenv("SWM_SHARD_R2_OFF") ? 8u : 0u) | (getenv("SWM_MSM_NO_TABLE") ? 16u : 0u);
+                    (getenv("SWM_SHARD_R2_OFF") ? 8u : 0u) | (getenv("SWM_MSM_NO_TABLE") ? 16u : 0u) | blk << 8;
     mine.n_powers_lo = (uint32_t)pk.n_powers;
     mine.n_shifted_lo = (uint32_t)pk.n_shifted;
     mine.world = ctx->shard_world;
-    mine.pad = 0;
+    // every other switch that shapes the split or the schedule (SWM_SHARD_*, SWM_MSM_*: table schedule thresholds, lane and
+    // segment choices ...), as one word: FNV-1a over the sorted NAME=value strings.  Schedule-only switches would not break a
+    // proof, but ranks that differ in them were not meant to: refused alike
+    {
+        std::vector<std::string> kv;
+        for (char** e = environ; e && *e; e++)
+            if (!strncmp(*e, "SWM_SHARD_", 10) || !strncmp(*e, "SWM_MSM_", 8)) kv.emplace_back(*e);
+        std::sort(kv.begin(), kv.end());
+        uint32_t h = 2166136261u;
+        for (const std::string& x : kv)
+            for (size_t i = 0; i <= x.size(); i++) h = (h ^ (uint8_t)(i < x.size() ? x[i] : 0)) * 16777619u;
+        mine.env_hash = h;
+    }
     std::vector<Rec> all(ctx->shard_world);
     rc_check(ctx, shard_exchange(ctx, &mine, sizeof(Rec), all.data()));
     for (unsigned g = 0; g < ctx->shard_world; g++)
@@ -413,7 +420,9 @@ void shard_agree(swm_ctx* ctx, const swm_pk& pk) {
                               "sharded proving: rank " + std::to_string(g) + " and rank 0 disagree on the key's window tables (widths " +
                                   std::to_string(all[g].tab_c) + "/" + std::to_string(all[g].shtab_c) + " vs " + std::to_string(all[0].tab_c) + "/" +
                                   std::to_string(all[0].shtab_c) + ", forms " + std::to_string(all[g].te) + " vs " + std::to_string(all[0].te) +
-                                  ") or on the sharding switches: every rank must build its key with the same free memory and environment");
+                                  ") or on the sharding switches (" + std::to_string(all[g].switches) + "/" + std::to_string(all[g].env_hash) + " vs " +
+                                  std::to_string(all[0].switches) + "/" + std::to_string(all[0].env_hash) +
+                                  "): every rank must build its key with the same free memory and the same SWM_SHARD_* / SWM_MSM_* environment");
 }
 // asynchronous form: alternates between the two MSM lanes of the context
 // With swm_set_msm_sharding active the context only takes its own point range of every MSM and the partial sums are
@@ -1986,24 +1995,6 @@ void put_matrix(ByteWriter& w, const HostCsr& m) {
         }
     }
 }
-HostCsr get_matrix(ByteReader& r, uint64_t ncols) {
-    HostCsr m;
-    uint64_t rows = r.u64();
-    if (rows > (1ull << 31)) throw MarlinError(SWM_ERR_SERIALIZATION, "bad matrix header");
-    m.rowptr.assign(1, 0);
-    for (uint64_t i = 0; i < rows; i++) {
-        uint64_t len = r.u64();
-        if (len > r.n - r.pos) throw MarlinError(SWM_ERR_SERIALIZATION, "bad matrix row");
-        for (uint64_t k = 0; k < len; k++) {
-            m.val.push_back(r.fr());
-            uint64_t c = r.u64();
-            if (c >= ncols) throw MarlinError(SWM_ERR_SERIALIZATION, "matrix column out of range");
-            m.col.push_back((uint32_t)c);
-        }
-        m.rowptr.push_back((uint32_t)m.col.size());
-    }
-    return m;
-}
 // trailing zero coefficients are not part of a DensePolynomial
 size_t trimmed_len(swm_ctx* ctx, const Fr* d, size_t n) {
     std::vector<Fr> h(n);
@@ -2062,16 +2053,6 @@ std::vector<uint8_t> pk_serialize(swm_ctx* ctx, const swm_pk& pk) {
     return w.b;
 }
 
-void skip_fr_vec(ByteReader& r, uint64_t expect_max) {
-    uint64_t n = r.u64();
-    if (n > expect_max) throw MarlinError(SWM_ERR_SERIALIZATION, "vector longer than its domain");
-    r.take(n * 32);
-}
-void skip_domain(ByteReader& r, uint64_t size) {
-    if (*r.take(1) != 0) throw MarlinError(SWM_ERR_SERIALIZATION, "not a radix-2 domain");
-    if (r.u64() != size) throw MarlinError(SWM_ERR_SERIALIZATION, "domain size does not match the index");
-    r.take(4 + 5 * 32);
-}
 // Vec<G1Affine> (compressed) -> host affine points, decompressed and checked on the device
 std::vector<G1Affine> get_g1_vec_dev(swm_ctx* ctx, ByteReader& r, uint64_t max_n) {
     uint64_t n = r.u64();
@@ -2095,54 +2076,18 @@ std::vector<G1Affine> get_g1_vec_dev(swm_ctx* ctx, ByteReader& r, uint64_t max_n
 swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
     ByteReader r(bytes, len);
     std::unique_ptr<swm_pk> pk(new swm_pk());
-    pk->vk = read_verifying_key(r);
-    uint64_t nr = r.u64();
-    if (nr != pk->vk.index_comms.size()) throw MarlinError(SWM_ERR_SERIALIZATION, "index_comm_rands does not match index_comms");
-    for (uint64_t i = 0; i < nr; i++) {
-        skip_fr_vec(r, 4);
-        if (r.boolean()) skip_fr_vec(r, 4);
-    }
-    pk->info.num_variables = r.u64();
-    pk->info.num_constraints = r.u64();
-    pk->info.num_non_zero = r.u64();
-    pk->info.num_instance_variables = r.u64();
-    if (pk->info.num_variables != pk->vk.info.num_variables || pk->info.num_constraints != pk->vk.info.num_constraints ||
-        pk->info.num_non_zero != pk->vk.info.num_non_zero || pk->info.num_instance_variables != pk->vk.info.num_instance_variables ||
-        pk->info.num_constraints != pk->info.num_variables || pk->info.num_variables > (1ull << 30) ||
-        pk->info.num_non_zero > (1ull << 31) || pk->info.num_non_zero == 0)
-        throw MarlinError(SWM_ERR_SERIALIZATION, "index info is inconsistent");
-    pk->ha = get_matrix(r, pk->info.num_variables);
-    pk->hb = get_matrix(r, pk->info.num_variables);
-    pk->hc = get_matrix(r, pk->info.num_variables);
-    if (pk->ha.rows() != pk->info.num_constraints || pk->hb.rows() != pk->info.num_constraints ||
-        pk->hc.rows() != pk->info.num_constraints)
-        throw MarlinError(SWM_ERR_SERIALIZATION, "matrix shape does not match index info");
-    if (std::max(pk->ha.nnz(), std::max(pk->hb.nnz(), pk->hc.nnz())) > pk->info.num_non_zero)
-        throw MarlinError(SWM_ERR_SERIALIZATION, "matrix density exceeds index info");
-    HDomain dh(pk->info.num_constraints), dk(pk->info.num_non_zero), dx(pk->info.num_instance_variables);
-    HDomain db(3 * dk.size - 3);
-    pk->H = dh.size; pk->logH = dh.log;
-    pk->K = dk.size; pk->logK = dk.log;
-    pk->X = dx.size; pk->logX = dx.log;
-    pk->B = db.size; pk->logB = db.log;
-    if (pk->X >= pk->H) throw MarlinError(SWM_ERR_SERIALIZATION, "index without witness variables");
-    for (int m = 0; m < 3; m++) {  // derived data: shape-checked, then recomputed below
-        for (int j = 0; j < 4; j++) {
-            uint64_t ll = r.u64();
-            if (ll > 64) throw MarlinError(SWM_ERR_SERIALIZATION, "bad polynomial label");
-            r.take(ll);
-            skip_fr_vec(r, pk->K);
-            if (r.boolean()) r.u64();
-            if (r.boolean()) r.u64();
-        }
-        for (int j = 0; j < 3; j++) {
-            skip_fr_vec(r, pk->K);
-            skip_domain(r, pk->K);
-        }
-        for (int j = 0; j < 4; j++) {
-            skip_fr_vec(r, pk->B);
-            skip_domain(r, pk->B);
-        }
+    {   // everything in front of the committer key is parsed and checked on the host (host/pk_codec.h: the same text runs under
+        // ASan / UBSan in tests/native/host_fuzz.cpp)
+        PkPrefix pre = pk_parse_prefix(r);
+        pk->vk = std::move(pre.vk);
+        pk->info = pre.info;
+        pk->ha = std::move(pre.a);
+        pk->hb = std::move(pre.b);
+        pk->hc = std::move(pre.c);
+        pk->H = pre.H; pk->logH = pre.logH;
+        pk->K = pre.K; pk->logK = pre.logK;
+        pk->X = pre.X; pk->logX = pre.logX;
+        pk->B = pre.B; pk->logB = pre.logB;
     }
     std::vector<G1Affine> powers = get_g1_vec_dev(ctx, r, 1ull << 31);
     std::vector<G1Affine> shifted;
@@ -2223,110 +2168,9 @@ void is_satisfied_impl(swm_ctx* ctx, const swm_r1cs* cs, int* ok, size_t* first_
 }  // namespace
 
 // ================================================================================================ C ABI
-#define SWM_GUARD(ctx, body)                                  \
-    try {                                                     \
-        body;                                                 \
-        return SWM_OK;                                        \
-    } catch (const MarlinError& e) {                          \
-        drain_streams(ctx);                                   \
-        set_err(ctx, e.code, "%s", e.what());                 \
-        return e.code;                                        \
-    } catch (const std::bad_alloc&) {                         \
-        drain_streams(ctx);                                   \
-        return SWM_ERR_OOM;                                   \
-    } catch (const std::exception& e) {                       \
-        drain_streams(ctx);                                   \
-        set_err(ctx, SWM_ERR_INTERNAL, "%s", e.what());       \
-        return SWM_ERR_INTERNAL;                              \
-    }
+#include "host/host_abi.inc"  // SWM_GUARD + every entry point that needs no GPU (rng, verifier, proof / vk codecs, hashes)
 
 extern "C" {
-
-int swm_rng_test_new(swm_rng** out) {
-    if (!out) return SWM_ERR_INVALID_ARG;
-    *out = new swm_rng();
-    (*out)->r = test_rng();
-    return SWM_OK;
-}
-int swm_rng_from_seed(const uint8_t seed[32], swm_rng** out) {
-    if (!out || !seed) return SWM_ERR_INVALID_ARG;
-    *out = new swm_rng();
-    (*out)->r.seed(seed, 12);
-    return SWM_OK;
-}
-int swm_rng_from_callback(swm_fill_bytes_fn fill_bytes, void* user, swm_rng** out) {
-    if (!out || !fill_bytes) return SWM_ERR_INVALID_ARG;
-    *out = new swm_rng();
-    (*out)->r = test_rng();  // unused state; every draw goes to the callback
-    (*out)->r.ext = fill_bytes;
-    (*out)->r.ext_user = user;
-    return SWM_OK;
-}
-int swm_rng_from_chacha(const uint8_t key[32], uint64_t word_pos, int rounds, swm_rng** out) {
-    if (!out || !key || (rounds != 8 && rounds != 12 && rounds != 20)) return SWM_ERR_INVALID_ARG;
-    *out = new swm_rng();
-    (*out)->r.seed(key, rounds);
-    (*out)->r.pos = word_pos;
-    return SWM_OK;
-}
-int swm_rng_word_pos(const swm_rng* rng, uint64_t* word_pos) {
-    if (!rng || !word_pos || rng->r.ext) return SWM_ERR_INVALID_ARG;
-    *word_pos = rng->r.pos;
-    return SWM_OK;
-}
-int swm_rng_fill_bytes(swm_rng* rng, uint8_t* dest, size_t len) {
-    if (!rng || (len && !dest)) return SWM_ERR_INVALID_ARG;
-    if (rng->r.ext) {
-        rng->r.ext(rng->r.ext_user, dest, len);
-        return SWM_OK;
-    }
-    size_t i = 0;
-    auto put_word = [&] {
-        uint32_t w = rng->r.next_u32();
-        dest[i] = (uint8_t)w; dest[i + 1] = (uint8_t)(w >> 8); dest[i + 2] = (uint8_t)(w >> 16); dest[i + 3] = (uint8_t)(w >> 24);
-        i += 4;
-    };
-    while (i + 4 <= len && (rng->r.pos & 15) != 0) put_word();  // up to the next block boundary word by word
-    // whole keystream blocks straight into the destination (little-endian host): what a bulk draw through the callback
-    // of a test harness asks for, 8 MB at a time
-#ifdef SWM_CHACHA_WIDE
-    while (chacha_have_avx2() && (rng->r.pos & 15) == 0 && len - i >= 512) {
-        uint32_t blk[128];
-        chacha_blocks8_avx2(rng->r.key, rng->r.pos >> 4, rng->r.rounds, blk);
-        memcpy(dest + i, blk, 512);
-        rng->r.pos += 128;
-        rng->r.have = false;
-        i += 512;
-    }
-#endif
-    while ((rng->r.pos & 15) == 0 && len - i >= 64) {
-        uint32_t blk[16];
-        chacha_block(rng->r.key, rng->r.pos >> 4, rng->r.rounds, blk);
-        memcpy(dest + i, blk, 64);
-        rng->r.pos += 16;
-        rng->r.have = false;
-        i += 64;
-    }
-    while (i + 4 <= len) put_word();
-    if (i < len) {
-        uint32_t w = rng->r.next_u32();
-        for (; i < len; i++, w >>= 8) dest[i] = (uint8_t)w;
-    }
-    return SWM_OK;
-}
-void swm_rng_fill_bytes_cb(void* user, uint8_t* dest, size_t len) { (void)swm_rng_fill_bytes(static_cast<swm_rng*>(user), dest, len); }
-void swm_rng_free(swm_rng* rng) { delete rng; }
-int swm_rng_next_u64(swm_rng* rng, uint64_t* out) {
-    if (!rng || !out) return SWM_ERR_INVALID_ARG;
-    *out = rng->r.next_u64();
-    return SWM_OK;
-}
-int swm_rng_rand_fr(swm_rng* rng, uint64_t out_mont[4]) {
-    if (!rng || !out_mont) return SWM_ERR_INVALID_ARG;
-    Fr v = rng->r.rand_fr();
-    memcpy(out_mont, v.v, 32);
-    return SWM_OK;
-}
 
 int swm_generate_universal_srs(swm_ctx* ctx, size_t nc, size_t nv, size_t nnz, swm_rng* rng, swm_srs** out) {
     if (!ctx || !rng || !out) return SWM_ERR_INVALID_ARG;
@@ -2421,7 +2265,6 @@ void swm_pk_destroy(swm_ctx* ctx, swm_pk* pk) {
     if (ctx) drain_streams(ctx);
     delete pk;
 }
-void swm_vk_destroy(swm_vk* vk) { delete vk; }
 
 int swm_generate_proof(swm_ctx* ctx, const swm_pk* pk, const swm_r1cs* cs, swm_rng* rng, uint8_t* proof_out, size_t cap,
                        size_t* len) {
@@ -2433,45 +2276,6 @@ int swm_generate_proof(swm_ctx* ctx, const swm_pk* pk, const swm_r1cs* cs, swm_r
         if (bytes.size() > cap) throw MarlinError(SWM_ERR_INVALID_ARG, "proof buffer too small");
         memcpy(proof_out, bytes.data(), bytes.size());
     });
-}
-
-int swm_verify_proof(const swm_vk* vk, const uint64_t* public_inputs, size_t n, const uint8_t* proof, size_t len,
-                     swm_rng* rng, int* ok) {
-    if (!vk || (n && !public_inputs) || !proof || !rng || !ok) return SWM_ERR_INVALID_ARG;
-    swm_ctx* none = nullptr;
-    SWM_GUARD(none, {
-        std::vector<Fr> pi;
-        for (size_t i = 0; i < n; i++) pi.push_back(fp_from_limbs<Fr>((const uint32_t*)(public_inputs + 4 * i)));
-        Proof p = deserialize_proof(proof, len);
-        *ok = verify(vk->vk, pi, p, rng->r) ? 1 : 0;
-    });
-}
-
-int swm_vk_serialize(const swm_vk* vk, uint8_t* out, size_t cap, size_t* len) {
-    if (!vk || !len) return SWM_ERR_INVALID_ARG;
-    swm_ctx* none = nullptr;
-    SWM_GUARD(none, {
-        std::vector<uint8_t> b = serialize_verifying_key(vk->vk);
-        *len = b.size();
-        if (out) {
-            if (b.size() > cap) throw MarlinError(SWM_ERR_INVALID_ARG, "buffer too small");
-            memcpy(out, b.data(), b.size());
-        }
-    });
-}
-int swm_vk_deserialize(const uint8_t* bytes, size_t len, swm_vk** out) {
-    if (!bytes || !out) return SWM_ERR_INVALID_ARG;
-    swm_ctx* none = nullptr;
-    SWM_GUARD(none, {
-        std::unique_ptr<swm_vk> v(new swm_vk());
-        v->vk = deserialize_verifying_key(bytes, len);
-        *out = v.release();
-    });
-}
-int swm_proof_validate(const uint8_t* bytes, size_t len) {
-    if (!bytes) return SWM_ERR_INVALID_ARG;
-    swm_ctx* none = nullptr;
-    SWM_GUARD(none, (void)deserialize_proof(bytes, len));
 }
 
 int swm_pk_serialize(swm_ctx* ctx, const swm_pk* pk, uint8_t* out, size_t cap, size_t* len) {
@@ -2495,20 +2299,6 @@ int swm_r1cs_is_satisfied(swm_ctx* ctx, const swm_r1cs* cs, int* ok, size_t* fir
     if (!ctx || !cs || !ok) return SWM_ERR_INVALID_ARG;
     SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, is_satisfied_impl(ctx, cs, ok, first_bad));
-}
-
-int swm_blake2s(const uint8_t* data, size_t len, uint8_t out[32]) {
-    if ((len && !data) || !out) return SWM_ERR_INVALID_ARG;
-    Blake2s::digest(data, len, out);
-    return SWM_OK;
-}
-int swm_chacha_block(const uint8_t key[32], uint64_t counter, int rounds, uint8_t out[64]) {
-    if (!key || !out) return SWM_ERR_INVALID_ARG;
-    uint32_t k[8], o[16];
-    for (int i = 0; i < 8; i++) memcpy(&k[i], key + 4 * i, 4);
-    chacha_block(k, counter, rounds, o);
-    memcpy(out, o, 64);
-    return SWM_OK;
 }
 
 }  // extern "C"

@@ -605,6 +605,24 @@ struct FlatSegOut {
 static constexpr int PLACE_U = SWM_PLACE_U;
 static constexpr uint32_t LEN_STRIDE = 32;  // the SEG + 1 length counters sit one per 128-byte line (see FLAT_CUR_STRIDE)
 __device__ __forceinline__ uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
+// segment k of the ns balanced segments of a bucket with c entries starting at `ent` (segment indices from s0); lh: the
+// workgroup's length histogram in LDS.  Interleaved segments pack their stride into seg_len (length | ns << 8): ns < 2^24,
+// otherwise (only reachable with a one-entry segment bound on a degenerate input) the bucket keeps consecutive ranges.
+static constexpr uint32_t FLAT_WIDE_NS = 16, FLAT_WIDE_Q = 32;  // segments above which a bucket is written by the workgroup; queue length
+__device__ __forceinline__ void flat_seg_write(const FlatSegOut& o, uint32_t c, uint32_t ns, uint32_t ent, uint32_t s0, uint32_t k,
+                                               uint32_t* lh) {
+    if (o.interleave && ns > 1 && ns < (1u << 24)) {
+        const uint32_t len = (c - k + ns - 1) / ns;
+        o.seg_start[s0 + k] = ent + k;
+        o.seg_len[s0 + k] = len | (ns << 8);
+        atomicAdd(&lh[o.SEG - len], 1u);
+    } else {
+        const uint32_t ks = (uint32_t)(((uint64_t)c * k) / ns), ke = (uint32_t)(((uint64_t)c * (k + 1)) / ns);
+        o.seg_start[s0 + k] = ent + ks;
+        o.seg_len[s0 + k] = ke - ks;
+        atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
+    }
+}
 __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
                                                                  const uint32_t* __restrict__ bin_off,
                                                                  const uint32_t* __restrict__ bin_seg_off, FlatSegOut o,
@@ -612,6 +630,7 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
     extern __shared__ uint32_t stage32[];  // fc[nf] | fo[nf] | FLAT_BIN_CAP entries
     __shared__ uint32_t wsum[2][BIN_THREADS / 64];
     __shared__ uint32_t lh[SEG_MAX + 1];
+    __shared__ uint32_t wide[FLAT_WIDE_Q][3], nwide;  // buckets whose descriptors the whole workgroup writes: (count, first entry, first segment)
     uint32_t* fc = stage32;
     uint32_t* fo = fc + (1u << fb);
     uint32_t* stage = fo + (1u << fb);
@@ -620,6 +639,7 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
     const uint32_t seg_lo = bin_seg_off[bin], seg_hi = bin_seg_off[bin + 1];
     for (uint32_t f = t; f < nf; f += BIN_THREADS) fc[f] = 0;
     for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS) lh[i] = 0;
+    if (t == 0) nwide = 0;
     __syncthreads();
     for (uint32_t i = t; i < cnt; i += BIN_THREADS) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
     __syncthreads();
@@ -662,18 +682,17 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
             o.hist[b] = c;
             o.bucket_off[b] = ent;
             o.seg_off[b] = s0;
-            for (uint32_t k = 0; k < ns; k++) {  // balanced split, as msm_seg_desc: one segment per bucket unless c > SEG
-                if (o.interleave && ns > 1) {
-                    const uint32_t len = (c - k + ns - 1) / ns;
-                    o.seg_start[s0 + k] = ent + k;
-                    o.seg_len[s0 + k] = len | (ns << 8);
-                    atomicAdd(&lh[o.SEG - len], 1u);
-                } else {
-                    const uint32_t ks = (uint32_t)(((uint64_t)c * k) / ns), ke = (uint32_t)(((uint64_t)c * (k + 1)) / ns);
-                    o.seg_start[s0 + k] = ent + ks;
-                    o.seg_len[s0 + k] = ke - ks;
-                    atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
-                }
+            // balanced split, as msm_seg_desc: one segment per bucket unless c > SEG.  A bucket with many segments (skewed
+            // scalars: 2^20 equal ones are 8192 segments of one bucket) is queued for the WHOLE workgroup (below) instead of
+            // being written by this lane alone — the kernel every flat MSM waits for must not serialise on one lane
+            uint32_t slot = FLAT_WIDE_Q;
+            if (ns > FLAT_WIDE_NS) slot = atomicAdd(&nwide, 1u);
+            if (slot < FLAT_WIDE_Q) {
+                wide[slot][0] = c;
+                wide[slot][1] = ent;
+                wide[slot][2] = s0;
+            } else {
+                for (uint32_t k = 0; k < ns; k++) flat_seg_write(o, c, ns, ent, s0, k, lh);
             }
             if (ns > o.big_nseg) o.big_list[atomicAdd(o.big_count, 1u)] = b;
         }
@@ -681,6 +700,11 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
         runs += ns;
     }
     for (uint32_t k = seg_lo + used + t; k < seg_hi; k += BIN_THREADS) o.seg_len[k] = 0;  // indices the bin did not need
+    __syncthreads();
+    for (uint32_t q = 0, nq = min(nwide, FLAT_WIDE_Q); q < nq; q++) {  // the queued many-segment buckets: one segment per lane and trip
+        const uint32_t c = wide[q][0], ns = nseg_of(c, o.SEG);
+        for (uint32_t k = t; k < ns; k += BIN_THREADS) flat_seg_write(o, c, ns, wide[q][1], wide[q][2], k, lh);
+    }
     __syncthreads();
     for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS)
         if (lh[i]) atomicAdd(&o.len_hist[i * LEN_STRIDE], lh[i]);
@@ -2577,12 +2601,26 @@ static bool msm_fold(const MsmJob* job, HostPool* pool, G1XYZZ* result, const G1
     return job->te ? msm_fold_form<HostTE>(job, pool, result, groups) : msm_fold_form<HostXYZZ>(job, pool, result, groups);
 }
 
+// Host workers of a context: 15 (7 on hosts with fewer than 32 hardware threads), but never more than this process's share of
+// the machine: hardware threads / ranks on the node (LOCAL_WORLD_SIZE of the launcher, or the context's shard world for ranks
+// that are threads of one process) minus the proving thread — eight ranks with 15 polling workers each would be 120 spinning
+// threads beside the provers, torch and the RCCL proxies.  SWM_POOL_WORKERS overrides.
 static HostPool* host_pool_of(swm_ctx* ctx) {
     if (!ctx->host_pool) {
         unsigned hw = std::thread::hardware_concurrency();
-        ctx->host_pool = new HostPool(hw > 1 ? std::min(hw - 1, hw >= 32 ? 15u : 7u) : 0u);
+        unsigned want = hw > 1 ? std::min(hw - 1, hw >= 32 ? 15u : 7u) : 0u;
+        unsigned ranks = std::max(1u, ctx->shard_world);
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(ranks, (unsigned)std::max(1, atoi(e)));
+        if (ranks > 1 && hw) want = std::min(want, std::max(1u, hw / ranks) - 1);
+        if (const char* e = getenv("SWM_POOL_WORKERS")) want = (unsigned)std::min(64, std::max(0, atoi(e)));
+        ctx->host_pool = new HostPool(want);
     }
     return ctx->host_pool;
+}
+// how long the workers poll for the fold that follows a wait (microseconds; SWM_POOL_SPIN_US, 0 = they sleep)
+static unsigned pool_spin_us() {
+    static const unsigned us = getenv("SWM_POOL_SPIN_US") ? (unsigned)std::min(100000, std::max(0, atoi(getenv("SWM_POOL_SPIN_US")))) : 1500u;
+    return us;
 }
 
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
@@ -2590,7 +2628,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     if (!job->active) return SWM_OK;
     static const bool trace = getenv("SWM_TRACE") != nullptr;
     auto tw0 = std::chrono::steady_clock::now();
-    host_pool_of(ctx)->arm(1500);  // the fold follows the wait at once: the workers poll for it meanwhile
+    if (pool_spin_us()) host_pool_of(ctx)->arm(pool_spin_us());  // the fold follows the wait at once: the workers poll for it meanwhile
     SWM_TRY(msm_finish_wait(ctx, job));
     auto tw1 = std::chrono::steady_clock::now();
     if (!msm_fold(job, host_pool_of(ctx), result)) return set_err(ctx, SWM_ERR_INTERNAL, "msm: inconsistent window fold");
@@ -2613,7 +2651,7 @@ int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
         if (jobs[i] && jobs[i]->active) live.push_back(i);
     }
     int rc = SWM_OK;
-    if (!live.empty()) host_pool_of(ctx)->arm(1500);  // the folds follow the wait at once: the workers poll for them meanwhile
+    if (!live.empty() && pool_spin_us()) host_pool_of(ctx)->arm(pool_spin_us());  // the folds follow the wait at once: the workers poll for them meanwhile
     // Jobs with their own tail finish one after the other (the tail stream runs them in order): each is folded as soon as
     // its results are there, while the GPU is still busy with the tails of the later ones — only the last fold is exposed.
     // Jobs of one joint tail launch finish together: those are folded side by side below.

@@ -302,6 +302,8 @@ def gen_pk_bytes():
         b = M.serialize_proving_key(pk)
         out[name] = {"srs": list(sizes), "len": len(b), "sha256": hashlib.sha256(b).hexdigest(), "head": b[:64].hex(),
                      "n_powers": len(pk["ck"].powers), "n_shifted": len(pk["ck"].shifted_powers)}
+        if name == "manual_constraints":  # the smallest key in full: input of the mutation harness (tests/test_host_sanitizers.py)
+            out[name]["bytes"] = b.hex()
         print(" pk bytes", name, len(b))
     dump("pk_bytes.json", out)
 

@@ -41,6 +41,7 @@ def test_bench_two_ranks_through_the_drivers_launcher():
     --master-port P bench.py --gpus 2 … — on a single-GPU box: both ranks on device 0, the collectives over gloo (the hooks
     SWM_BENCH_BACKEND / SWM_BENCH_DEVICE), the sharded leg off (two ranks of one RCCL communicator cannot share a device).  Rank 0
     must print ONE JSON line whose value is the whole job: both ranks' proofs over the max-over-ranks time."""
+    pytest.importorskip("torch")
     env = dict(os.environ)
     env.update({"SWM_BENCH_BACKEND": "gloo", "SWM_BENCH_DEVICE": "0", "SWM_BENCH_NO_SHARDED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):

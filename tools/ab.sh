@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the library on ONE box, alternating (box-to-box spread is +-3 %, more than most changes):
 #   bash tools/ab.sh <libA.so> <libB.so> [rounds] [bench.py arguments ...]      prints ms per step of every run
-a=$1; b=$2; rounds=${3:-2}; shift 3 2>/dev/null
+a=$1; b=$2; shift 2; rounds=${1:-2}; [ $# -gt 0 ] && shift
 args=${@:---steps 10 --warmup 3 --no-cpu-baseline --no-drop-in}
 for r in $(seq $rounds); do
   for lib in $a $b; do

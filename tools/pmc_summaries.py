@@ -12,19 +12,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 o, p = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 
 
-def kernel_source_sha16(files):
-    """Identity of the code a counter summary was measured on: sha256 over the kernel's source files.  bench.py recomputes it and
-    marks a figure `..._stale` when the sources have changed since the PMC passes were collected."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in files:
-        h.update(open(os.path.join(root, "simpleworks_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
-
-
-ACC_SOURCES = ("msm.hip", "fq28.cuh", "fq28_mul_asm.inc", "g1.cuh")
-NTT_SOURCES = ("ntt.hip", "fr29.cuh", "fr29_mul_asm.inc")
-SPMV_SOURCES = ("spmv.hip",)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from srchash import unit_sha16  # noqa: E402  (sha256 over the include closure of the kernel's translation unit)
 
 
 def counters(d, skip_first=1):
@@ -116,7 +105,7 @@ def dominant_sq():
     util = g("SQ_ACTIVE_INST_ANY") * waves_per_simd / g("SQ_WAVE_CYCLES")
     ms = dur[(kern, "SQ_WAVE_CYCLES")]
     out = {
-        "kernel": kern, "source_sha16": kernel_source_sha16(ACC_SOURCES), "launch": "2^20-point MSM, %d non-zero digits (mixed additions) per launch" % int(b["work_per_step"]["msm_adds"]),
+        "kernel": kern, "source_sha16": unit_sha16("msm_accumulate"), "launch": "2^20-point MSM, %d non-zero digits (mixed additions) per launch" % int(b["work_per_step"]["msm_adds"]),
         "command": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY "
                    "SQ_WAIT_ANY --kernel-include-regex msm_accumulate -- python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline"
                    "   (+ a second pass with GRBM_GUI_ACTIVE GRBM_COUNT; tools/collect_profiles.sh)",
@@ -148,7 +137,7 @@ def dominant_traffic():
     cf, _, _ = counters("pmc_fetch")
     cw, _, _ = counters("pmc_write")
     f, w, npts = cf[(kern, "FETCH_SIZE")], cw[(kern, "WRITE_SIZE")], 1 << 20
-    json.dump({"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "kernel": kern, "source_sha16": kernel_source_sha16(ACC_SOURCES),
+    json.dump({"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "kernel": kern, "source_sha16": unit_sha16("msm_accumulate"),
                "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-include-regex msm_accumulate -- "
                           "python3 bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline   (tools/collect_profiles.sh)",
                "points_per_launch": npts, "hbm_bytes_per_launch": (f + w) * 1024, "hbm_bytes_per_point": (f + w) * 1024 / npts,
@@ -173,7 +162,7 @@ def ntt_traffic():
     write = sum(cw[(k, "WRITE_SIZE")] * nf[(k, "FETCH_SIZE")] for k in ks) * 1024
     ntr = last_json("pmc_ntt_fetch.log")["transforms"]  # what ntt_one.py ran under the profiler (warm-up included)
     assert ntr == last_json("pmc_ntt_write.log")["transforms"] and all(nf[(k, "FETCH_SIZE")] % ntr == 0 for k in ks), "launch counts do not match the transforms of the pass"
-    json.dump({"kernel": "ntt_pass", "source_sha16": kernel_source_sha16(NTT_SOURCES), "log_n": lg, "transforms_in_the_pass": ntr, "launches": {k: nf[(k, "FETCH_SIZE")] for k in ks},
+    json.dump({"kernel": "ntt_pass", "source_sha16": unit_sha16("ntt_pass"), "log_n": lg, "transforms_in_the_pass": ntr, "launches": {k: nf[(k, "FETCH_SIZE")] for k in ks},
                "hbm_bytes_per_transform": (fetch + write) / ntr, "hbm_bytes_per_element_per_transform": (fetch + write) / ntr / (1 << lg),
                "algorithmic_bytes_per_element": 64, "ms_per_transform_unprofiled": one["ms_per_transform"],
                "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-include-regex ntt_pass -- python3 tools/ubench/ntt_one.py 22 5",
@@ -195,7 +184,7 @@ def spmv_traffic():
     fetch_face = sum(v * nf[k] for k, v in cf.items()) * 1024
     write = sum(v * nw[k] for k, v in cw.items()) * 1024
     streamed = nmv * (32.0 * nnz + 4.0 * nnz + 4.0 * (rows_ + 1))   # val, col, rowptr: coalesced streams, counted at half
-    json.dump({"kernel": "spmv_rows_direct (+ spmv_row_stats)", "source_sha16": kernel_source_sha16(SPMV_SOURCES), "rows": rows_, "nnz": nnz, "matvecs_in_the_pass": nmv,
+    json.dump({"kernel": "spmv_rows_direct (+ spmv_row_stats)", "source_sha16": unit_sha16("spmv"), "rows": rows_, "nnz": nnz, "matvecs_in_the_pass": nmv,
                "FETCH_bytes_face_value_per_matvec": fetch_face / nmv, "WRITE_bytes_per_matvec": write / nmv,
                "hbm_bytes_per_nnz": (fetch_face + streamed / 2 + write) / nmv / nnz,
                "hbm_bytes_per_nnz_face_value": (fetch_face + write) / nmv / nnz, "algorithmic_bytes_per_nnz": 68 + 36,
