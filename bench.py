@@ -154,6 +154,10 @@ def main():
                     help="prove workloads: `synthetic` = the 2^L-row a*b=c circuit of BASELINE configs[1-3] (default, the "
                          "headline); `merkle` = the Pedersen-hash Merkle-membership circuit of BASELINE configs[4] "
                          "(tree over 2^18 leaves, + the simpleworks UInt8 gadget block; --log-n is ignored)")
+    ap.add_argument("--r1cs", default=None, metavar="FILE",
+                    help="prove workloads: the constraint system of an SWMR1CS1 dump (simpleworks_amd/workloads.py; written on the "
+                         "Rust side by swmarlin_sys::r1cs_dump::dump_r1cs, INTEGRATION.md) instead of a built-in circuit — how the "
+                         "reference's own circuits, e.g. MerkleTreeVerificationU8 at height 19 (BASELINE configs[4]), are timed")
     ap.add_argument("--rng", default="builtin", choices=["builtin", "callback", "adopt"],
                     help="where the prover's randomness comes from in the TIMED loop: `builtin` = the library's ChaCha12 "
                          "(ark_std::test_rng's stream; the headline), `callback` = a caller-owned generator behind "
@@ -240,7 +244,14 @@ def main():
             from simpleworks_amd.dist import enable_sharded_prover
             enable_sharded_prover(ctx)
         rng = M.generate_rand()
-        if args.circuit == "merkle":
+        if args.r1cs:
+            cs, public = W.load_r1cs(args.r1cs)
+            n = cs.num_constraints
+            nvars = cs.instance.shape[0] + cs.witness.shape[0]
+            nnz = max(int(m[0][-1]) for m in cs.mats)
+            assert cs.is_satisfied(ctx), "bench: the assignment of %s does not satisfy its constraints" % args.r1cs
+            srs = M.generate_universal_srs(n, nvars, nnz, rng)
+        elif args.circuit == "merkle":
             # configs[4] for real: the tree over 2^18 u8 leaves is built first (MerkleTree::new,
             # src/merkle_tree/simple_merkle_tree.rs:47-49 — on the GPU, swm_merkle_tree_build), the proof is for one of its paths
             mparams = W.MerkleParams()
@@ -285,7 +296,10 @@ def main():
             last["proof"] = prove_with(args.rng)
         dominant, units, unit = "msm_accumulate", n, "constraints/s"
         alg_bytes = None
-        if args.circuit == "merkle":
+        if args.r1cs:
+            workload = ("marlin_prove: constraint system of the SWMR1CS1 dump %s: %d constraints, %d variables, max nnz %d, "
+                        "SRS + proving key device resident" % (os.path.basename(args.r1cs), n, nvars, nnz))
+        elif args.circuit == "merkle":
             workload = ("marlin_prove: Pedersen-hash Merkle-membership circuit (BASELINE configs[4] stand-in: tree height 19 = "
                         "2^18 leaves, 256-bit digests, + 2400 simpleworks UInt8 gadget ops): %d constraints, %d variables, "
                         "max nnz %d (|H| = 2^17, |K| = 2^18), SRS + proving key device resident; the path is one of a real tree over "
@@ -384,7 +398,7 @@ def main():
         if args.sharded_log_n:
             sizes = [int(x) for x in args.sharded_log_n.split(",") if x]
         else:
-            sizes = [args.log_n] + ([22] if args.circuit == "synthetic" and args.log_n == 20 and world > 1 else [])
+            sizes = [args.log_n] + ([22] if args.circuit == "synthetic" and not args.r1cs and args.log_n == 20 and world > 1 else [])
         state = {"comm": False}
 
         def run_sharded(lg_s, box):
@@ -398,7 +412,12 @@ def main():
                     ctx.rccl_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
                     state["comm"] = True
                 rng_s = M.generate_rand()
-                if args.circuit == "merkle":
+                if args.r1cs:
+                    scs, pub_s = W.load_r1cs(args.r1cs)
+                    ns = scs.num_constraints
+                    srs_s = M.generate_universal_srs(ns, scs.instance.shape[0] + scs.witness.shape[0],
+                                                     max(int(m[0][-1]) for m in scs.mats), rng_s)
+                elif args.circuit == "merkle":
                     mcs_s, pub_s, _ = W.merkle_membership_circuit(leaf_u8=0xA7)
                     scs = mcs_s.pack()
                     ns = scs.num_constraints

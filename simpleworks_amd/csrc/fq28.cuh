@@ -539,6 +539,35 @@ __device__ __forceinline__ void te28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, con
     dst->y = fq28_pack(M::mul(G, H));
     dst->zzz = fq28_pack(M::mul(F, G));
 }
+// te28_slot_add for steps in which a lane reads ANOTHER lane's slot that the same step rewrites (the in-place suffix scan of
+// msm_bucket_reduce_low): every load of the workgroup precedes a barrier, every store follows it.  `act` = the lane takes part;
+// all lanes of the workgroup must reach the call with the same `barrier`.  Same products, same limbs as te28_slot_add.
+template <class M = MulAsm>
+__device__ __forceinline__ void te28_slot_add_sync(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, bool act, bool barrier = true) {
+    Fq28 E, F, G, H;
+#pragma unroll
+    for (int i = 0; i < 14; i++) E.l[i] = F.l[i] = G.l[i] = H.l[i] = 0;
+    if (act) {
+        Fq28 A, B;
+        {
+            Fq28 ax = fq28_unpack(pa->x), ay = fq28_unpack(pa->y), qx = fq28_unpack(pq->x), qy = fq28_unpack(pq->y);
+            A = M::mul(FQ28_SUB(ay, ax, SPREAD4), FQ28_SUB(qy, qx, SPREAD4));
+            B = M::mul(fq28_add(ay, ax), fq28_add(qy, qx));
+        }
+        Fq28 C = M::mul(M::mul(fq28_unpack(pa->zz), fq28_unpack(pq->zz)), fq28_const(Fq28TeConsts::K2D));
+        Fq28 D = M::mul(fq28_unpack(pa->zzz), fq28_unpack(pq->zzz));
+        D = fq28_add(D, D);
+        E = FQ28_SUB(B, A, SPREAD4), H = fq28_add(B, A);
+        F = FQ28_SUB(D, C, SPREAD4), G = fq28_add(D, C);
+    }
+    if (barrier) __syncthreads();  // (uniform over the workgroup; false for steps in which every lane works on slots of its own)
+    if (act) {
+        dst->x = fq28_pack(M::mul(E, F));
+        dst->zz = fq28_pack(M::mul(E, H));
+        dst->y = fq28_pack(M::mul(G, H));
+        dst->zzz = fq28_pack(M::mul(F, G));
+    }
+}
 // The same addition by FOUR lanes (a quad of one wave; `q` = the lane's index in it): the nine multiplications of
 // te28_slot_add as three rounds of one product per lane — (A, B, T1 T2, Z1 Z2), then 2d (T1 T2) on lane 2, then (X3, Y3, T3,
 // Z3) — with the four intermediate values passed around the quad by DPP moves and every lane storing one coordinate of the

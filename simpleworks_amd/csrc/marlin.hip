@@ -497,8 +497,13 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // 2^16 17.4 -> 14.7 ms.  Per-window schedule (no table): a single stage fills the chip from ~2^15 points, a joint
     // launch only queues them behind one another (2^16: 16.5 -> 20.3 ms) — those keep their own tail, as do large MSMs,
     // whose tail overlaps the next commitment's accumulation.
+    // r05: with the low-LDS bucket stage (msm_bucket_reduce_low: two workgroups per CU) the joint launch pays up to 10^6 points —
+    // the commitments of proofs up to 2^18 constraints and of the Merkle circuit of BASELINE config #5: the stages of a round's
+    // jobs (128 workgroups each, 16 buckets per lane) are resident together and run at the chip's issue rate, where one stage
+    // after the other ran at one wave per SIMD (2^18: 19.5 -> 17.3 ms, Merkle circuit 17.0 -> 15.2 ms; profiles/r05_*).
     static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
-    const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? 200000 : 32768);
+    static const bool low_on = !(getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) == 0);
+    const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? (tab.te && low_on ? 1000000 : 200000) : 32768);
     if (tab.scalar_stride != 1) {
         rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, coeffs + first, count, 1, &out->job, MsmInfMask(),
                                   (long)count <= batch_below, tab));

@@ -83,6 +83,8 @@ struct MsmJob {
     WinLayout pl;
     unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
     bool quad = false;  // bucket stage with four lanes per chain (small twisted Edwards jobs)
+    bool low = false;   // bucket stage by msm_bucket_reduce_low (one LDS slot per lane, weighted sums in d_acc)
+    unsigned max_blocks = 256;  // most workgroups per window a later re-shaping of the stage may ask for (result slot, d_acc)
     unsigned red_blocks = 0, log_m = 0, rb = 256;  // bucket stage: workgroups per window, log2 buckets per lane, lanes per workgroup
     unsigned blk_lo = 0, blk_hi = 0, blk_low = 0;  // workgroups [blk_lo, blk_hi) and [0, blk_low) hold buckets of this rank (bucket-range split); the others emit the identity
     bool te = false;         // partial sums and workgroup results are twisted Edwards points (the host fold converts the total)
@@ -92,7 +94,7 @@ struct MsmJob {
     bool needs_acc_wait = false;
     hipStream_t stream = nullptr;
     hipEvent_t acc_done = nullptr;
-    G1XYZZ *d_partial = nullptr, *d_wpart = nullptr;
+    G1XYZZ *d_partial = nullptr, *d_wpart = nullptr, *d_acc = nullptr;
     const uint32_t *d_seg_off = nullptr, *d_hist = nullptr, *d_status = nullptr, *d_entries = nullptr;
     uint32_t seg = 0;  // segment bound of the accumulation: bucket b owns the partial sums d_seg_off[b] .. + ceil(d_hist[b] / seg)
     G1XYZZ* host = nullptr;  // pinned slot receiving nwin * red_blocks (A, R) pairs

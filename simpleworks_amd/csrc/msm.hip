@@ -1434,6 +1434,7 @@ struct TailJob {
     const uint32_t *seg_off, *hist;  // first segment and entry count of every bucket: its segments are seg_off[b] .. + ceil(hist[b] / seg)
     uint32_t seg;
     G1XYZZ* out;
+    G1XYZZ* acc;  // msm_bucket_reduce_low: the weighted sums of the lanes, one slot per lane in HBM / L2 (red_blocks x RB per window)
     unsigned log_m, red_blocks, big_nseg;
     unsigned blk_lo, blk_hi, blk_low;   // workgroups of this rank's bucket share (MsmJob); the others only emit the identity
     const uint32_t *status, *entries;  // device status words of the job, forwarded to ...
@@ -1592,6 +1593,151 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
             job.host_flags[0] = job.status[0];
             job.host_flags[1] = *job.entries;
             job.host_flags[2] = job.status[1];  // points with a zero scalar / identity base
+        }
+    }
+}
+
+// The bucket stage of twisted Edwards jobs with a THIRD of the LDS (r05).  msm_bucket_reduce keeps three slots per lane in LDS
+// (running sum twice — the scan goes from one copy to the other — and the weighted sum): 144 KB per 256-lane workgroup, i.e.
+// ONE workgroup per CU and one wave per SIMD, where a lone wave issues an instruction every ~5.5 cycles (SQ utilisation 0.62,
+// profiles/r04_pmc_sq_msm_bucket_reduce_and_sort.json) and nothing else that wants LDS fits beside it.  Here
+//   * the running sum is ONE slot per lane: the suffix scan works in place, every lane's loads ahead of a barrier and its
+//     stores behind it (te28_slot_add_sync) — the unified law reads all eight input coordinates before it writes any;
+//   * the weighted sum of a lane lives in HBM / L2 (job.acc: touched once per bucket, 384 B per step against ~4 400
+//     instructions) and moves into the lane's LDS slot with the step that folds the suffix into it; the tree runs there;
+// (256 + 1) x 192 B = 49 KB per workgroup: three workgroups per CU, three waves per SIMD (156 VGPRs) — the issue port is kept
+// busy by the other workgroups' chains, and a stage no longer owns its CU.  Same micro-operations in the same order per lane as
+// msm_bucket_reduce<RB, FormTE>: the same limbs, the same workgroup results.
+#ifndef SWM_LOW_WAVES
+#define SWM_LOW_WAVES 2  // waves per SIMD the register budget allows (3: 168 VGPRs, spills 37 of them)
+#endif
+template <int RB>
+__global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailBatch batch) {
+    const TailJob& job = batch.j[blockIdx.z];
+    if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
+    const G1XYZZ* __restrict__ partial = job.partial;
+    const uint32_t* __restrict__ seg_off = job.seg_off;
+    const WinLayout& L = job.L;
+    const unsigned log_m = job.log_m;
+    G1XYZZ* __restrict__ out = job.out;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);  // RB + 1 slots
+    G1XYZZ* sm_tree = sm_run + 1;
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    if (!((blockIdx.x >= job.blk_lo && blockIdx.x < job.blk_hi) || blockIdx.x < job.blk_low)) {
+        if (t == 0) {
+            te28_store_identity(sm_run[0]);
+            size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
+            te28_store_384(out[o], sm_run[0]);
+            te28_store_384(out[o + 1], sm_run[0]);
+            if (blockIdx.x == 0 && w == 0 && job.host_flags) {
+                job.host_flags[0] = job.status[0];
+                job.host_flags[1] = *job.entries;
+                job.host_flags[2] = job.status[1];
+            }
+        }
+        return;
+    }
+    G1XYZZ* __restrict__ my_acc = job.acc + ((size_t)w * job.red_blocks + blockIdx.x) * RB + t;
+    const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
+    const uint32_t lo = (blockIdx.x * RB + t) << log_m;
+    const uint32_t base = L.boff[w];
+    te28_store_identity(sm_run[t]);
+    if (t == 0) te28_store_identity(sm_run[RB]);
+    te28_store_identity(*my_acc);
+    uint32_t b = min(lo + m, B), s = 0, e = 0;
+    bool walking = lo < B;
+    if (walking) {
+        b--;
+        s = seg_off[base + b];
+        e = s + nseg_of(job.hist[base + b], job.seg);
+        if (e - s > job.big_nseg) e = s + 1;  // already folded into the first partial
+    }
+    enum { WALK = 0, SCAN = 1, SHIFT = 2, FOLD = 3, TREE = 4 };
+    int phase = WALK;
+    uint32_t d = 1;
+    __syncthreads();
+#pragma unroll 1
+    for (;;) {
+        G1XYZZ* dst = &sm_run[t];
+        const G1XYZZ* pa = &sm_run[t];
+        const G1XYZZ* pq = &sm_run[t];
+        bool act = false;
+        if (phase == WALK) {
+            if (!__syncthreads_or(walking)) {
+                phase = SCAN;
+                continue;
+            }
+            if (walking) {
+                act = true;
+                if (s < e) {
+                    pq = &partial[s++];
+                } else {  // acc += run
+                    dst = my_acc;
+                    pa = my_acc;
+                    if (b == lo) {
+                        walking = false;
+                    } else {
+                        b--;
+                        s = seg_off[base + b];
+                        e = s + nseg_of(job.hist[base + b], job.seg);
+                        if (e - s > job.big_nseg) e = s + 1;
+                    }
+                }
+            }
+        } else if (phase == SCAN) {  // inclusive suffix scan of run over the workgroup (Hillis-Steele), IN PLACE
+            if (d >= RB) {
+                phase = SHIFT;
+                continue;
+            }
+            act = t + d < RB;
+            if (act) pq = &sm_run[t + d];
+            d <<= 1;
+        } else if (phase == SHIFT) {  // slot_t <- m Suffix_t for t >= 1, in place; slot 0 keeps R_blk = Suffix_0 (m Suffix_0 is never needed)
+#pragma unroll 1
+            for (unsigned i = 0; i < log_m; i++) te28_slot_add_sync(&sm_run[t], &sm_run[t], &sm_run[t], t >= 1, false);
+            __syncthreads();  // the fold reads the NEIGHBOUR's doubled slot
+            phase = FOLD;
+            continue;
+        } else if (phase == FOLD) {
+            // slot_{t+1} <- acc_t + m Suffix_{t+1}: lane t reads and rewrites slot t + 1 alone (slot RB holds the identity for the
+            // last lane), the weighted sums move into LDS, slot 0 is left alone; summed over t this is A_blk
+            dst = &sm_run[t + 1];
+            pa = my_acc;
+            pq = &sm_run[t + 1];
+            act = true;
+            phase = TREE;
+            d = RB / 2;
+        } else {  // tree over the slots 1 .. RB
+            if (d == 0) break;
+            if (d <= RB / 4) {  // narrow tree steps: four lanes per sum (te28_quad_add)
+                const uint32_t c = threadIdx.x >> 2;
+                if (c < d) te28_quad_add(&sm_tree[c], &sm_tree[c], &sm_tree[c + d], threadIdx.x & 3u);
+                __syncthreads();
+                d >>= 1;
+                continue;
+            }
+            dst = &sm_tree[t];
+            pa = &sm_tree[t];
+            act = t < d;
+            if (act) pq = &sm_tree[t + d];
+            d >>= 1;
+        }
+        // barriers: the in-place scan needs its loads ahead of one and its stores behind it; a tree step and the fold are read by
+        // other lanes in the NEXT step (trailing barrier); a walk step touches the lane's own slots only (the vote at the top
+        // of the loop is the workgroup's only meeting point there)
+        const bool walk = phase == WALK;
+        te28_slot_add_sync(dst, pa, pq, act, phase == SCAN);
+        if (!walk) __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
+        te28_store_384(out[o], sm_tree[0]);
+        te28_store_384(out[o + 1], sm_run[0]);
+        if (blockIdx.x == 0 && w == 0 && job.host_flags) {
+            job.host_flags[0] = job.status[0];
+            job.host_flags[1] = *job.entries;
+            job.host_flags[2] = job.status[1];
         }
     }
 }
@@ -1918,8 +2064,21 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const bool quad = lat && te && quad_on && flat_rb != 64 && pl.maxB <= quad_maxb;
     const unsigned rb = quad ? (quad_rb == 256 ? 256u : (quad_rb == 128 ? 128u : 64u)) : (flat ? (flat_rb == 64 ? 64u : 256u) : 256u);
     job->quad = quad;
+    // One-lane twisted Edwards stages take the low-LDS kernel (msm_bucket_reduce_low: 49 KB per workgroup, three per CU);
+    // SWM_MSM_LOW=0: the 144-KB kernel of r02 - r04.  SWM_MSM_LOW_BLOCKS: workgroups a stage may be cut into (result slot:
+    // up to 1024 (A, R) pairs; the host folds them in groups of 16).
+    static const bool low_on = !(getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) == 0);
+    static const unsigned low_blocks = getenv("SWM_MSM_LOW_BLOCKS") ? (unsigned)std::min(1024, std::max(16, atoi(getenv("SWM_MSM_LOW_BLOCKS")))) : 256u;
+    // (joint stages of small jobs: SWM_MSM_JOINT_BLOCKS workgroups per job — with the low-LDS kernel twelve waves per CU are resident)
+    // 64 per job in the low-latency schedule (r02), 128 for the larger jobs that join a round's launch since r05 (n >= 2^18 points:
+    // 2^19 buckets -> 16 per lane; four jobs = 512 workgroups = two per CU)
+    static const unsigned joint_env = getenv("SWM_MSM_JOINT_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_JOINT_BLOCKS"))) : 0u;
+    const unsigned joint_blocks = joint_env ? joint_env : (lat ? 64u : 128u);
+    const bool low = te && !quad && rb == 256 && low_on;
+    job->low = low;
     // (low-latency schedule: the bucket stages of a round's four MSMs run in one launch and have to be resident together)
-    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (lat && defer_tail ? 64u : 256u)) : 16u);
+    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (defer_tail && (lat || low) ? joint_blocks : (low ? low_blocks : 256u))) : 16u);
+    job->max_blocks = low ? std::max(max_blocks, low_blocks) : std::max(max_blocks, 256u);
     while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
     if (red_blocks == 0) red_blocks = 1;
@@ -2028,7 +2187,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     hipStream_t st = st_sort;
     const size_t slot_bytes = (size_t)MAX_WIN * 32 * sizeof(G1XYZZ) + 64;  // up to 1024 (A, R) pairs + status words
     const size_t flags_off = slot_bytes - 16;  // the last 16 bytes of a slot carry the status words of the job
-    if ((size_t)rl.nwin * red_blocks * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
+    if ((size_t)rl.nwin * std::max(red_blocks, flat ? job->max_blocks : 0u) * 2 * sizeof(G1XYZZ) > flags_off) return set_err(ctx, SWM_ERR_INTERNAL, "msm: result slot too small");
     if (!ctx->pinned) {  // coherent + mapped: the bucket stage writes its results straight into the slots
         SWM_HIP(ctx, hipHostMalloc(&ctx->pinned, slot_bytes * swm_ctx::MSM_SLOTS, hipHostMallocCoherent | hipHostMallocMapped));
         SWM_HIP(ctx, hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0));
@@ -2209,8 +2368,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_TRY(scratch(ctx, nm[7], (size_t)pl.NB * 4, (void**)&big_list));
     // XYZZ scratch: partial[nseg_max] | wpart[nwin * red_blocks * 2]
     G1XYZZ *partial, *wpart;
-    SWM_TRY(scratch(ctx, nm[8], (nseg_max + (size_t)rl.nwin * red_blocks * 2) * sizeof(G1XYZZ), (void**)&partial));
+    const size_t wpart_n = (size_t)rl.nwin * std::max(red_blocks, flat ? job->max_blocks : 0u) * 2;
+    SWM_TRY(scratch(ctx, nm[8], (nseg_max + wpart_n) * sizeof(G1XYZZ), (void**)&partial));
     wpart = partial + nseg_max;
+    job->d_acc = nullptr;
+    if (low) {  // the lanes' weighted sums of the low-LDS bucket stage: one point per lane, per result slot like `partial`
+        char nma[32];
+        snprintf(nma, sizeof(nma), "msmS%d.acc", slot);
+        SWM_TRY(scratch(ctx, nma, (size_t)rl.nwin * job->max_blocks * 256 * sizeof(G1XYZZ), (void**)&job->d_acc));
+    }
 
     SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
@@ -2366,8 +2532,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
 // a prover round —, THIN (m = 32) when another job follows.  The job's result slot takes up to 256 workgroup results either way.
 static void msm_tail_shape(MsmJob* j, bool wide) {
     static const unsigned thin_log_m = getenv("SWM_MSM_LOGM_THIN") ? (unsigned)std::min(8, std::max(2, atoi(getenv("SWM_MSM_LOGM_THIN")))) : 5u;
-    unsigned log_m = wide ? 2u : thin_log_m;
-    while (((j->pl.maxB >> log_m) + j->rb - 1) / j->rb > 256u) log_m++;
+    // (SWM_MSM_LOGM_WIDE: log2 buckets per lane of the wide shape before the workgroup cap applies — 2; the cap is the job's
+    // max_blocks: 256, or SWM_MSM_LOW_BLOCKS with the low-LDS kernel)
+    static const unsigned wide_log_m = getenv("SWM_MSM_LOGM_WIDE") ? (unsigned)std::min(8, std::max(0, atoi(getenv("SWM_MSM_LOGM_WIDE")))) : 2u;
+    unsigned log_m = wide ? wide_log_m : thin_log_m;
+    while (((j->pl.maxB >> log_m) + j->rb - 1) / j->rb > j->max_blocks) log_m++;
     j->log_m = log_m;
     j->red_blocks = std::max(1u, ((j->pl.maxB >> log_m) + j->rb - 1) / j->rb);
     j->blk_hi = j->red_blocks;  // (no bucket-range share on this path: blk_lo = 0, blk_low = 0)
@@ -2402,6 +2571,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         batch.j[i].hist = j->d_hist;
         batch.j[i].seg = j->seg;
         batch.j[i].out = j->zero_copy ? j->host_dev : j->d_wpart;
+        batch.j[i].acc = j->d_acc;
         batch.j[i].status = j->d_status;
         batch.j[i].entries = j->d_entries;
         batch.j[i].host_flags = j->zero_copy ? j->host_flags_dev : nullptr;
@@ -2435,6 +2605,9 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         else
             SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormXYZZ>), dim3(max_red, max_win, (unsigned)k), dim3(64),
                        (3 * 64 + 1) * sizeof(G1XYZZ), batch);
+    } else if (te && jobs[0]->low) {
+        SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce_low<256>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
+                   (RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
     } else if (te) {
         SWM_TRY(allow_big_lds(ctx, 7, (const void*)msm_bucket_reduce<256, FormTE>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
         SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
@@ -2468,7 +2641,7 @@ int msm_flush_tails(swm_ctx* ctx) {
     for (size_t i = 0; i < jobs.size();) {  // one launch per run of up to TAIL_MAX jobs of the same workgroup width
         size_t k = 1;
         while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb && jobs[i + k]->te == jobs[i]->te &&
-               jobs[i + k]->quad == jobs[i]->quad)
+               jobs[i + k]->quad == jobs[i]->quad && jobs[i + k]->low == jobs[i]->low)
             k++;
         SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)k));
         i += k;

@@ -10,7 +10,7 @@ synthetic_r1cs              configs #2-#4: the ark-marlin test/bench circuit sha
 """
 import numpy as np
 
-from .marlin import ConstraintSystem, PackedR1cs, R_MODULUS, _to_mont_limbs
+from .marlin import ConstraintSystem, PackedR1cs, R_MODULUS, _MONT_R, _to_mont_limbs
 
 
 def manual_constraints_circuit(a, b):
@@ -132,6 +132,100 @@ def synthetic_r1cs(n, a, b):
 
     packed = PackedR1cs(instance, witness, mat(col_a, col_c), mat(col_b, col_b), mat(col_c, col_d))
     return packed, [c, d]
+
+
+# ------------------------------------------------------------------------------------------------ R1CS dump ("SWMR1CS1")
+# A synthesised constraint system as ONE flat little-endian file: what a Rust-side caller writes with
+# swmarlin_sys::r1cs_dump::dump_r1cs(&cs, path) after `cs.finalize()` (ark-relations' `to_matrices` + the two assignment
+# vectors), and what `load_r1cs` / `bench.py --r1cs FILE` read back — the way the reference's REAL circuits (e.g.
+# MerkleTreeVerificationU8, /root/reference/src/merkle_tree/merkle_tree_verification_u8.rs:25-58, whose constraint layout
+# comes out of ark-r1cs-std and cannot be reproduced here) reach this library without a Rust toolchain on the GPU box.
+#   0   8  magic "SWMR1CS1"
+#   8   8  num_instance   (instance assignment, the leading one included)          u64
+#  16   8  num_witness                                                              u64
+#  24   8  num_constraints                                                          u64
+#  32  24  nnz of A, B, C                                                           3 x u64
+#  56   8  flags: bit 0 = field elements are Montgomery limbs (R = 2^256; always set)
+#  64      instance  num_instance x 32 B | witness  num_witness x 32 B
+#          per matrix A, B, C:  rowptr (num_constraints + 1) x u32 | col nnz x u32 (variable index: instance variables first,
+#          then witness variables — ark-relations' Matrix convention) | zero padding to a multiple of 8 | val nnz x 32 B
+#  end 32  BLAKE2s-256 of everything before it
+R1CS_MAGIC = b"SWMR1CS1"
+
+
+def dump_r1cs(packed, path):
+    """Writes PackedR1cs `packed` (or anything with .pack()) to `path` in the SWMR1CS1 layout; returns the byte count."""
+    import hashlib
+    packed = packed.pack()
+    head = np.array([packed.instance.shape[0], packed.witness.shape[0], packed.num_constraints] +
+                    [int(m[1].shape[0]) for m in packed.mats] + [1], dtype="<u8")
+    parts = [R1CS_MAGIC, head.tobytes(), packed.instance.astype("<u8").tobytes(), packed.witness.astype("<u8").tobytes()]
+    for rowptr, col, val in packed.mats:
+        idx = rowptr.astype("<u4").tobytes() + col.astype("<u4").tobytes()
+        parts += [idx, b"\0" * (-len(idx) % 8), val.astype("<u8").tobytes()]
+    body = b"".join(parts)
+    with open(path, "wb") as f:
+        f.write(body)
+        f.write(hashlib.blake2s(body).digest())
+    return len(body) + 32
+
+
+def pack_model_system(cs):
+    """A constraint system with .instance / .witness (ints) and .to_matrices() -> rows of (coefficient, column) — the oracle's
+    model, or anything shaped like ark-relations' ConstraintSystem after finalize — as a PackedR1cs."""
+    mats = []
+    for rows in cs.to_matrices():
+        rowptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+        col = np.array([c for r in rows for _, c in r], dtype=np.uint32)
+        mats.append((rowptr, col, _to_mont_limbs([v for r in rows for v, _ in r])))
+    return PackedR1cs(_to_mont_limbs(cs.instance), _to_mont_limbs(cs.witness), *mats)
+
+
+def load_r1cs(path):
+    """SWMR1CS1 file -> (PackedR1cs, public_inputs): the public inputs are the instance assignment without its leading one,
+    as ints in standard form (what verify_proof takes).  Every inconsistency of the file is a ValueError."""
+    import hashlib
+    data = open(path, "rb").read()
+    if len(data) < 64 + 32 or data[:8] != R1CS_MAGIC:
+        raise ValueError("not an SWMR1CS1 file")
+    if hashlib.blake2s(data[:-32]).digest() != data[-32:]:
+        raise ValueError("SWMR1CS1: checksum mismatch (truncated or corrupted file)")
+    ninst, nwit, nrows, na, nb, nc, flags = (int(x) for x in np.frombuffer(data, dtype="<u8", count=7, offset=8))
+    if flags != 1:
+        raise ValueError("SWMR1CS1: unknown flags %#x" % flags)
+    if ninst < 1 or max(ninst, nwit, nrows, na, nb, nc) >= 1 << 31:
+        raise ValueError("SWMR1CS1: implausible header")
+    want = 64 + 32 * (ninst + nwit) + sum(4 * (nrows + 1 + k) + (-4 * (nrows + 1 + k) % 8) + 32 * k for k in (na, nb, nc)) + 32
+    if want != len(data):
+        raise ValueError("SWMR1CS1: %d bytes, the header describes %d" % (len(data), want))
+    off = 64
+    instance = np.frombuffer(data, dtype="<u8", count=4 * ninst, offset=off).reshape(-1, 4)
+    off += 32 * ninst
+    witness = np.frombuffer(data, dtype="<u8", count=4 * nwit, offset=off).reshape(-1, 4)
+    off += 32 * nwit
+    mats = []
+    for k in (na, nb, nc):
+        rowptr = np.frombuffer(data, dtype="<u4", count=nrows + 1, offset=off)
+        col = np.frombuffer(data, dtype="<u4", count=k, offset=off + 4 * (nrows + 1))
+        off += 4 * (nrows + 1 + k) + (-4 * (nrows + 1 + k) % 8)
+        val = np.frombuffer(data, dtype="<u8", count=4 * k, offset=off).reshape(-1, 4)
+        off += 32 * k
+        if int(rowptr[0]) != 0 or int(rowptr[-1]) != k or (np.diff(rowptr.astype(np.int64)) < 0).any():
+            raise ValueError("SWMR1CS1: row pointers are not a monotone prefix of the non-zeros")
+        if k and int(col.max()) >= ninst + nwit:
+            raise ValueError("SWMR1CS1: column index beyond the variables")
+        mats.append((rowptr, col, val))
+    mont_r_inv = pow(_MONT_R, -1, R_MODULUS)
+
+    def std(limbs):  # Montgomery limbs -> int in standard form; a non-canonical residue is refused
+        v = sum(int(limbs[i]) << (64 * i) for i in range(4))
+        if v >= R_MODULUS:
+            raise ValueError("SWMR1CS1: field element out of range")
+        return v * mont_r_inv % R_MODULUS
+    if std(instance[0]) != 1:
+        raise ValueError("SWMR1CS1: the instance assignment does not start with one")
+    public = [std(instance[i]) for i in range(1, ninst)]
+    return PackedR1cs(instance, witness, *mats), public
 
 
 # ===================================================================================================================

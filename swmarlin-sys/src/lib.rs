@@ -21,3 +21,5 @@ pub mod marlin;
 pub mod merkle;
 #[cfg(not(feature = "pin"))]
 mod convert;
+/// SWMR1CS1 dumps of synthesised constraint systems (`dump_r1cs(&cs, path)`): arkworks only, available with and without `pin`
+pub mod r1cs_dump;

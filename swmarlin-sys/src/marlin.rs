@@ -4,7 +4,8 @@
 //!
 //! How arkworks values cross the boundary
 //! * `&mut StdRng`         -> through `swm_rng_from_callback` over a `fill_bytes` trampoline (the caller's stream, word for
-//!                            word, at the caller's speed: 95 instead of 58 ms per 2^20 proof); with the cargo feature
+//!                            word, at the caller's speed: r04 measured 88 ms per 2^20 proof against the 51-ms headline, which
+//!                            is the built-in generator — see `drop_in_rng` in the bench line); with the cargo feature
 //!                            `adopt-std-rng` by STATE — `swm_rng_from_chacha(seed, word position)`, position written back
 //!                            afterwards: the library then produces the ChaCha12 stream itself (on the GPU for the 3|H| mask
 //!                            coefficients).  Opt-in because it views the StdRng through a layout rand does not guarantee.

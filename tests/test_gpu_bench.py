@@ -56,3 +56,24 @@ def test_bench_two_ranks_through_the_drivers_launcher():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert abs(line["value"] - 2 * (1 << 14) / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]   # whole-job units / max-over-ranks time
     assert line["sharded"] is None
+
+
+@pytest.mark.gpu
+def test_bench_times_an_r1cs_dump(tmp_path):
+    """`bench.py --r1cs FILE`: the constraint system of an SWMR1CS1 dump (how the reference's own circuits — MerkleTreeVerificationU8 as
+    ark-r1cs-std lays it out — are timed on a box without Rust) through the whole bench path: load, is_satisfied, SRS, index, proofs,
+    verification of the last proof; the line names the file."""
+    sys.path.insert(0, ROOT)
+    from simpleworks_amd import workloads as W
+    cs, _, _ = W.merkle_membership_circuit(height=4, gadget_byte_ops=16)
+    path = str(tmp_path / "merkle_h4.r1cs")
+    W.dump_r1cs(cs, path)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--r1cs", path, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-drop-in"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "merkle_h4.r1cs" in line["config"]["workload"] and line["config"]["per_gpu_units"] == cs.pack().num_constraints
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0

@@ -73,3 +73,55 @@ def test_merkle_full_shape():
         def ev(lc):
             return sum(c * (cs_.instance[k] if kind == "i" else cs_.witness[k]) for c, (kind, k) in lc) % R_MODULUS
         assert all(ev(a) * ev(b) % R_MODULUS == ev(c) for a, b, c in zip(*cs_.rows))
+
+
+# ---- SWMR1CS1: the flat dump a Rust-side caller writes (swmarlin_sys::r1cs_dump) and `bench.py --r1cs` reads
+def test_r1cs_dump_round_trip_and_rejections(tmp_path):
+    import numpy as np
+    import pytest
+    cs, public = W.synthetic_r1cs(1 << 12, 0x1234, 0x5678)
+    path = str(tmp_path / "synthetic_2p12.r1cs")
+    size = W.dump_r1cs(cs, path)
+    assert size == os.path.getsize(path)
+    back, public2 = W.load_r1cs(path)
+    assert public2 == [int(x) for x in public]
+    assert back.num_constraints == cs.num_constraints
+    assert np.array_equal(back.instance, cs.instance) and np.array_equal(back.witness, cs.witness)
+    for m0, m1 in zip(cs.mats, back.mats):
+        assert all(np.array_equal(x, y) for x, y in zip(m0, m1))
+    # a model constraint system with multi-term rows and |K| != |H| (the matrices as ark-relations' to_matrices returns them)
+    model = PM.random_sparse_circuit(seed=20261002)
+    packed = W.pack_model_system(model)
+    W.dump_r1cs(packed, path)
+    back, public2 = W.load_r1cs(path)
+    assert public2 == model.instance[1:]
+    for m0, m1 in zip(packed.mats, back.mats):
+        assert all(np.array_equal(x, y) for x, y in zip(m0, m1))
+    # every inconsistency is a ValueError, never a wrong system
+    data = bytearray(open(path, "rb").read())
+
+    def refuse(mutate):
+        d = bytearray(data)
+        mutate(d)
+        bad = str(tmp_path / "bad.r1cs")
+        with open(bad, "wb") as f:
+            f.write(d)
+        with pytest.raises(ValueError):
+            W.load_r1cs(bad)
+    refuse(lambda d: d.__setitem__(0, ord("X")))                       # magic
+    refuse(lambda d: d.__setitem__(100, d[100] ^ 1))                   # a flipped bit: checksum
+    refuse(lambda d: d.__delitem__(slice(len(d) - 40, len(d) - 32)))   # truncated body
+    refuse(lambda d: d.__delitem__(slice(64, len(d))))                 # header only
+
+    def resealed(mutate):   # a file whose checksum is right but whose content is not
+        import hashlib
+
+        def f(d):
+            del d[-32:]
+            mutate(d)
+            d += hashlib.blake2s(bytes(d)).digest()
+        return f
+    refuse(resealed(lambda d: d.__setitem__(slice(8, 16), (0).to_bytes(8, "little"))))              # no instance variable
+    refuse(resealed(lambda d: d.__setitem__(slice(32, 40), (1 << 40).to_bytes(8, "little"))))       # implausible nnz
+    refuse(resealed(lambda d: d.__setitem__(slice(64, 96), b"\xff" * 32)))                           # non-canonical field element
+    refuse(resealed(lambda d: d.__setitem__(slice(56, 64), (3).to_bytes(8, "little"))))              # unknown flags
