@@ -49,6 +49,7 @@ void drain_streams(swm_ctx* ctx) {
     ctx->pending_tails.clear();
     ctx->lazy_tail = nullptr;
     for (auto& e : ctx->set_acc_event) e = nullptr;
+    ctx->msm_since_wait = 0;
 }
 
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -381,7 +382,10 @@ void swm_destroy(swm_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    if (ctx->ext_pinned) free(ctx->ext_pinned);
+    if (ctx->ext_pinned) {
+        if (ctx->ext_registered) (void)hipHostUnregister(ctx->ext_pinned);
+        free(ctx->ext_pinned);
+    }
     for (auto e : ctx->ext_event)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

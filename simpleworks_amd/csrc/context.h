@@ -49,8 +49,8 @@ struct swm_ctx {
     size_t ntt_pass_table_bytes = 0;      // HBM held by the per-pass twiddle tables of the lazy transform (capped, ntt.hip)
     // asynchronous MSM lanes: auxiliary streams (the prover alternates between two of them), a fork event, pinned result slots with their completion events
     static constexpr int MSM_SLOTS = 8;
-    static constexpr int MSM_LANES = 4;
-    hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int MSM_LANES = 5;  // sort | accumulation 0 | accumulation 1 | bucket stage | second bucket-stage stream (SWM_MSM_TAILS=2)
+    hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipStream_t> spare_streams;  // never used: placeholders / rejected candidates of the hardware-queue placement (msm_enqueue)
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
@@ -101,7 +101,9 @@ struct swm_ctx {
     // bulk draws from a caller-owned generator (sample_fr_bulk): a ring of two host chunks filled through the callback
     // and sent up on a copy stream of its own, so that the transfers run beside whatever the context's stream is doing
     hipStream_t copy_stream = nullptr;
-    void* ext_pinned = nullptr;  // the ring's two host chunks (malloc'd: see sample_fr_bulk)
+    void* ext_pinned = nullptr;  // the ring's two host chunks (page-aligned host memory, registered with the runtime: see sample_fr_bulk)
+    bool ext_registered = false;
+    unsigned msm_since_wait = 0;  // MSM jobs enqueued since the last msm_finish*: 0 = nothing of this context is in flight
     hipEvent_t ext_event[3] = {nullptr, nullptr, nullptr};  // [0], [1]: chunk buffer free again; [2]: destination may be written
 };
 

@@ -12,6 +12,7 @@
 #include <atomic>
 #include "context.h"
 #include "ff.cuh"
+#include "fill.cuh"
 #include "host/chacha.h"
 #include "host/marlin_types.h"
 
@@ -83,7 +84,7 @@ struct DBuf {
         }
         p = nullptr;
     }
-    void zero() { hip_check(ctx, hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream), "memset"); }
+    void zero() { hip_check(ctx, zero_fill_async(p, n * sizeof(T), ctx->stream), "memset"); }
     void upload(const T* h, size_t count) {
         hip_check(ctx, hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream), "h2d");
         hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
@@ -107,13 +108,18 @@ inline DVec dv_copy_padded(swm_ctx* ctx, const Fr* src, size_t len, size_t n) {
     DVec v(ctx, n);
     if (len > n) len = n;
     if (len) hip_check(ctx, hipMemcpyAsync(v.p, src, len * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream), "d2d");
-    if (n > len) hip_check(ctx, hipMemsetAsync(v.p + len, 0, (n - len) * sizeof(Fr), ctx->stream), "memset");
+    if (n > len) hip_check(ctx, zero_fill_async(v.p + len, (n - len) * sizeof(Fr), ctx->stream), "memset");
     return v;
 }
+
+// first kernel of every proof when SWM_TRACE / SWM_PROOF_MARKS is set: the delimiter tools/trace_dump.py and trace_share.py cut a
+// kernel trace by (a proof with a caller-owned generator has no bulk-sampling kernel to go by)
+static __global__ void swm_proof_begin() {}
 
 // ------------------------------------------------------------------------------------------------ pointwise launcher
 template <class F>
 static __global__ void __launch_bounds__(256) ew_kernel(size_t n, F f) {
+    SWM_LIGHT_KERNEL();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) f(i);
 }
 template <class F>
@@ -163,6 +169,7 @@ inline DVec dv_ntt_from(swm_ctx* ctx, const Fr* src, size_t len, unsigned log_n,
 static constexpr int REC_T = 16;  // rows per lane: short chains, many lanes (the kernels are latency-bound)
 
 static __global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t m, Fr z, Fr* head, size_t nblk) {
+    SWM_LIGHT_KERNEL();
     // lane = (block of REC_T rows, column); rows = ceil(n / m)
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nblk * m) return;
@@ -179,6 +186,7 @@ static __global__ void __launch_bounds__(256) rec_local(Fr* a, size_t n, size_t 
     head[blk * m + col] = acc;
 }
 static __global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m, Fr z, const Fr* head, size_t nblk) {
+    SWM_LIGHT_KERNEL();
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nblk * m) return;
     size_t blk = t / m, col = t % m;
@@ -194,6 +202,7 @@ static __global__ void __launch_bounds__(256) rec_fix(Fr* a, size_t n, size_t m,
     }
 }
 static __global__ void rec_serial(Fr* a, size_t n, size_t m, Fr z) {
+    SWM_LIGHT_KERNEL();
     size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (col >= m) return;
     size_t rows = (n + m - 1) / m;
@@ -218,6 +227,7 @@ struct Pow256Args {
     Fr sq[8];
 };
 static __global__ void __launch_bounds__(256) pow256_kernel(Pow256Args a, Fr* __restrict__ out) {
+    SWM_LIGHT_KERNEL();
     const unsigned i = threadIdx.x;
     Fr r = fp_one<Fr>();
 #pragma unroll
@@ -243,6 +253,7 @@ struct RecConsts {
 static __global__ void __launch_bounds__(256) rec_tile_total(const Fr* __restrict__ a, size_t n, RecConsts rc,
                                                              const Fr* __restrict__ zlow /* z^0..z^255 */,
                                                              Fr* __restrict__ totals) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sm[256];
     const size_t base = (size_t)blockIdx.x * RT_TILE;
     const unsigned t = threadIdx.x;
@@ -264,6 +275,7 @@ static __global__ void __launch_bounds__(256) rec_tile_total(const Fr* __restric
 __device__ __forceinline__ unsigned rt_pad(unsigned i) { return i + i / RT_PER; }  // one 32-B pad slot per lane chunk
 static __global__ void __launch_bounds__(256) rec_tile_scan(Fr* __restrict__ a, size_t n, RecConsts rc,
                                                             const Fr* __restrict__ tile_true /* S_b */, size_t ntiles) {
+    SWM_LIGHT_KERNEL();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fr* tile = reinterpret_cast<Fr*>(smem_raw);      // RT_TILE + 256 padded slots
     Fr* hs = tile + RT_TILE + 256;                   // 257 heads
@@ -394,6 +406,7 @@ static constexpr int EVAL_PER = 16;
 static constexpr int EVAL_TILE = 256 * EVAL_PER;
 static __global__ void __launch_bounds__(256) eval_chunks(const Fr* __restrict__ c, size_t n, Fr x256, const Fr* __restrict__ xpow,
                                                           Fr* __restrict__ out) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sm[256];
     const size_t base = (size_t)blockIdx.x * EVAL_TILE;
     const unsigned t = threadIdx.x;
@@ -468,6 +481,7 @@ struct EvalBatch {
     Fr* out[EVAL_MANY];
 };
 static __global__ void __launch_bounds__(256) eval_chunks_many(EvalBatch b, Fr x256, const Fr* __restrict__ xpow) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sm[256];
     const Fr* __restrict__ c = b.c[blockIdx.y];
     const size_t n = b.n[blockIdx.y];
@@ -562,6 +576,7 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* sm) {
     return sm[tid];
 }
 static __global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* in, size_t n, uint32_t* tot) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t sm[SC_BLOCK];
     size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t a = 0;
@@ -570,6 +585,7 @@ static __global__ void __launch_bounds__(SC_BLOCK) scan_totals(const uint32_t* i
     if (threadIdx.x == SC_BLOCK - 1) tot[blockIdx.x] = inc;
 }
 static __global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint32_t ntiles) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t sm[SC_BLOCK];
     uint32_t per = (ntiles + SC_BLOCK - 1) / SC_BLOCK;
     uint32_t lo = threadIdx.x * per, hi = min(lo + per, ntiles);
@@ -585,6 +601,7 @@ static __global__ void __launch_bounds__(SC_BLOCK) scan_mid(uint32_t* tot, uint3
     if (threadIdx.x == SC_BLOCK - 1) tot[ntiles] = inc;
 }
 static __global__ void __launch_bounds__(SC_BLOCK) scan_final(const uint32_t* in, size_t n, const uint32_t* tot, uint32_t* out) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t sm[SC_BLOCK];
     size_t lo = (size_t)blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
     uint32_t a = 0;
@@ -616,6 +633,7 @@ struct ChaChaKey {
 };
 static __global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, int rounds, uint64_t pos, size_t m,
                                                          Fr* __restrict__ cand, uint32_t* __restrict__ flag) {
+    SWM_LIGHT_KERNEL();
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= m) return;
     uint64_t w0 = pos + 8 * j;
@@ -645,6 +663,7 @@ static __global__ void __launch_bounds__(256) sample_candidates(ChaChaKey key, i
 static __global__ void __launch_bounds__(256) sample_compact(const Fr* __restrict__ cand, const uint32_t* __restrict__ flag,
                                                       const uint32_t* __restrict__ rank, size_t m, size_t need,
                                                       Fr* __restrict__ out, uint32_t* __restrict__ last_idx) {
+    SWM_LIGHT_KERNEL();
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= m || !flag[j]) return;
     uint32_t r = rank[j];
@@ -655,6 +674,7 @@ static __global__ void __launch_bounds__(256) sample_compact(const Fr* __restric
 }
 // candidates uploaded as raw bytes (caller-owned generator): clear the top bits in place, flag the ones below r
 static __global__ void __launch_bounds__(256) sample_flag_raw(Fr* __restrict__ cand, size_t m, uint32_t* __restrict__ flag) {
+    SWM_LIGHT_KERNEL();
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= m) return;
     Fr r = cand[j];
@@ -670,11 +690,26 @@ static __global__ void __launch_bounds__(256) sample_flag_raw(Fr* __restrict__ c
     cand[j] = r;
     flag[j] = lt ? 1u : 0u;
 }
+// compaction of a run of the caller-owned draw: the run's accepted candidates go behind the *base accepted before it (a device
+// word: the host does not count the runs it knows cannot complete the draw), as long as they are among the first `need`
+static __global__ void __launch_bounds__(256) sample_compact_base(const Fr* __restrict__ cand, const uint32_t* __restrict__ flag,
+                                                           const uint32_t* __restrict__ rank, size_t m, size_t need,
+                                                           Fr* __restrict__ out, const uint32_t* __restrict__ base) {
+    SWM_LIGHT_KERNEL();
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= m || !flag[j]) return;
+    const size_t r = (size_t)*base + rank[j];
+    if (r < need) out[r] = cand[j];
+}
+static __global__ void sample_base_add(uint32_t* __restrict__ base, const uint32_t* __restrict__ run_total) { *base += *run_total; }
 // Draws `need` field elements from rng's stream into out[0..need) (device), advancing rng exactly as `need`
 // successive Fr::rand(rng) calls would.
 // Caller-owned generator (rng.ext): the candidates come from its fill_bytes in runs of at most EXT_CHUNK and never more than
 // the number still missing, so the stream stops right behind the candidate that completes the draw.  The host only COUNTS
-// the accepted candidates of a run (it has to know how many are still missing); the raw run goes up from a ring of
+// the accepted candidates of a run when the run could complete the draw (r05: as long as even a fully accepted run cannot, whole
+// runs go up uncounted — the GPU's scan keeps the running total in a device word the compaction reads its offset from — and
+// that word is read back when the bound gets close: each such phase covers 58 % of what is missing, so three or four read-backs
+// replace 90 % of the host's counting, ~4 ms of a 3 x 2^20 draw); the raw run goes up from a ring of
 // two host chunks on the context's copy stream and is flagged, scanned and compacted into place on the GPU (the kernels of the
 // built-in path), while the callback produces the next run: ~170 MB through the callback for 3 * 2^20 elements, i.e. as
 // fast as the caller's generator.  The call returns once the callback is done; the context's stream is made to wait for the
@@ -691,9 +726,17 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         if (!ctx->copy_stream) hip_check(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "copy stream");
         // (the chunks are ordinary cacheable host memory: a host ChaCha fills pinned memory at a fifth of the rate it fills
         // malloc'd memory on the bench host — 1.1 against 5.2 GB/s — and the runtime's staged copy of 8 MB is fast)
+        // r05: ... and REGISTERED with the runtime (hipHostRegister pins the pages where they are: still cacheable for the host's
+        // writes, but the copy engine reads them directly).  From unregistered memory hipMemcpyAsync is a synchronous staged copy:
+        // ~0.35 ms per 8-MB run in which the host neither draws nor returns — 7 ms of a 3 x 2^20 draw that no counter showed
+        // (round 1 took 50 ms with a 35-ms draw).  SWM_EXT_REGISTER=0: the unregistered ring.
         if (!ctx->ext_pinned) {
-            ctx->ext_pinned = malloc(2 * EXT_CHUNK * sizeof(Fr));
-            if (!ctx->ext_pinned) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
+            void* ring = nullptr;
+            if (posix_memalign(&ring, 4096, 2 * EXT_CHUNK * sizeof(Fr)) != 0 || !ring) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
+            ctx->ext_pinned = ring;
+            static const bool reg = !(getenv("SWM_EXT_REGISTER") && atoi(getenv("SWM_EXT_REGISTER")) == 0);
+            if (reg && hipHostRegister(ring, 2 * EXT_CHUNK * sizeof(Fr), hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError();  // (not fatal: staged copies)
+            else ctx->ext_registered = reg;
         }
         for (int i = 0; i < 2; i++)
             if (!ctx->ext_event[i]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[i], hipEventDisableTiming), "event");
@@ -701,68 +744,92 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         const unsigned ntiles = (unsigned)((EXT_CHUNK + SC_TILE - 1) / SC_TILE);
         const size_t slot_bytes = (EXT_CHUNK * (sizeof(Fr) + 8) + ((size_t)ntiles + 2) * 4 + 255) & ~(size_t)255;
         char* dev = nullptr;
-        if (scratch(ctx, "ext.ring", 2 * slot_bytes, (void**)&dev) != SWM_OK) throw MarlinError(SWM_ERR_OOM, "sample: device ring");
+        if (scratch(ctx, "ext.ring", 2 * slot_bytes + 256, (void**)&dev) != SWM_OK) throw MarlinError(SWM_ERR_OOM, "sample: device ring");
         if (!marked) sample_fr_ext_mark(ctx);  // no earlier mark: everything enqueued so far may still use the buffer
         hipStream_t cs = ctx->copy_stream;
         hip_check(ctx, hipStreamWaitEvent(cs, ctx->ext_event[2], 0), "wait");
-        size_t have = 0;
-        bool used[2] = {false, false};
+        // have: accepted candidates the host knows of exactly; unc: candidates uploaded since whose acceptance only the device knows
+        size_t have = 0, unc = 0;
+        uint32_t* d_base = reinterpret_cast<uint32_t*>(dev + 2 * slot_bytes);
+        hip_check(ctx, hipMemsetAsync(d_base, 0, 4, cs), "memset");
         static const bool trace = getenv("SWM_TRACE") != nullptr;
+        static const bool count_all = getenv("SWM_EXT_COUNT_ALL") != nullptr;  // (switch: the r02 - r04 behaviour, every run counted on the host)
         double t_cb = 0, t_count = 0, t_wait = 0;
+        int readbacks = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        for (int b = 0; have < need; b ^= 1) {
-            const size_t want = std::min(need - have, EXT_CHUNK);
+        for (int b = 0;; b ^= 1) {
+            // a whole run cannot complete the draw even if every candidate of it (and of the uncounted runs before it) is accepted
+            const bool blind = !count_all && have + unc + EXT_CHUNK <= need;
+            if (!blind && unc) {  // close to the end with uncounted runs behind us: ask the device how many it has accepted
+                auto t0 = now();
+                uint32_t h = 0;
+                hip_check(ctx, hipMemcpyAsync(&h, d_base, 4, hipMemcpyDeviceToHost, cs), "d2h");
+                hip_check(ctx, hipStreamSynchronize(cs), "sync");
+                t_wait += ms(t0, now());
+                have = h;
+                unc = 0;
+                readbacks++;
+                b ^= 1;  // (this trip drew nothing: keep the ring's alternation)
+                continue;
+            }
+            if (!blind && have >= need) break;
+            const size_t want = blind ? EXT_CHUNK : std::min(need - have, EXT_CHUNK);
             uint32_t* buf = reinterpret_cast<uint32_t*>((char*)ctx->ext_pinned + (size_t)b * EXT_CHUNK * sizeof(Fr));
             auto t0 = now();
-            if (used[b]) hip_check(ctx, hipEventSynchronize(ctx->ext_event[b]), "ring");
+            // (the first trips of a draw as well: with the ring registered the copies are asynchronous, and the last run of the
+            // PREVIOUS draw — the piece before this one, or the proof before — may still be reading the chunk)
+            hip_check(ctx, hipEventSynchronize(ctx->ext_event[b]), "ring");
             auto t1 = now();
             rng.ext(rng.ext_user, reinterpret_cast<uint8_t*>(buf), want * 32);
             auto t2 = now();
             t_wait += ms(t0, t1);
             t_cb += ms(t1, t2);
-            size_t acc = 0;
-            const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
-            for (size_t i = 0; i < want; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
-                const uint32_t* r = buf + 8 * i;  // in all but 2^-29 of the cases
-                const uint32_t t = r[7] & top_mask;
-                if (t != p7) {
-                    acc += t < p7;
-                } else {
-                    bool lt = false;
-                    for (int k = 6; k >= 0; k--) {
-                        if (r[k] < FrParams::P[k]) { lt = true; break; }
-                        if (r[k] > FrParams::P[k]) break;
+            if (blind) {
+                unc += want;
+            } else {
+                size_t acc = 0;
+                const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
+                for (size_t i = 0; i < want; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
+                    const uint32_t* r = buf + 8 * i;  // in all but 2^-29 of the cases
+                    const uint32_t t = r[7] & top_mask;
+                    if (t != p7) {
+                        acc += t < p7;
+                    } else {
+                        bool lt = false;
+                        for (int k = 6; k >= 0; k--) {
+                            if (r[k] < FrParams::P[k]) { lt = true; break; }
+                            if (r[k] > FrParams::P[k]) break;
+                        }
+                        acc += lt;
                     }
-                    acc += lt;
                 }
+                have += acc;
+                t_count += ms(t2, now());
             }
-            t_count += ms(t2, now());
             Fr* d_raw = reinterpret_cast<Fr*>(dev + (size_t)b * slot_bytes);
             uint32_t* d_flag = reinterpret_cast<uint32_t*>(d_raw + EXT_CHUNK);
             uint32_t* d_rank = d_flag + EXT_CHUNK;
             uint32_t* d_tot = d_rank + EXT_CHUNK;
             hip_check(ctx, hipMemcpyAsync(d_raw, buf, want * sizeof(Fr), hipMemcpyHostToDevice, cs), "h2d");
-            hip_check(ctx, hipEventRecord(ctx->ext_event[b], cs), "record");  // the pinned chunk may be refilled after the copy
-            used[b] = true;
+            hip_check(ctx, hipEventRecord(ctx->ext_event[b], cs), "record");  // the host chunk may be refilled after the copy
             const unsigned grid = (unsigned)((want + 255) / 256), nt = (unsigned)((want + SC_TILE - 1) / SC_TILE);
             hipLaunchKernelGGL(sample_flag_raw, dim3(grid), dim3(256), 0, cs, d_raw, want, d_flag);
             hipLaunchKernelGGL(scan_totals, dim3(nt), dim3(SC_BLOCK), 0, cs, (const uint32_t*)d_flag, want, d_tot);
             hipLaunchKernelGGL(scan_mid, dim3(1), dim3(SC_BLOCK), 0, cs, d_tot, nt);
             hipLaunchKernelGGL(scan_final, dim3(nt), dim3(SC_BLOCK), 0, cs, (const uint32_t*)d_flag, want, d_tot, d_rank);
-            if (acc)
-                hipLaunchKernelGGL(sample_compact, dim3(grid), dim3(256), 0, cs, (const Fr*)d_raw, (const uint32_t*)d_flag,
-                                   (const uint32_t*)d_rank, want, acc, out + have, d_tot + nt + 1);
+            hipLaunchKernelGGL(sample_compact_base, dim3(grid), dim3(256), 0, cs, (const Fr*)d_raw, (const uint32_t*)d_flag,
+                               (const uint32_t*)d_rank, want, need, out, (const uint32_t*)d_base);
+            hipLaunchKernelGGL(sample_base_add, dim3(1), dim3(1), 0, cs, d_base, (const uint32_t*)(d_tot + nt));  // the scan's total of the run
             hip_check(ctx, hipGetLastError(), "sample (caller-owned generator)");
-            have += acc;
         }
         hip_check(ctx, hipEventRecord(ctx->ext_event[2], cs), "record");
         hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ext_event[2], 0), "wait");
         if (trace)
             fprintf(stderr, "[swm trace]   bulk draw of %zu elements from the caller's generator: callback %.1f ms, counting %.1f ms, "
-                            "waiting for the ring %.1f ms\n", need, t_cb, t_count, t_wait);
+                            "waiting for the ring and %d read-backs %.1f ms\n", need, t_cb, t_count, readbacks, t_wait);
         // the device ring is reused by the next draw: its kernels are ordered behind these on the copy stream
         return;
     }

@@ -15,6 +15,31 @@
 #include <hip/hip_runtime.h>
 #include "constants_gen.h"
 
+// Issue priority of the "light" kernels — everything of a proof that is not the bucket accumulation or the bucket stage: sort
+// stages, transforms, mat-vecs, pointwise forms, recurrences.  An accumulation in flight keeps every SIMD's issue port busy with
+// three always-ready waves, and the arbiter serves the OLDEST ready wave first: a kernel launched beside it is resident but
+// starved (r05 timeline: msm_flat_coarse_hist 1.6 ms beside an accumulation, 30 us alone).  s_setprio raises a wave's priority in
+// that arbitration; the light kernels are mostly waiting for memory, so they take few issue cycles from the accumulation and
+// stop being the reason the next accumulation starts late.  Measured r05 (builds with -DSWM_LIGHT_PRIO=0 / 1 / 3, alternating on
+// one box): prove 2^20 50.4 -> 49.3 ms, "no accumulation in flight" 16.6 -> 12.7 ms of a profiled proof; 2^12 3.55 -> 3.39,
+// 2^16 7.9 -> 7.5, 2^18 17.5 -> 17.0 ms, Merkle circuit 15.1 -> 14.8 ms.  0 = off (the r01 - r04 behaviour).
+#ifndef SWM_LIGHT_PRIO
+#define SWM_LIGHT_PRIO 3
+#endif
+#define SWM_LIGHT_KERNEL()                                               \
+    do {                                                                 \
+        if (SWM_LIGHT_PRIO) __builtin_amdgcn_s_setprio(SWM_LIGHT_PRIO);  \
+    } while (0)
+// the bucket stage and the pre-fold of oversized buckets: VALU-bound chains that share the chip with the NEXT job's accumulation
+// (priority 1: above the accumulation, below the light kernels; 0 / 1 / 3 measured within 0.2 ms of one another at 2^20)
+#ifndef SWM_TAIL_PRIO
+#define SWM_TAIL_PRIO 1
+#endif
+#define SWM_TAIL_KERNEL()                                              \
+    do {                                                               \
+        if (SWM_TAIL_PRIO) __builtin_amdgcn_s_setprio(SWM_TAIL_PRIO);  \
+    } while (0)
+
 #define SWM_HD __host__ __device__ __forceinline__
 
 namespace swm {

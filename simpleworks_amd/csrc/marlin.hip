@@ -497,13 +497,13 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // 2^16 17.4 -> 14.7 ms.  Per-window schedule (no table): a single stage fills the chip from ~2^15 points, a joint
     // launch only queues them behind one another (2^16: 16.5 -> 20.3 ms) — those keep their own tail, as do large MSMs,
     // whose tail overlaps the next commitment's accumulation.
-    // r05: with the low-LDS bucket stage (msm_bucket_reduce_low: two workgroups per CU) the joint launch pays up to 10^6 points —
-    // the commitments of proofs up to 2^18 constraints and of the Merkle circuit of BASELINE config #5: the stages of a round's
-    // jobs (128 workgroups each, 16 buckets per lane) are resident together and run at the chip's issue rate, where one stage
-    // after the other ran at one wave per SIMD (2^18: 19.5 -> 17.3 ms, Merkle circuit 17.0 -> 15.2 ms; profiles/r05_*).
+    // r05: the joint launch pays up to 10^6 points — the commitments of proofs up to 2^18 constraints and of the Merkle circuit of
+    // BASELINE config #5.  At those sizes a proof IS its bucket stages (2^19 buckets per commitment, 3 - 13 entries per bucket:
+    // the stage of a job takes as long as its accumulation), and one stage after the other on the tail stream — each a full chip of
+    // lone waves — was the critical path; the stages of a round's jobs in ONE launch (64 workgroups each, 32 buckets per lane, all
+    // resident together) share one chain latency: 2^18: 19.3 -> 17.1 ms, Merkle circuit 17.5 -> 15.1 ms (profiles/r05_*).
     static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
-    static const bool low_on = !(getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) == 0);
-    const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? (tab.te && low_on ? 1000000 : 200000) : 32768);
+    const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? (tab.te ? 1000000 : 200000) : 32768);
     if (tab.scalar_stride != 1) {
         rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, coeffs + first, count, 1, &out->job, MsmInfMask(),
                                   (long)count <= batch_below, tab));
@@ -611,6 +611,10 @@ struct CommitJob {
     bool has_bound = false, hiding = false;
     bool blinded = false;  // pc_commit_blind has drawn the blinding polynomials and computed the hiding terms
     G1XYZZ blind_plain, blind_shifted;
+    // a commitment computed in pieces (the mask polynomial of a caller-owned generator, prove_impl): `plain` is the first piece,
+    // the rest has been summed into `extra`
+    bool has_extra = false;
+    G1XYZZ extra;
 };
 void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
                      bool hiding, CommitJob* job) {
@@ -667,6 +671,7 @@ void pc_commit_end_round(swm_ctx* ctx, const swm_pk& pk, std::initializer_list<C
     for (CommitJob* job : jobs) {
         if (!job->blinded) pc_commit_blind(pk, job, *rng, *pr);
         G1XYZZ plain = commit_wait(ctx, &job->plain);
+        if (job->has_extra) g1_add(plain, job->extra);
         if (job->hiding) g1_add(plain, job->blind_plain);
         pts.push_back(plain);
         where.push_back({idx, false});
@@ -1060,6 +1065,8 @@ void upload_small(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk) {
     PhaseTrace tr(ctx);
+    static const bool proof_marks = getenv("SWM_TRACE") != nullptr || getenv("SWM_PROOF_MARKS") != nullptr;
+    if (proof_marks) hipLaunchKernelGGL(swm_proof_begin, dim3(1), dim3(1), 0, ctx->stream);
     // padded shape (pad_input_for_indexer_and_prover + make_matrices_square); the witness itself is uploaded straight
     // from the caller's buffer, padding is filled on the device
     if (!cs || cs->num_instance == 0 || !cs->instance || (cs->num_witness && !cs->witness))
@@ -1131,15 +1138,47 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // untouched: nothing between here and there touches `zk` (rho_w, rho_a, rho_b were drawn above, the blinding
     // polynomials are drawn after the round's last commitment is enqueued, as before).
     const bool mask_late = zk.ext != nullptr;
+    // r05: with a caller-owned generator the commitment is computed IN PIECES — the MSM over the coefficients [1, |H|) is
+    // enqueued as soon as the first |H| coefficients are there and runs while the host draws the next |H|, and so on; what is
+    // exposed behind the draw is a third of the MSM instead of all of it.  Coefficient 0 is only known after the whole draw
+    // (mask_fix below): its term [c_0] g is one scalar multiplication on the host.  A commitment is a sum over coefficients, so
+    // the pieces add up to the same group element: same bytes (test_callback_rng_reproduces_golden_bytes).  SWM_MASK_PIECES=1:
+    // one piece (r02 - r04).  Sharded proofs keep one piece (their commitments are split over the ranks already).
+    static const unsigned mask_pieces_env = getenv("SWM_MASK_PIECES") ? (unsigned)std::min(3, std::max(1, atoi(getenv("SWM_MASK_PIECES")))) : 3u;
+    const unsigned mask_pieces = mask_late && ctx->shard_world <= 1 && commit_early && H >= 4096 ? mask_pieces_env : 1u;
+    AsyncMsm mask_part[2];
+    static const int mask_commit_env = getenv("SWM_MASK_COMMIT") ? std::min(2, std::max(0, atoi(getenv("SWM_MASK_COMMIT")))) : 0;
+    const int mask_commit_at = mask_late ? 0 : mask_commit_env;
     auto draw_mask = [&] {
-        sample_fr_bulk(ctx, zk, mask.p, mask_len, mask_late);
         Fr* mp = mask.p;
+        if (mask_pieces > 1) {
+            // thirds of |H| coefficients in stream order (the candidates are consumed exactly as by one draw of 3|H|: a draw stops
+            // right behind the candidate that completes it); three pieces: [1, H) | [H, 2H) | [2H, 3H), two: [1, H) | [H, 3H)
+            j1[3].has_bound = false;
+            j1[3].hiding = false;
+            sample_fr_bulk(ctx, zk, mp, H, mask_late);
+            commit_enqueue(ctx, &lane, pk, 1, mp + 1, H - 1, &j1[3].plain);
+            sample_fr_bulk(ctx, zk, mp + H, H, true);   // (marked: the destination is the buffer marked above, nothing else touches it)
+            if (mask_pieces == 3) commit_enqueue(ctx, &lane, pk, H, mp + H, H, &mask_part[0]);
+            sample_fr_bulk(ctx, zk, mp + 2 * H, H, true);
+            if (mask_pieces == 3) commit_enqueue(ctx, &lane, pk, 2 * H, mp + 2 * H, H, &mask_part[1]);
+            else commit_enqueue(ctx, &lane, pk, H, mp + H, 2 * H, &mask_part[0]);
+        } else {
+            sample_fr_bulk(ctx, zk, mask.p, mask_len, mask_late);
+        }
         ew(ctx, "mask_fix", 1, [=] __device__(size_t) {
             // remainder mod v_H at coefficient 0 = c[0] + c[H] + c[2H]; subtracting it from c[0] leaves -(c[H] + c[2H])
             mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
         });
         P_mask.p = mask.p; P_mask.n = mask_len;
-        begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+        if (mask_pieces == 1 && mask_commit_at == 0) begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+    };
+    // (experiment, built-in generator: the mask is sampled at the start either way — the draw fixes the generator's position for
+    // the blinding draws — but its 3|H|-point commitment can be enqueued behind w's (1) or behind z_B's (2) instead of first (0):
+    // an accumulation in flight starves the small kernels that prepare w, z_A and z_B)
+    auto commit_mask_at = [&](int where) {
+        if (!mask_late && mask_pieces == 1 && mask_commit_at == where && where != 0)
+            begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
     };
     if (mask_late) sample_fr_ext_mark(ctx);  // the transfers of the late draw only wait for what precedes the allocation
     else draw_mask();
@@ -1241,6 +1280,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const size_t w_len = H + 1 - X;
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
     begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0]);
+    commit_mask_at(1);
     DVec za_poly = dv_zeros(ctx, H + 1), zb_poly = dv_zeros(ctx, H + 1);
     // sharded form of "interpolate, add rho v_H, commit" for one of the two polynomials
     auto sharded_interpolate_and_commit = [&](DVec& loc, const Fr& rho, DVec& poly, CommitJob* job) {
@@ -1282,6 +1322,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
         begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
     }
+    commit_mask_at(2);
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
     if (!mask_late) flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
@@ -1333,6 +1374,14 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     pc_commit_blind(pk, &j1[1], &zk, &P_za.rand);
     pc_commit_blind(pk, &j1[2], &zk, &P_zb.rand);
     pc_commit_blind(pk, &j1[3], nullptr, &P_mask.rand);
+    if (mask_pieces > 1) {  // the other pieces of the mask commitment and the term of coefficient 0
+        Fr c0 = mask.download(0, 1)[0];
+        Fr c0s = fp_to_std(c0);
+        G1XYZZ extra = g1_mul_limbs(pk.vk.vk.g, c0s.v, 8);
+        for (unsigned k = 0; k + 1 < mask_pieces; k++) g1_add(extra, commit_wait(ctx, &mask_part[k]));
+        j1[3].has_extra = true;
+        j1[3].extra = extra;
+    }
     commit_gather(ctx, {&j1[0].plain, &j1[1].plain, &j1[2].plain, &j1[3].plain});
     pc_commit_end_round(ctx, pk, {&j1[0], &j1[1], &j1[2], &j1[3]}, {&zk, &zk, &zk, nullptr},
                         {&P_w.rand, &P_za.rand, &P_zb.rand, &P_mask.rand}, comms1.data());

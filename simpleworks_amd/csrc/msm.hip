@@ -28,6 +28,7 @@
 #include <string.h>
 #include <algorithm>
 #include "context.h"
+#include "fill.cuh"
 #include "fq28.cuh"
 #include "g1.cuh"
 #include "msm.h"
@@ -149,6 +150,7 @@ __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars
                                                   uint32_t* __restrict__ digits, const uint32_t* __restrict__ inf_mask,
                                                   size_t inf_first, uint32_t* __restrict__ bad, DigitShard sh, unsigned sblk_log,
                                                   size_t sbstride) {
+    SWM_LIGHT_KERNEL();
     // scalar i sits at scalars[(i >> sblk_log) * sbstride + (i & (2^sblk_log - 1))]: contiguous by default (sblk_log = 31), the
     // blocks a rank of a sharded proof takes of a polynomial every rank holds otherwise (MsmTable::scalar_stride, blk_log, bstride)
     const size_t smask = ((size_t)1 << sblk_log) - 1;
@@ -401,6 +403,7 @@ static constexpr uint32_t FLAT_CUR_STRIDE = 32;   // = the most windows a table 
 // bin's entries WINDOW BY WINDOW (see msm_flat_scan_bins), for which it needs the bin's count of every window
 __global__ void __launch_bounds__(SORT_THREADS) msm_flat_coarse_hist(const uint32_t* __restrict__ digits, size_t n, unsigned fb,
                                                                      uint32_t nbins, uint32_t tile, uint32_t* __restrict__ bin_count) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t lh[FLAT_MAX_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += SORT_THREADS) lh[b] = 0;
     __syncthreads();
@@ -433,6 +436,7 @@ template <int BPT>
 __global__ void __launch_bounds__(1024) msm_flat_scan_bins(const uint32_t* __restrict__ bin_count, uint32_t nbins, uint32_t nwin,
                                                            uint32_t* __restrict__ bin_off, uint32_t* __restrict__ win_off, unsigned fb,
                                                            uint32_t SEG, uint32_t* __restrict__ bin_seg_off) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t sm[1024], sg[1024];
     const uint32_t t = threadIdx.x;
     uint32_t v[BPT], g[BPT], s = 0, q = 0;
@@ -505,6 +509,7 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
                                                            uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb, uint32_t nbins,
                                                            const uint32_t* __restrict__ win_off, uint32_t nwin,
                                                            uint32_t* __restrict__ bin_cursor, uint2* __restrict__ tmp) {
+    SWM_LIGHT_KERNEL();
     // LDS: PART_TILE pairs | cnt, start, gpos (nbins words each, rounded up to a multiple of 4) | 1024 scan words: sized by
     // the bin count of the call (74 KB at 512 bins: two workgroups per CU; the fixed 4096-bin arrays allowed one)
     constexpr uint32_t FLAT_PART_TILE = FLAT_PART_U * 1024u;
@@ -582,6 +587,98 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         tmp[gpos[b] + (i - start[b])] = e;
     }
 }
+// The same partition for a job whose sort runs BESIDE the accumulation of the job before it (r05).  That accumulation holds three
+// waves of 144 VGPRs on every SIMD: 80 registers per lane are free, i.e. room for ONE more wave per SIMD — a 256-lane workgroup
+// of at most 80 VGPRs becomes resident at once, while the 1024-lane kernel above (four waves per SIMD, 82 VGPRs) has to wait
+// until two of the three accumulation waves of all four SIMDs of a CU have retired (r05 timeline: 1 - 2.4 ms per partition beside
+// an accumulation, 0.2 ms alone, and the next accumulation waits for it).  Same tile (16 K digits, the pairs staged in 128 KB of
+// LDS: the accumulation uses none), same runs, same output; a lane takes 64 digits in rounds of 8 and reads them twice (the
+// second time from L2) instead of holding 16 in registers.  Alone on the chip it is the slower of the two (four waves per CU hide
+// less latency): the first job of a round, with nothing in flight, keeps the wide kernel.
+static constexpr uint32_t PARTN_THREADS = 256, PARTN_TILE = 16384, PARTN_U = 8;
+__global__ void __launch_bounds__(PARTN_THREADS, 6) msm_flat_partition_narrow(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
+                                                                           uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb,
+                                                                           uint32_t nbins, const uint32_t* __restrict__ win_off, uint32_t nwin,
+                                                                           uint32_t* __restrict__ bin_cursor, uint2* __restrict__ tmp) {
+    SWM_LIGHT_KERNEL();
+    extern __shared__ uint2 stage[];  // PARTN_TILE pairs | cnt, start, gpos (nbins words each, rounded up to 4) | scan words
+    const uint32_t nb4 = (nbins + 3) & ~3u;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PARTN_TILE);
+    uint32_t* start = cnt + nb4;
+    uint32_t* gpos = start + nb4;
+    uint32_t* scan = gpos + nb4;
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * PARTN_TILE;
+    for (uint32_t b = t; b < nbins; b += PARTN_THREADS) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)w * n;
+#pragma unroll 1
+    for (uint32_t r = 0; r < PARTN_TILE / (PARTN_THREADS * PARTN_U); r++) {  // pass 1: counts per bin
+        uint32_t c[PARTN_U];
+#pragma unroll
+        for (int u = 0; u < (int)PARTN_U; u++) {
+            const size_t i = lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t;
+            c[u] = i < n ? d[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < (int)PARTN_U; u++)
+            if (c[u]) atomicAdd(&cnt[((c[u] - 1) >> 1) >> fb], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt over <= 4096 bins: 16 bins per lane in two halves of 8 (registers), shuffles inside a wave, the four
+    // wave totals through LDS
+    const uint32_t per = (nbins + PARTN_THREADS - 1) / PARTN_THREADS, b0 = t * per, b1 = min(b0 + per, nbins);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += cnt[b];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t x = __shfl_up(inc, dd, 64);
+        if ((t & 63) >= (uint32_t)dd) inc += x;
+    }
+    if ((t & 63) == 63) scan[t >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t wv = 0; wv < PARTN_THREADS / 64; wv++) {
+        const uint32_t x = scan[wv];
+        if (wv < (t >> 6)) before += x;
+        total += x;
+    }
+    uint32_t run = before + inc - sum;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t v = cnt[b];
+        start[b] = run;
+        cnt[b] = run;  // running cursor of the bin inside the staged tile
+        gpos[b] = v ? win_off[(size_t)b * FLAT_CUR_STRIDE + w] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE + w], v) : 0u;
+        run += v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t r = 0; r < PARTN_TILE / (PARTN_THREADS * PARTN_U); r++) {  // pass 2: the pairs, grouped by bin in the stage
+        uint32_t c[PARTN_U];
+#pragma unroll
+        for (int u = 0; u < (int)PARTN_U; u++) {
+            const size_t i = lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t;
+            c[u] = i < n ? d[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < (int)PARTN_U; u++)
+            if (c[u]) {
+                const uint32_t bucket = (c[u] - 1) >> 1;
+                const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
+                const uint32_t i = (uint32_t)(lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t);
+                const uint32_t row = w * tstride + toff + (i >> blk_log) * bstride + (i & ((1u << blk_log) - 1u));
+                stage[p] = make_uint2(row | (((c[u] - 1) & 1u) << 31), bucket);
+            }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < total; i += PARTN_THREADS) {
+        const uint2 e = stage[i];
+        const uint32_t b = e.y >> fb;
+        tmp[gpos[b] + (i - start[b])] = e;
+    }
+}
 // One workgroup per bin: bucket histogram of the bin, placement by bucket — and everything the accumulation and the bucket
 // stage need to know about the bin's buckets (r04; four launches — three scans over the histogram and a binary search per
 // segment — did this before): a bin is a contiguous bucket range whose first entry (bin_off) and first segment index
@@ -623,12 +720,16 @@ __device__ __forceinline__ void flat_seg_write(const FlatSegOut& o, uint32_t c, 
         atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
     }
 }
-__global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
+// (BT lanes: 1024, or 256 for a sort that runs beside an accumulation — one more wave per SIMD fits next to its three, see
+// msm_flat_partition_narrow)
+template <int BT>
+__global__ void __launch_bounds__(BT) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
                                                                  const uint32_t* __restrict__ bin_off,
                                                                  const uint32_t* __restrict__ bin_seg_off, FlatSegOut o,
                                                                  uint32_t* __restrict__ sorted) {
+    SWM_LIGHT_KERNEL();
     extern __shared__ uint32_t stage32[];  // fc[nf] | fo[nf] | FLAT_BIN_CAP entries
-    __shared__ uint32_t wsum[2][BIN_THREADS / 64];
+    __shared__ uint32_t wsum[2][BT / 64];
     __shared__ uint32_t lh[SEG_MAX + 1];
     __shared__ uint32_t wide[FLAT_WIDE_Q][3], nwide;  // buckets whose descriptors the whole workgroup writes: (count, first entry, first segment)
     uint32_t* fc = stage32;
@@ -637,15 +738,15 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
     const uint32_t bin = blockIdx.x, nf = 1u << fb, first = bin << fb, fmask = nf - 1, t = threadIdx.x;
     const uint32_t lo = bin_off[bin], cnt = bin_off[bin + 1] - lo;
     const uint32_t seg_lo = bin_seg_off[bin], seg_hi = bin_seg_off[bin + 1];
-    for (uint32_t f = t; f < nf; f += BIN_THREADS) fc[f] = 0;
-    for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS) lh[i] = 0;
+    for (uint32_t f = t; f < nf; f += BT) fc[f] = 0;
+    for (uint32_t i = t; i <= o.SEG; i += BT) lh[i] = 0;
     if (t == 0) nwide = 0;
     __syncthreads();
-    for (uint32_t i = t; i < cnt; i += BIN_THREADS) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
+    for (uint32_t i = t; i < cnt; i += BT) atomicAdd(&fc[tmp[lo + i].y & fmask], 1u);
     __syncthreads();
     // exclusive prefixes of the fine counts and of the segments per bucket (nf <= 2048): a chunk per lane, shuffles inside
     // a wave, the 16 wave totals through LDS
-    const uint32_t per = (nf + BIN_THREADS - 1) / BIN_THREADS, f0 = t * per, f1 = min(f0 + per, nf);
+    const uint32_t per = (nf + BT - 1) / BT, f0 = t * per, f1 = min(f0 + per, nf);
     uint32_t sum = 0, sums = 0;
     for (uint32_t f = f0; f < f1; f++) {
         sum += fc[f];
@@ -667,7 +768,7 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
     __syncthreads();
     uint32_t run = inc - sum, runs = incs - sums, used = 0;
 #pragma unroll
-    for (uint32_t wv = 0; wv < BIN_THREADS / 64; wv++) {
+    for (uint32_t wv = 0; wv < BT / 64; wv++) {
         if (wv < (t >> 6)) {
             run += wsum[0][wv];
             runs += wsum[1][wv];
@@ -699,30 +800,30 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_flat_bin_sort(const uint2* __
         run += c;
         runs += ns;
     }
-    for (uint32_t k = seg_lo + used + t; k < seg_hi; k += BIN_THREADS) o.seg_len[k] = 0;  // indices the bin did not need
+    for (uint32_t k = seg_lo + used + t; k < seg_hi; k += BT) o.seg_len[k] = 0;  // indices the bin did not need
     __syncthreads();
     for (uint32_t q = 0, nq = min(nwide, FLAT_WIDE_Q); q < nq; q++) {  // the queued many-segment buckets: one segment per lane and trip
         const uint32_t c = wide[q][0], ns = nseg_of(c, o.SEG);
-        for (uint32_t k = t; k < ns; k += BIN_THREADS) flat_seg_write(o, c, ns, wide[q][1], wide[q][2], k, lh);
+        for (uint32_t k = t; k < ns; k += BT) flat_seg_write(o, c, ns, wide[q][1], wide[q][2], k, lh);
     }
     __syncthreads();
-    for (uint32_t i = t; i <= o.SEG; i += BIN_THREADS)
+    for (uint32_t i = t; i <= o.SEG; i += BT)
         if (lh[i]) atomicAdd(&o.len_hist[i * LEN_STRIDE], lh[i]);
     if (cnt <= FLAT_BIN_CAP) {
         // the bin's entries lie window by window (msm_flat_scan_bins); they are placed in chunks of PLACE_U x 1024 consecutive
         // entries, so a bucket's entries keep that order up to the chunk size — what the accumulation's locality rests on
-        for (uint32_t i = t; i < cnt; i += PLACE_U * BIN_THREADS) {
+        for (uint32_t i = t; i < cnt; i += PLACE_U * BT) {
             uint2 e[PLACE_U];
 #pragma unroll
-            for (int u = 0; u < PLACE_U; u++) e[u] = i + u * BIN_THREADS < cnt ? tmp[lo + i + u * BIN_THREADS] : make_uint2(0u, 0u);
+            for (int u = 0; u < PLACE_U; u++) e[u] = i + u * BT < cnt ? tmp[lo + i + u * BT] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < PLACE_U; u++)
-                if (i + u * BIN_THREADS < cnt) stage[atomicAdd(&fo[e[u].y & fmask], 1u)] = e[u].x;
+                if (i + u * BT < cnt) stage[atomicAdd(&fo[e[u].y & fmask], 1u)] = e[u].x;
         }
         __syncthreads();
-        for (uint32_t i = t; i < cnt; i += BIN_THREADS) sorted[lo + i] = stage[i];
+        for (uint32_t i = t; i < cnt; i += BT) sorted[lo + i] = stage[i];
     } else {  // oversized bin (many equal digits): scattered 4-byte stores, correct for any size
-        for (uint32_t i = t; i < cnt; i += BIN_THREADS) {
+        for (uint32_t i = t; i < cnt; i += BT) {
             uint2 e = tmp[lo + i];
             sorted[lo + atomicAdd(&fo[e.y & fmask], 1u)] = e.x;
         }
@@ -991,6 +1092,7 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __re
 }
 __global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG,
                                                        uint32_t* __restrict__ nseg_live) {
+    SWM_LIGHT_KERNEL();
     // one wave, three consecutive counters per lane (SEG <= SEG_MAX = 128: 129 counters at most), shuffle scan across the lanes
     static_assert(SEG_MAX + 1 <= 3 * 64, "three counters per lane");
     if (blockIdx.x) return;
@@ -1024,6 +1126,7 @@ __global__ void __launch_bounds__(ORD2_THREADS) msm_seg_order(const uint32_t* __
                                                               const uint32_t* __restrict__ nseg_ptr, uint32_t SEG,
                                                               uint32_t* __restrict__ len_cursor /* offsets, advanced */,
                                                               uint32_t* __restrict__ order) {
+    SWM_LIGHT_KERNEL();
     __shared__ uint32_t lh[SEG_MAX + 1];
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD2_THREADS) lh[i] = 0;
     __syncthreads();
@@ -1176,11 +1279,14 @@ __global__ void __launch_bounds__(256, 3) msm_accumulate(const G1Affine* __restr
     }
 }
 
-// The same kernel over a twisted Edwards table (msm_table_build_te): rows are the affine triples (y - x, y + x, 2 d x y),
-// the accumulator is an extended point and every addition is the UNIFIED 7-multiplication law of te28_madd — no doubling /
-// cancellation test, no cold path, 2 646 instead of 3 598 multiply-adds per addition (3 890 instead of 4 817 instructions in
-// the loop, 148 VGPRs, no scratch).  Partial sums leave as extended points (X, Y, T, Z in the four slots of a G1XYZZ).
-// Algorithmic bytes per point are unchanged (96 B base + 32 B scalar); a table row is 144 B instead of 96 B.
+// The same kernel over a twisted Edwards table (msm_table_build_te): rows are the affine triples (y - x, y + x, 2 d x y), each
+// coordinate as the fourteen 28-bit limbs the multiplier takes, in a 64-byte sector of its own (192 B per row, consumed as loaded);
+// the accumulator is an extended point and every addition is the UNIFIED 7-product law of te28_madd_row — no doubling /
+// cancellation test, no cold path: 3 223 VALU instructions per addition of which 2 646 are multiply-adds (SQ pass, r04:
+// profiles/r04_pmc_sq_msm_accumulate.json; XYZZ: 4 817), 139 VGPRs, no scratch, three waves per SIMD.  Rows go HBM -> registers,
+// not through LDS: the kernel is issue-bound, a row is read once by one lane.  It is the one kernel of a
+// proof WITHOUT an issue priority (ff.cuh SWM_LIGHT_KERNEL): the filler everything else runs beside.  Partial sums leave as
+// extended points (X, Y, T, Z in the four slots of a G1XYZZ).  Algorithmic bytes per point: 96 B base + 32 B scalar.
 __global__ void __launch_bounds__(256, SWM_TE_EARLY_LOADS ? 3 : 4) msm_accumulate_te(const G1TE* __restrict__ rows,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ seg_start,
@@ -1381,6 +1487,7 @@ __global__ void __launch_bounds__(RED_BLOCK) msm_big_bucket_sum(G1XYZZ* __restri
                                                                 const uint32_t* __restrict__ hist, uint32_t SEG,
                                                                 const uint32_t* __restrict__ big_count,
                                                                 const uint32_t* __restrict__ big_list, unsigned log_g) {
+    SWM_TAIL_KERNEL();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     G1XYZZ* sm = reinterpret_cast<G1XYZZ*>(smem_raw);
     const uint32_t nbig = *big_count;
@@ -1443,10 +1550,12 @@ struct TailJob {
 };
 struct TailBatch {
     TailJob j[TAIL_MAX];
+    unsigned flags;  // bit 0 (msm_bucket_reduce_low, experiment SWM_LOW_SYNC_ALL): a barrier behind every step, walk steps included
 };
 // (RB = chains per workgroup; a chain is one lane, or Form::LANES of them: RB x LANES threads)
 template <int RB, class Form>
 __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch batch) {
+    SWM_TAIL_KERNEL();
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
     const G1XYZZ* __restrict__ partial = job.partial;
@@ -1613,6 +1722,7 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
 #endif
 template <int RB>
 __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailBatch batch) {
+    SWM_TAIL_KERNEL();
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
     const G1XYZZ* __restrict__ partial = job.partial;
@@ -1726,8 +1836,8 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
         // barriers: the in-place scan needs its loads ahead of one and its stores behind it; a tree step and the fold are read by
         // other lanes in the NEXT step (trailing barrier); a walk step touches the lane's own slots only (the vote at the top
         // of the loop is the workgroup's only meeting point there)
-        const bool walk = phase == WALK;
-        te28_slot_add_sync(dst, pa, pq, act, phase == SCAN);
+        const bool walk = phase == WALK && !(batch.flags & 1u);
+        te28_slot_add_sync(dst, pa, pq, act, phase == SCAN || (batch.flags & 1u));
         if (!walk) __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -2015,6 +2125,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stat_msm_calls++;
     ctx->stat_msm_points += n;
     ctx->log_call('m', n);
+    struct SinceWait {  // (counted when this call returns: the choices below see the jobs BEFORE this one)
+        swm_ctx* c;
+        ~SinceWait() { c->msm_since_wait++; }
+    } since_wait{ctx};
     // the job before this one waited to learn whether anything follows it: something does, so its bucket stage takes the
     // thin shape that runs BESIDE this job's sort and accumulation (msm_tail_shape)
     SWM_TRY(msm_launch_lazy_tail(ctx, false));
@@ -2067,17 +2181,17 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // One-lane twisted Edwards stages take the low-LDS kernel (msm_bucket_reduce_low: 49 KB per workgroup, three per CU);
     // SWM_MSM_LOW=0: the 144-KB kernel of r02 - r04.  SWM_MSM_LOW_BLOCKS: workgroups a stage may be cut into (result slot:
     // up to 1024 (A, R) pairs; the host folds them in groups of 16).
-    static const bool low_on = !(getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) == 0);
+    static const bool low_on = getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) != 0;  // (off: measured r05, see msm_bucket_reduce_low)
     static const unsigned low_blocks = getenv("SWM_MSM_LOW_BLOCKS") ? (unsigned)std::min(1024, std::max(16, atoi(getenv("SWM_MSM_LOW_BLOCKS")))) : 256u;
     // (joint stages of small jobs: SWM_MSM_JOINT_BLOCKS workgroups per job — with the low-LDS kernel twelve waves per CU are resident)
-    // 64 per job in the low-latency schedule (r02), 128 for the larger jobs that join a round's launch since r05 (n >= 2^18 points:
-    // 2^19 buckets -> 16 per lane; four jobs = 512 workgroups = two per CU)
-    static const unsigned joint_env = getenv("SWM_MSM_JOINT_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_JOINT_BLOCKS"))) : 0u;
-    const unsigned joint_blocks = joint_env ? joint_env : (lat ? 64u : 128u);
+    // 64 per job: the four stages of a round's launch are resident together, one workgroup per CU — in the low-latency schedule
+    // (r02) and for the larger jobs that join a round's launch since r05 (up to 10^6 points: 2^19 buckets -> 32 per lane).  With the
+    // low-LDS kernel 128 per job (two workgroups per CU) measured SLOWER per launch: 1.43 against 1.06 ms for four 2^19-bucket jobs.
+    static const unsigned joint_blocks = getenv("SWM_MSM_JOINT_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_JOINT_BLOCKS"))) : 64u;
     const bool low = te && !quad && rb == 256 && low_on;
     job->low = low;
     // (low-latency schedule: the bucket stages of a round's four MSMs run in one launch and have to be resident together)
-    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (defer_tail && (lat || low) ? joint_blocks : (low ? low_blocks : 256u))) : 16u);
+    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (defer_tail ? joint_blocks : (low ? low_blocks : 256u))) : 16u);
     job->max_blocks = low ? std::max(max_blocks, low_blocks) : std::max(max_blocks, 256u);
     while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
@@ -2123,9 +2237,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             // The four streams are created and probed into locals and published to the context only when all of it
             // succeeded: a failure half way must not leave aux_stream[0] set with the later entries null (every later MSM
             // would skip this block and silently run its tail on the legacy default stream).
-            hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+            hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             auto setup = [&]() -> int {
-                static const char* role_env[swm_ctx::MSM_LANES] = {"SWM_PRIO_SORT", "SWM_PRIO_ACC", "SWM_PRIO_ACC", "SWM_PRIO_TAIL"};
+                static const char* role_env[swm_ctx::MSM_LANES] = {"SWM_PRIO_SORT", "SWM_PRIO_ACC", "SWM_PRIO_ACC", "SWM_PRIO_TAIL", "SWM_PRIO_TAIL"};
                 for (int i = 0; i < 3; i++) SWM_HIP(ctx, msm_create_stream(&aux[i], role_env[i]));
                 if (steer) {
                     hipStream_t ph = nullptr;
@@ -2133,6 +2247,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                     ctx->spare_streams.push_back(ph);
                 }
                 SWM_HIP(ctx, msm_create_stream(&aux[3], role_env[3]));
+                SWM_HIP(ctx, msm_create_stream(&aux[4], role_env[4]));  // (not probed: shares a hardware queue with whatever the runtime picks)
                 if (steer) {
                     SWM_HIP(ctx, hipStreamSynchronize(main_stream));
                     const int roles[3] = {0, 1, 3};  // sort, accumulation 0, tail
@@ -2175,7 +2290,10 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         } else {
             st_sort = ctx->aux_stream[0];
             st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + (lane & 1)];
-            st_tail = ctx->aux_stream[3];
+            // SWM_MSM_TAILS=2 (experiment): the bucket stages of consecutive jobs alternate between two streams, so that the thin
+            // stage of job k (beside the accumulation of job k + 1) does not hold back the stage of job k + 1
+            static const int tails = getenv("SWM_MSM_TAILS") ? std::min(2, std::max(1, atoi(getenv("SWM_MSM_TAILS")))) : 1;
+            st_tail = ctx->aux_stream[tails == 2 && (ctx->next_slot & 1) ? 4 : 3];
         }
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
@@ -2378,7 +2496,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_TRY(scratch(ctx, nma, (size_t)rl.nwin * job->max_blocks * 256 * sizeof(G1XYZZ), (void**)&job->d_acc));
     }
 
-    SWM_HIP(ctx, hipMemsetAsync(hist, 0, zero_words * 4, ctx->stream));
+    SWM_HIP(ctx, zero_fill_async(hist, zero_words * 4, ctx->stream));  // (a kernel with issue priority, not the runtime's fill: fill.cuh)
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
@@ -2400,7 +2518,18 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         const size_t lds_part = (size_t)part_tile * sizeof(uint2) + lds_bins;
         SWM_TRY(allow_big_lds(ctx, tile16 ? 10 : 5, tile16 ? (const void*)msm_flat_partition<16> : (const void*)msm_flat_partition<8>, lds_part));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
-        SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort, lds_bin));
+        SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort<BIN_THREADS>, lds_bin));
+        SWM_TRY(allow_big_lds(ctx, 11, (const void*)msm_flat_bin_sort<256>, lds_bin));
+        // A sort that runs beside the accumulation of the job before it takes the 256-lane forms of the partition and the bin sort
+        // (resident at once next to the accumulation's three waves per SIMD); the first job after a wait — nothing in flight —
+        // the 1024-lane forms, which are faster alone.  SWM_SORT_NARROW=0: always the wide forms (r02 - r04), 2: always narrow.
+        // Measured r05 on top of the issue priorities (ff.cuh SWM_LIGHT_PRIO), alternating on one box: prove 2^20 50.8 ms wide, 51.15 ms
+        // with this rule, 52.0 ms always narrow — with s_setprio the wide kernels no longer wait long enough for the narrow ones'
+        // lower throughput to pay.  Default 0; kept as a switch (tests/test_gpu_switches.py).
+        static const int narrow_env = getenv("SWM_SORT_NARROW") ? atoi(getenv("SWM_SORT_NARROW")) : 0;
+        const bool narrow_sort = lane >= 0 && !lat && (narrow_env == 2 || (narrow_env == 1 && ctx->msm_since_wait > 0)) &&
+                                 (size_t)PARTN_TILE * sizeof(uint2) + lds_bins <= 160 * 1024;
+        if (narrow_sort) SWM_TRY(allow_big_lds(ctx, 12, (const void*)msm_flat_partition_narrow, (size_t)PARTN_TILE * sizeof(uint2) + lds_bins));
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
                    digits, n, flat_fb, flat_bins, ctile, flat_cnt);
         unsigned scan_threads = 64;
@@ -2412,7 +2541,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         else
             SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins<4>, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
                    flat_fb, SEG, flat_seg_off);
-        if (tile16)
+        if (narrow_sort)
+            SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition_narrow, dim3((unsigned)((n + PARTN_TILE - 1) / PARTN_TILE), pl.nwin),
+                   dim3(PARTN_THREADS), (size_t)PARTN_TILE * sizeof(uint2) + lds_bins, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset,
+                   tab.blk_log, (uint32_t)tab.bstride, flat_fb, flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
+        else if (tile16)
             SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition<16>, dim3((unsigned)((n + part_tile - 1) / part_tile), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
                    flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
@@ -2423,8 +2556,12 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
         // the bin sort: no scans over the bucket histogram, no msm_seg_desc)
         const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg, te ? 1u : 0u};
-        SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
-                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
+        if (narrow_sort)
+            SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<256>, dim3(flat_bins), dim3(256), lds_bin,
+                       (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
+        else
+            SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<BIN_THREADS>, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
+                       (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
     } else {
         // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
         uint32_t SORT_TILE = SORT_TILE_MIN;
@@ -2585,6 +2722,8 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);
     }
+    static const bool low_sync_all = getenv("SWM_LOW_SYNC_ALL") != nullptr;
+    batch.flags = low_sync_all ? 1u : 0u;
     const bool te = jobs[0]->te;  // every job of a launch has the same point form (msm_flush_tails groups them)
     if (jobs[0]->quad) {
         const size_t lds = (3 * (size_t)jobs[0]->rb + 1) * sizeof(G1XYZZ);
@@ -2798,6 +2937,7 @@ static unsigned pool_spin_us() {
 
 int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     *result = g1_xyzz_identity();
+    ctx->msm_since_wait = 0;
     if (!job->active) return SWM_OK;
     static const bool trace = getenv("SWM_TRACE") != nullptr;
     auto tw0 = std::chrono::steady_clock::now();
@@ -2817,6 +2957,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 // ~0.25 ms between the last kernel of a round and its Fiat-Shamir challenge).
 int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
     static const bool trace = getenv("SWM_TRACE") != nullptr;
+    ctx->msm_since_wait = 0;
     auto tw0 = std::chrono::steady_clock::now();
     std::vector<int> live;
     for (int i = 0; i < k; i++) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned bitrev_u(unsigned x, unsigned bits) { return
 
 template <int J>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass(NttPassArgs a) {
+    SWM_LIGHT_KERNEL();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fr* tile = reinterpret_cast<Fr*>(smem_raw);  // [R][J]
     const unsigned R = 1u << a.log_r;
@@ -206,6 +207,7 @@ __device__ __forceinline__ Fr29 tile_get(const uint32_t* tile, unsigned idx) {
 }
 template <int J>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_lazy(NttLazyArgs args) {
+    SWM_LIGHT_KERNEL();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);  // [R][J] elements of 9 words
     const NttPassArgs& a = args.a;

@@ -51,6 +51,7 @@ __device__ __forceinline__ Fr block_sum_fr(Fr acc, Fr* sm) {
 __global__ void __launch_bounds__(SPMV_BLOCK) spmv_long_chunks(const uint32_t* __restrict__ chunks,
                                                                 const uint32_t* __restrict__ col, const Fr* __restrict__ val,
                                                                 const Fr* __restrict__ z, Fr* __restrict__ partial) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sm[SPMV_BLOCK];
     const uint32_t start = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2];
     Fr acc = fp_zero<Fr>();
@@ -65,6 +66,7 @@ __global__ void __launch_bounds__(SPMV_BLOCK) spmv_long_chunks(const uint32_t* _
 // one workgroup per long row (row, first_chunk, n_chunks): out[row] = sum of its chunk sums
 __global__ void __launch_bounds__(SPMV_BLOCK) spmv_long_rows(const uint32_t* __restrict__ lrows, const Fr* __restrict__ partial,
                                                               Fr* __restrict__ out) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sm[SPMV_BLOCK];
     const uint32_t row = lrows[3 * blockIdx.x], first = lrows[3 * blockIdx.x + 1], cnt = lrows[3 * blockIdx.x + 2];
     Fr acc = fp_zero<Fr>();

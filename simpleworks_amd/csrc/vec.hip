@@ -14,6 +14,7 @@ namespace swm {
 
 __global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b,
                                                       Fr* __restrict__ out, size_t n) {
+    SWM_LIGHT_KERNEL();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = fp_mul(a[i], b[i]);
 }
@@ -30,6 +31,7 @@ static constexpr int BINV_CHUNK = 16, BINV_CHUNK_SMALL = 4;
 static constexpr int BINV_THREADS = 256;
 template <int BINV_CHUNK>
 __global__ void __launch_bounds__(BINV_THREADS) batch_inverse_kernel(Fr* __restrict__ v, size_t n) {
+    SWM_LIGHT_KERNEL();
     __shared__ Fr sp[BINV_THREADS], ss[BINV_THREADS];
     __shared__ Fr s_inv;
     const unsigned tid = threadIdx.x;

@@ -29,6 +29,10 @@ for lg in (12, 17):
     a = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
     b = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
     assert a == b, "same rng, same proof"
+    # the same stream behind the fill_bytes callback (a caller-owned generator): the mask commitment in pieces, the host
+    # counting only the runs that could complete the draw
+    c = S.serialize_proof(M.generate_proof(cs, pk, M.rng_behind_callback(M.generate_rand())))
+    assert c == a, "callback rng, same proof"
     assert M.verify_proof(vk, public, S.deserialize_proof(a), M.generate_rand())
     print("sha", lg, __import__("hashlib").sha256(a).hexdigest())
 """
@@ -58,5 +62,14 @@ def test_switches_select_equivalent_paths():
                 {"SWM_MSM_QUAD_RB": "64", "SWM_MSM_QUAD_MAXB": "1048576"},   # quad bucket stage in its other shapes, also at 2^17
                 {"SWM_MSM_QUAD_RB": "256", "SWM_MSM_QUAD_BLOCKS": "16"},
                 {"SWM_MSM_QUAD_ACC": "0", "SWM_FLAT_PART_TILE": "8192"},  # one lane per segment in small accumulations; 8 K-digit partition tiles
-                {"SWM_MSM_TABLE_C": "15"}):      # narrower window tables (what a rank of a sharded proof takes)
+                {"SWM_MSM_TABLE_C": "15"},      # narrower window tables (what a rank of a sharded proof takes)
+                # r05: the low-LDS bucket stage (joint launches of the 2^17 jobs; alone, re-shaped up to 512 workgroups, a barrier
+                # behind every step), two bucket-stage streams, smaller joint stages, the mask commitment enqueued last
+                {"SWM_MSM_LOW": "1"},
+                {"SWM_MSM_LOW": "1", "SWM_MSM_LOW_BLOCKS": "512", "SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0", "SWM_LOW_SYNC_ALL": "1"},
+                {"SWM_MSM_TAILS": "2", "SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
+                {"SWM_MSM_JOINT_BLOCKS": "16", "SWM_MASK_COMMIT": "2"},
+                {"SWM_SORT_NARROW": "2", "SWM_MSM_LAT_BELOW": "0"},   # 256-lane partition and bin sort (co-resident with an accumulation)
+                # the caller-owned generator's draw: one piece / two pieces of the mask commitment, every run counted on the host
+                {"SWM_MASK_PIECES": "1", "SWM_EXT_COUNT_ALL": "1"}, {"SWM_MASK_PIECES": "2"}):
         assert _run(env) == ref, env

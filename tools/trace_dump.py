@@ -10,7 +10,14 @@ def name(k):
     if m: return "ew:%s#%s" % (m.group(1), m.group(2))
     return k.split("(")[0].replace("swm::", "").replace("void ", "").replace("(anonymous namespace)::", "")[:40]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name(r["Kernel_Name"]), r["Queue_Id"]) for r in rows)
-marks = [s for s, e, k, q in ev if k.startswith("sample_candidates")]
+# one mark per proof: the bulk mask sampling (sample_candidates); TRACE_MARK=<kernel name prefix> picks another kernel (a proof with a
+# caller-owned generator has none) — launches of it closer than 10 ms to the previous mark belong to the same proof
+import os
+_mk = os.environ.get("TRACE_MARK") or ("swm_proof_begin" if any(x[2].startswith("swm_proof_begin") for x in ev) else "sample_candidates")
+marks = []
+for s, e, k, q in ev:
+    if k.startswith(_mk) and (not marks or s - marks[-1] > 10e6):
+        marks.append(s)
 t0, t1 = marks[-2], marks[-1]
 acc = [(s, e) for s, e, k, q in ev if k.startswith("msm_accumulate")]
 for s, e, k, q in ev:

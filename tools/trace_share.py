@@ -11,7 +11,12 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (lambda k: (re.
 def name(k):
     m = re.search(r"ew_kernel<swm::(\w+)", k) or re.search(r"ew_kernel<.*?::(\w+)\(", k)
     return m.group(1) if m else k
-marks = [s for s, e, k in ev if k.startswith("sample_candidates")]
+import os
+_mk = os.environ.get("TRACE_MARK") or ("swm_proof_begin" if any(x[2].startswith("swm_proof_begin") for x in ev) else "sample_candidates")   # (TRACE_MARK: see trace_dump.py)
+marks = []
+for s, e, k in ev:
+    if k.startswith(_mk) and (not marks or s - marks[-1] > 10e6):
+        marks.append(s)
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t0, t1 = marks[-nlast - 1], marks[-nlast]
 sel = [(max(s, t0), min(e, t1), k) for s, e, k in ev if e > t0 and s < t1]
