@@ -457,7 +457,7 @@ def main():
             box = {}
             th = threading.Thread(target=run_sharded, args=(lg_s, box), daemon=True)
             th.start()
-            th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240" if lg_s <= 20 else "600")))
+            th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240" if lg_s <= 20 else "360")))
             results.append(box.get("res", {"error": "timed out", "log_n": lg_s}))
             if "error" in results[-1]:
                 break  # a rank that gave up cannot take part in the next size's collectives

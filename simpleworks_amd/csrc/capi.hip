@@ -386,6 +386,9 @@ void swm_destroy(swm_ctx* ctx) {
         if (ctx->ext_registered) (void)hipHostUnregister(ctx->ext_pinned);
         free(ctx->ext_pinned);
     }
+    if (ctx->ext_totals) (void)hipHostFree(ctx->ext_totals);
+    for (auto e : ctx->ext_cnt_event)
+        if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->ext_event)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

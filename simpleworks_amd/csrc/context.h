@@ -101,10 +101,12 @@ struct swm_ctx {
     // bulk draws from a caller-owned generator (sample_fr_bulk): a ring of two host chunks filled through the callback
     // and sent up on a copy stream of its own, so that the transfers run beside whatever the context's stream is doing
     hipStream_t copy_stream = nullptr;
-    void* ext_pinned = nullptr;  // the ring's two host chunks (page-aligned host memory, registered with the runtime: see sample_fr_bulk)
+    void* ext_pinned = nullptr;  // the ring's four host chunks (page-aligned host memory, registered with the runtime: see sample_fr_bulk)
     bool ext_registered = false;
     unsigned msm_since_wait = 0;  // MSM jobs enqueued since the last msm_finish*: 0 = nothing of this context is in flight
-    hipEvent_t ext_event[3] = {nullptr, nullptr, nullptr};  // [0], [1]: chunk buffer free again; [2]: destination may be written
+    uint32_t* ext_totals = nullptr;  // eight pinned words: the device's running total behind each of the last eight runs of a draw
+    hipEvent_t ext_cnt_event[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and when each has arrived
+    hipEvent_t ext_event[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0 .. 3]: host chunk free again; [4]: destination may be written
 };
 
 struct swm_bases {

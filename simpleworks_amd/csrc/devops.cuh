@@ -8,11 +8,13 @@
 #pragma once
 #include <chrono>
 #include <exception>
+#include <functional>
 #include <utility>
 #include <atomic>
 #include "context.h"
 #include "ff.cuh"
 #include "fill.cuh"
+#include "fr29.cuh"
 #include "host/chacha.h"
 #include "host/marlin_types.h"
 
@@ -322,6 +324,99 @@ static __global__ void __launch_bounds__(256) rec_tile_scan(Fr* __restrict__ a, 
     }
 }
 
+// The two tiled passes on the transform's multiplier (r05; fr29.cuh: nine 29-bit lazy limbs, 197 instructions per product instead
+// of ~330, additions without a comparison against the modulus).  `rc` holds the constants in Montgomery form of radix 2^261 (times
+// 2^5: what fr29_mul takes as its second operand), so the data keep the memory format; values are < 2r between products, < 5r
+// before they are made canonical for the store.  Same results bit for bit (every golden-bytes test runs through them).
+__device__ __forceinline__ Fr29 fr29_zero() {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ Fr29 fr29_below_2r(const Fr29& lazy_below_4r) {  // lazy limbs, value < 4r -> normalised, < 2r
+    return fr29_cond_sub(fr29_normalize(lazy_below_4r), Fr29Consts::P2);
+}
+static __global__ void __launch_bounds__(256) rec_tile_total29(const Fr* __restrict__ a, size_t n, RecConsts rc,
+                                                               const Fr* __restrict__ zlow /* z^0..z^255, memory form */,
+                                                               Fr* __restrict__ totals) {
+    SWM_LIGHT_KERNEL();
+    __shared__ Fr sm[256];
+    const size_t base = (size_t)blockIdx.x * RT_TILE;
+    const unsigned t = threadIdx.x;
+    const Fr29 z256 = fr29_unpack(rc.z256);
+    Fr29 acc = fr29_zero();
+#pragma unroll 1
+    for (int j = RT_PER - 1; j >= 0; j--) {
+        size_t k = base + (size_t)j * 256 + t;
+        acc = fr29_mul_fenced(acc, z256);  // (acc < 3r with limbs < 2^30)
+        if (k < n) acc = fr29_add(acc, fr29_unpack(a[k]));
+    }
+    // zlow is in the memory format: this product comes out with 2^-5, put right on the tile's total (rc.zpow[0] = 2^261 = the
+    // memory form of 2^5)
+    sm[t] = fr29_pack(fr29_canonical(fr29_mul_fenced(acc, fr29_unpack(zlow[t])), true));
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (t < s) sm[t] = fp_add(sm[t], sm[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) totals[blockIdx.x] = fp_mul(sm[0], rc.zpow[0]);
+}
+static __global__ void __launch_bounds__(256) rec_tile_scan29(Fr* __restrict__ a, size_t n, RecConsts rc,
+                                                              const Fr* __restrict__ tile_true /* S_b */, size_t ntiles) {
+    SWM_LIGHT_KERNEL();
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Fr* tile = reinterpret_cast<Fr*>(smem_raw);      // RT_TILE + 256 padded slots
+    Fr* hs = tile + RT_TILE + 256;                   // 257 heads, each < 2r
+    const size_t b = blockIdx.x, base = b * RT_TILE;
+    const unsigned t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < RT_PER; j++) {
+        unsigned e = j * 256 + t;
+        size_t k = base + e;
+        tile[rt_pad(e)] = k < n ? a[k] : fp_zero<Fr>();
+    }
+    __syncthreads();
+    // local scan of this lane's 8 consecutive elements (carry-in 0): element + product, < 3r with limbs < 2^30
+    Fr29 loc[RT_PER];
+    {
+        const Fr29 z1 = fr29_unpack(rc.zpow[1]);
+        Fr29 acc = fr29_zero();
+#pragma unroll
+        for (int i = RT_PER - 1; i >= 0; i--) {
+            acc = fr29_add(fr29_unpack(tile[rt_pad(t * RT_PER + i)]), fr29_mul_fenced(acc, z1));
+            loc[i] = acc;
+        }
+        hs[t] = fr29_pack(fr29_below_2r(acc));
+    }
+    if (t == 0) hs[256] = b + 1 < ntiles ? tile_true[b + 1] : fp_zero<Fr>();  // carry into the tile
+    __syncthreads();
+    // inclusive suffix scan of the heads with multiplier z^8 per lane step (Hillis-Steele, 257 entries)
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        unsigned d = 1u << k;
+        Fr v = hs[t];
+        bool has = t + d <= 256;
+        Fr o = has ? hs[t + d] : fp_zero<Fr>();
+        __syncthreads();
+        if (has) hs[t] = fr29_pack(fr29_below_2r(fr29_add(fr29_unpack(v), fr29_mul_fenced(fr29_unpack(o), fr29_unpack(rc.zstep[k])))));
+        __syncthreads();
+    }
+    const Fr29 carry = fr29_unpack(hs[t + 1]);  // true value (< 2r) at the first element of the next lane's chunk
+#pragma unroll
+    for (int i = 0; i < RT_PER; i++) {
+        const Fr29 v = fr29_add(loc[i], fr29_mul_fenced(carry, fr29_unpack(rc.zpow[RT_PER - i])));  // < 5r
+        tile[rt_pad(t * RT_PER + i)] = fr29_pack(fr29_cond_sub(fr29_cond_sub(fr29_cond_sub(fr29_normalize(v), Fr29Consts::P2), Fr29Consts::P2), Fr29Consts::P));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RT_PER; j++) {
+        unsigned e = j * 256 + t;
+        size_t k = base + e;
+        if (k < n) a[k] = tile[rt_pad(e)];
+    }
+}
+
 inline void suffix_recurrence(swm_ctx* ctx, Fr* a, size_t n, size_t m, const Fr& z);
 inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) {
     size_t ntiles = (n + RT_TILE - 1) / RT_TILE;
@@ -332,9 +427,15 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     for (int k = 1; k < 9; k++) rc.zstep[k] = fp_sqr(rc.zstep[k - 1]);
     DVec zlow(ctx, 256), totals(ctx, ntiles);
     rc.z256 = dv_pow256(ctx, z, zlow.p);
+    static const bool lazy = !(getenv("SWM_REC_LAZY") && atoi(getenv("SWM_REC_LAZY")) == 0);  // 0: the 8 x 32-bit Comba kernels (r02 - r04)
+    RecConsts rc29;  // the same constants in radix-2^261 form
+    const Fr two5 = fp_from_u64<Fr>(32);
+    for (int i = 0; i <= RT_PER; i++) rc29.zpow[i] = fp_mul(rc.zpow[i], two5);
+    for (int k = 0; k < 9; k++) rc29.zstep[k] = fp_mul(rc.zstep[k], two5);
+    rc29.z256 = fp_mul(rc.z256, two5);
     prof_begin(ctx, "rec_tile_total");
-    hipLaunchKernelGGL(rec_tile_total, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc, (const Fr*)zlow.p,
-                       totals.p);
+    if (lazy) hipLaunchKernelGGL(rec_tile_total29, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc29, (const Fr*)zlow.p, totals.p);
+    else hipLaunchKernelGGL(rec_tile_total, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc, (const Fr*)zlow.p, totals.p);
     prof_end(ctx);
     hip_check(ctx, hipGetLastError(), "rec_tile_total");
     Fr ztile = rc.z256;
@@ -345,10 +446,12 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     static std::atomic<bool> attr_set[64];  // per device: the attribute belongs to the device's copy of the kernel
     if (!attr_set[ctx->device & 63].load(std::memory_order_acquire)) {
         hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
+        hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan29, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
         attr_set[ctx->device & 63].store(true, std::memory_order_release);
     }
     prof_begin(ctx, "rec_tile_scan");
-    hipLaunchKernelGGL(rec_tile_scan, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc, (const Fr*)totals.p, ntiles);
+    if (lazy) hipLaunchKernelGGL(rec_tile_scan29, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc29, (const Fr*)totals.p, ntiles);
+    else hipLaunchKernelGGL(rec_tile_scan, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc, (const Fr*)totals.p, ntiles);
     prof_end(ctx);
     hip_check(ctx, hipGetLastError(), "rec_tile_scan");
 }
@@ -702,14 +805,34 @@ static __global__ void __launch_bounds__(256) sample_compact_base(const Fr* __re
     if (r < need) out[r] = cand[j];
 }
 static __global__ void sample_base_add(uint32_t* __restrict__ base, const uint32_t* __restrict__ run_total) { *base += *run_total; }
+// accepted candidates among n raw 32-byte draws (Fr::rand: the top three bits masked off, accepted when below the modulus)
+inline size_t ext_count_accepted(const uint32_t* buf, size_t n) {
+    size_t acc = 0;
+    const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
+    for (size_t i = 0; i < n; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
+        const uint32_t* r = buf + 8 * i;  // in all but 2^-29 of the cases
+        const uint32_t t = r[7] & top_mask;
+        if (t != p7) {
+            acc += t < p7;
+        } else {
+            bool lt = false;
+            for (int k = 6; k >= 0; k--) {
+                if (r[k] < FrParams::P[k]) { lt = true; break; }
+                if (r[k] > FrParams::P[k]) break;
+            }
+            acc += lt;
+        }
+    }
+    return acc;
+}
 // Draws `need` field elements from rng's stream into out[0..need) (device), advancing rng exactly as `need`
 // successive Fr::rand(rng) calls would.
 // Caller-owned generator (rng.ext): the candidates come from its fill_bytes in runs of at most EXT_CHUNK and never more than
 // the number still missing, so the stream stops right behind the candidate that completes the draw.  The host only COUNTS
 // the accepted candidates of a run when the run could complete the draw (r05: as long as even a fully accepted run cannot, whole
 // runs go up uncounted — the GPU's scan keeps the running total in a device word the compaction reads its offset from — and
-// that word is read back when the bound gets close: each such phase covers 58 % of what is missing, so three or four read-backs
-// replace 90 % of the host's counting, ~4 ms of a 3 x 2^20 draw); the raw run goes up from a ring of
+// that word follows the host asynchronously, one pinned copy per run: the host's counting shrinks to the last few runs of a
+// draw, ~2 ms of a 3 x 2^20 draw, and it never waits for the device); the raw run goes up from a ring of
 // two host chunks on the context's copy stream and is flagged, scanned and compacted into place on the GPU (the kernels of the
 // built-in path), while the callback produces the next run: ~170 MB through the callback for 3 * 2^20 elements, i.e. as
 // fast as the caller's generator.  The call returns once the callback is done; the context's stream is made to wait for the
@@ -717,11 +840,21 @@ static __global__ void sample_base_add(uint32_t* __restrict__ base, const uint32
 // the context's stream, not for what was enqueued since (the prover requests the mask after enqueueing the rest of round 1,
 // so that the GPU works while the host draws).
 static constexpr size_t EXT_CHUNK = (size_t)1 << 18;
+// Host chunks in the ring.  Four, not two (r05): the copy of a run is a kernel of the runtime, and beside the accumulations of
+// round 1 it is starved like every kernel without an issue priority — the first copy of a 3 x 2^20 draw completed 5 ms after
+// the draw began and the host, two runs ahead, waited 2.1 ms for its chunk.  With four chunks the copies lag and catch up
+// once the accumulations are through (SWM_EXT_RING=2: the ring of r02 - r04).
+static constexpr int EXT_RING = 4;
+static constexpr int EXT_TOTALS = 8;  // device totals in flight (pinned words + events), a power of two
 inline void sample_fr_ext_mark(swm_ctx* ctx) {  // call right after allocating the destination of a later bulk draw
-    if (!ctx->ext_event[2]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[2], hipEventDisableTiming), "event");
-    hip_check(ctx, hipEventRecord(ctx->ext_event[2], ctx->stream), "record");
+    if (!ctx->ext_event[EXT_RING]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[EXT_RING], hipEventDisableTiming), "event");
+    hip_check(ctx, hipEventRecord(ctx->ext_event[EXT_RING], ctx->stream), "record");
 }
-inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, bool marked = false) {
+// `progress` (caller-owned generator only): called with the number of elements known to be in place whenever the host learns it
+// exactly (a read-back of the device's running total, or a run it counted itself) — every kernel that writes those elements has
+// been enqueued on ctx->copy_stream by then.  The prover commits to the mask polynomial piece by piece from it.
+inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, bool marked = false,
+                           const std::function<void(size_t)>* progress = nullptr) {
     if (rng.ext) {
         if (!ctx->copy_stream) hip_check(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "copy stream");
         // (the chunks are ordinary cacheable host memory: a host ChaCha fills pinned memory at a fifth of the rate it fills
@@ -732,13 +865,13 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         // (round 1 took 50 ms with a 35-ms draw).  SWM_EXT_REGISTER=0: the unregistered ring.
         if (!ctx->ext_pinned) {
             void* ring = nullptr;
-            if (posix_memalign(&ring, 4096, 2 * EXT_CHUNK * sizeof(Fr)) != 0 || !ring) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
+            if (posix_memalign(&ring, 4096, EXT_RING * EXT_CHUNK * sizeof(Fr)) != 0 || !ring) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
             ctx->ext_pinned = ring;
             static const bool reg = !(getenv("SWM_EXT_REGISTER") && atoi(getenv("SWM_EXT_REGISTER")) == 0);
-            if (reg && hipHostRegister(ring, 2 * EXT_CHUNK * sizeof(Fr), hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError();  // (not fatal: staged copies)
+            if (reg && hipHostRegister(ring, EXT_RING * EXT_CHUNK * sizeof(Fr), hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError();  // (not fatal: staged copies)
             else ctx->ext_registered = reg;
         }
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < EXT_RING; i++)
             if (!ctx->ext_event[i]) hip_check(ctx, hipEventCreateWithFlags(&ctx->ext_event[i], hipEventDisableTiming), "event");
         // device side of the ring: raw candidates, flags, ranks and the scan's tile totals, per slot
         const unsigned ntiles = (unsigned)((EXT_CHUNK + SC_TILE - 1) / SC_TILE);
@@ -747,11 +880,11 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         if (scratch(ctx, "ext.ring", 2 * slot_bytes + 256, (void**)&dev) != SWM_OK) throw MarlinError(SWM_ERR_OOM, "sample: device ring");
         if (!marked) sample_fr_ext_mark(ctx);  // no earlier mark: everything enqueued so far may still use the buffer
         hipStream_t cs = ctx->copy_stream;
-        hip_check(ctx, hipStreamWaitEvent(cs, ctx->ext_event[2], 0), "wait");
+        hip_check(ctx, hipStreamWaitEvent(cs, ctx->ext_event[EXT_RING], 0), "wait");
         // have: accepted candidates the host knows of exactly; unc: candidates uploaded since whose acceptance only the device knows
         size_t have = 0, unc = 0;
         uint32_t* d_base = reinterpret_cast<uint32_t*>(dev + 2 * slot_bytes);
-        hip_check(ctx, hipMemsetAsync(d_base, 0, 4, cs), "memset");
+        hip_check(ctx, zero_fill_async(d_base, 4, cs), "clear");  // (the runtime's fill kernel waited 2 ms beside round 1's accumulations: fill.cuh)
         static const bool trace = getenv("SWM_TRACE") != nullptr;
         static const bool count_all = getenv("SWM_EXT_COUNT_ALL") != nullptr;  // (switch: the r02 - r04 behaviour, every run counted on the host)
         double t_cb = 0, t_count = 0, t_wait = 0;
@@ -760,61 +893,104 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        for (int b = 0;; b ^= 1) {
+        // What the host knows of the accepted count (second half of r05): behind every run the device's running total is copied
+        // into one of eight pinned words and an event recorded; before a run the host takes the NEWEST total that has arrived
+        // (hipEventQuery: no waiting) and treats the runs behind it as uncounted.  Where a run could complete the draw it counts
+        // the uncounted runs itself — the last two are still in the host ring, hot in its cache — and waits for the device only
+        // for older ones (never seen: the device lags by less than a run).  The first half of the round read the total back with
+        // a stream synchronisation where the bound got close: 3 - 4 round trips behind whatever the copy stream's kernels were
+        // waiting for, 3.1 ms of a 3 x 2^20 draw (SWM_EXT_READBACK=1).  A helper thread counting beside the callback was tried
+        // and dropped: the callback slowed from 33 to 48 ms (every line it writes is shared with the helper's core).
+        static const bool readback = getenv("SWM_EXT_READBACK") && atoi(getenv("SWM_EXT_READBACK")) != 0;
+        if (!ctx->ext_totals) hip_check(ctx, hipHostMalloc((void**)&ctx->ext_totals, EXT_TOTALS * sizeof(uint32_t), hipHostMallocDefault), "totals");
+        for (auto& e : ctx->ext_cnt_event)
+            if (!e) hip_check(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+        volatile uint32_t* totals = ctx->ext_totals;
+        constexpr size_t UNKNOWN = ~(size_t)0;
+        std::vector<float> ring_waits;  // (trace) per run: how long the host waited for its chunk of the ring
+        long j = 0, dev_upto = -1;  // runs uploaded; the newest run whose device total the host has
+        size_t dev_total = 0, told = 0;
+        size_t cands4[EXT_TOTALS] = {}, accm4[EXT_TOTALS] = {};  // per run (index mod 8): candidates, accepted as counted here
+        int buf4[EXT_TOTALS] = {};                                   // ... and the host chunk it was drawn into
+        auto take_total = [&](long i, bool wait) {  // the device's total behind run i
+            if (wait) hip_check(ctx, hipEventSynchronize(ctx->ext_cnt_event[i & (EXT_TOTALS - 1)]), "total");
+            dev_upto = i;
+            dev_total = totals[i & (EXT_TOTALS - 1)];
+        };
+        static const long ring = getenv("SWM_EXT_RING") ? std::min((long)EXT_RING, std::max(2l, atol(getenv("SWM_EXT_RING")))) : (long)EXT_RING;
+        for (;;) {
+            const int hb = (int)(j % ring), b = (int)(j & 1);  // host chunk and device slot of the next run
+            if (!readback) {
+                for (long i = j - 1; i > dev_upto && i + EXT_TOTALS >= j; i--)
+                    if (hipEventQuery(ctx->ext_cnt_event[i & (EXT_TOTALS - 1)]) == hipSuccess) {
+                        take_total(i, false);
+                        break;
+                    }
+                have = dev_total;
+                unc = 0;
+                for (long k = dev_upto + 1; k < j; k++) {
+                    if (accm4[k & (EXT_TOTALS - 1)] != UNKNOWN) have += accm4[k & (EXT_TOTALS - 1)];
+                    else unc += cands4[k & (EXT_TOTALS - 1)];
+                }
+                if (progress && std::min(have, need) > told) (*progress)(told = std::min(have, need));
+            }
             // a whole run cannot complete the draw even if every candidate of it (and of the uncounted runs before it) is accepted
             const bool blind = !count_all && have + unc + EXT_CHUNK <= need;
-            if (!blind && unc) {  // close to the end with uncounted runs behind us: ask the device how many it has accepted
+            if (!blind && unc) {  // close to the end with uncounted runs behind us
                 auto t0 = now();
-                uint32_t h = 0;
-                hip_check(ctx, hipMemcpyAsync(&h, d_base, 4, hipMemcpyDeviceToHost, cs), "d2h");
-                hip_check(ctx, hipStreamSynchronize(cs), "sync");
-                t_wait += ms(t0, now());
-                have = h;
-                unc = 0;
+                if (readback) {  // ask the device how many it has accepted
+                    uint32_t h = 0;
+                    hip_check(ctx, hipMemcpyAsync(&h, d_base, 4, hipMemcpyDeviceToHost, cs), "d2h");
+                    hip_check(ctx, hipStreamSynchronize(cs), "sync");
+                    have = h;
+                    unc = 0;
+                    t_wait += ms(t0, now());
+                    if (progress) (*progress)(told = std::min(have, need));
+                } else {
+                    // (the runs j - ring .. j - 1 are still in the host ring; older uncounted ones: the device's word)
+                    if (dev_upto + 1 < j - ring) take_total(j - ring - 1, true);
+                    auto t1 = now();
+                    for (long k = std::max(dev_upto + 1, j - ring); k < j; k++)
+                        if (accm4[k & (EXT_TOTALS - 1)] == UNKNOWN)
+                            accm4[k & (EXT_TOTALS - 1)] = ext_count_accepted(reinterpret_cast<const uint32_t*>((char*)ctx->ext_pinned + (size_t)buf4[k & (EXT_TOTALS - 1)] * EXT_CHUNK * sizeof(Fr)),
+                                                              cands4[k & (EXT_TOTALS - 1)]);
+                    t_wait += ms(t0, t1);
+                    t_count += ms(t1, now());
+                }
                 readbacks++;
-                b ^= 1;  // (this trip drew nothing: keep the ring's alternation)
-                continue;
+                continue;  // (this trip drew nothing)
             }
             if (!blind && have >= need) break;
             const size_t want = blind ? EXT_CHUNK : std::min(need - have, EXT_CHUNK);
-            uint32_t* buf = reinterpret_cast<uint32_t*>((char*)ctx->ext_pinned + (size_t)b * EXT_CHUNK * sizeof(Fr));
+            uint32_t* buf = reinterpret_cast<uint32_t*>((char*)ctx->ext_pinned + (size_t)hb * EXT_CHUNK * sizeof(Fr));
             auto t0 = now();
             // (the first trips of a draw as well: with the ring registered the copies are asynchronous, and the last run of the
             // PREVIOUS draw — the piece before this one, or the proof before — may still be reading the chunk)
-            hip_check(ctx, hipEventSynchronize(ctx->ext_event[b]), "ring");
+            hip_check(ctx, hipEventSynchronize(ctx->ext_event[hb]), "ring");
+            if (!readback && j >= EXT_TOTALS && dev_upto < j - EXT_TOTALS) take_total(j - EXT_TOTALS, true);  // its word and event are about to be reused
             auto t1 = now();
             rng.ext(rng.ext_user, reinterpret_cast<uint8_t*>(buf), want * 32);
             auto t2 = now();
             t_wait += ms(t0, t1);
             t_cb += ms(t1, t2);
+            if (trace) ring_waits.push_back((float)ms(t0, t1));
+            size_t counted = UNKNOWN;
             if (blind) {
                 unc += want;
             } else {
-                size_t acc = 0;
-                const uint32_t top_mask = 0xffffffffu >> 3, p7 = FrParams::P[7];
-                for (size_t i = 0; i < want; i++) {  // little-endian host: 8 x u32 limbs, low first; decided by the top limb
-                    const uint32_t* r = buf + 8 * i;  // in all but 2^-29 of the cases
-                    const uint32_t t = r[7] & top_mask;
-                    if (t != p7) {
-                        acc += t < p7;
-                    } else {
-                        bool lt = false;
-                        for (int k = 6; k >= 0; k--) {
-                            if (r[k] < FrParams::P[k]) { lt = true; break; }
-                            if (r[k] > FrParams::P[k]) break;
-                        }
-                        acc += lt;
-                    }
-                }
-                have += acc;
+                counted = ext_count_accepted(buf, want);
+                have += counted;
                 t_count += ms(t2, now());
             }
+            cands4[j & (EXT_TOTALS - 1)] = want;
+            accm4[j & (EXT_TOTALS - 1)] = counted;
+            buf4[j & (EXT_TOTALS - 1)] = hb;
             Fr* d_raw = reinterpret_cast<Fr*>(dev + (size_t)b * slot_bytes);
             uint32_t* d_flag = reinterpret_cast<uint32_t*>(d_raw + EXT_CHUNK);
             uint32_t* d_rank = d_flag + EXT_CHUNK;
             uint32_t* d_tot = d_rank + EXT_CHUNK;
             hip_check(ctx, hipMemcpyAsync(d_raw, buf, want * sizeof(Fr), hipMemcpyHostToDevice, cs), "h2d");
-            hip_check(ctx, hipEventRecord(ctx->ext_event[b], cs), "record");  // the host chunk may be refilled after the copy
+            hip_check(ctx, hipEventRecord(ctx->ext_event[hb], cs), "record");  // the host chunk may be refilled after the copy
             const unsigned grid = (unsigned)((want + 255) / 256), nt = (unsigned)((want + SC_TILE - 1) / SC_TILE);
             hipLaunchKernelGGL(sample_flag_raw, dim3(grid), dim3(256), 0, cs, d_raw, want, d_flag);
             hipLaunchKernelGGL(scan_totals, dim3(nt), dim3(SC_BLOCK), 0, cs, (const uint32_t*)d_flag, want, d_tot);
@@ -824,12 +1000,23 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
                                (const uint32_t*)d_rank, want, need, out, (const uint32_t*)d_base);
             hipLaunchKernelGGL(sample_base_add, dim3(1), dim3(1), 0, cs, d_base, (const uint32_t*)(d_tot + nt));  // the scan's total of the run
             hip_check(ctx, hipGetLastError(), "sample (caller-owned generator)");
+            if (!readback) {
+                hip_check(ctx, hipMemcpyAsync((void*)&totals[j & (EXT_TOTALS - 1)], d_base, 4, hipMemcpyDeviceToHost, cs), "total");
+                hip_check(ctx, hipEventRecord(ctx->ext_cnt_event[j & (EXT_TOTALS - 1)], cs), "record");
+            }
+            j++;
+            if (progress && !blind) (*progress)(told = std::max(told, std::min(have, need)));
         }
-        hip_check(ctx, hipEventRecord(ctx->ext_event[2], cs), "record");
-        hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ext_event[2], 0), "wait");
+        hip_check(ctx, hipEventRecord(ctx->ext_event[EXT_RING], cs), "record");
+        hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ext_event[EXT_RING], 0), "wait");
         if (trace)
             fprintf(stderr, "[swm trace]   bulk draw of %zu elements from the caller's generator: callback %.1f ms, counting %.1f ms, "
                             "waiting for the ring and %d read-backs %.1f ms\n", need, t_cb, t_count, readbacks, t_wait);
+        if (trace) {
+            fprintf(stderr, "[swm trace]   ring waits per run (ms):");
+            for (float w : ring_waits) fprintf(stderr, " %.2f", w);
+            fprintf(stderr, "\n");
+        }
         // the device ring is reused by the next draw: its kernels are ordered behind these on the copy stream
         return;
     }

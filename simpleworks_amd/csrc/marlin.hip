@@ -77,6 +77,10 @@ struct swm_pk {
         if (d_shifted28) (void)hipFree(d_shifted28);
         if (d_powers_te) (void)hipFree(d_powers_te);
         if (d_shifted_te) (void)hipFree(d_shifted_te);
+        for (auto& t : prefix_tab) {
+            if (t.te) (void)hipFree(t.te);
+            if (t.d28) (void)hipFree(t.d28);
+        }
     }
     IndexInfo info;
     uint64_t H = 0, K = 0, X = 0, B = 0;
@@ -100,12 +104,32 @@ struct swm_pk {
     // flat schedule runs on them and d_*28 are the n-point scaled copies only
     G1TE* d_powers_te = nullptr;
     G1TE* d_shifted_te = nullptr;
+    // r05 experiment (SWM_MSM_PREFIX_TABLES=1, off by default — see install_committer_key): NARROWER tables over PREFIXES of the powers.  The width of a table follows the size of its base set, but a key's
+    // commitments are not all of that size: with |K| = 2 |H| (the Merkle circuit of BASELINE config #5) the powers are 3 |K| =
+    // 6 |H| points (width 20: 2^19 buckets) while w, z_A, z_B, t, g_1 have |H| coefficients — 3 entries per bucket, and a
+    // bucket stage that costs five times their accumulation.  A prefix [0, |H| + 1) and a prefix [0, max(2 |H|, |K|) + 1) get a
+    // table of their own, of the width the rule gives for THAT many points (18 / 19 for the Merkle circuit: a quarter / half
+    // of the buckets for one more window); an MSM takes the smallest prefix it fits.  Only prefixes whose width comes out below
+    // the main table's are built (none at |H| = |K| = 2^20: everything is 20 wide there).  ~1.4 GB for the Merkle key.
+    struct PrefixTab {
+        size_t n = 0;
+        unsigned c = 0;
+        G1TE* te = nullptr;
+        G1Affine* d28 = nullptr;
+    };
+    PrefixTab prefix_tab[2];
     // bases for an MSM of n points starting at SRS power `offset`
     void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28, MsmTable* tab) const {
         *tab = MsmTable();
         if (offset + n <= n_powers) {
             *b = d_powers + offset;
             *b28 = d_powers28 + offset;
+            for (const PrefixTab& t : prefix_tab)
+                if (t.te && offset + n <= t.n) {
+                    *b28 = t.d28 + offset;
+                    *tab = MsmTable{nullptr, t.n, t.c, offset, t.te};
+                    return;
+                }
             if (tab_c) *tab = MsmTable{d_powers_te ? nullptr : d_powers28, n_powers, tab_c, offset, d_powers_te};
         } else if (offset >= shift_base && offset + n <= shift_base + n_shifted) {
             *b = d_shifted + (offset - shift_base);
@@ -615,12 +639,28 @@ struct CommitJob {
     // the rest has been summed into `extra`
     bool has_extra = false;
     G1XYZZ extra;
+    // the first commitment of a round as two MSMs (SWM_HEAD_SPLIT, experiment): `head` covers the first n >> k coefficients
+    bool has_head = false;
+    AsyncMsm head;
 };
 void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
-                     bool hiding, CommitJob* job) {
+                     bool hiding, CommitJob* job, bool first_of_round = false) {
     job->has_bound = has_bound;
     job->hiding = hiding;
-    commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
+    // Experiment (r05): nothing hides the sort of a round's FIRST commitment — no accumulation is in flight yet.  Split, the
+    // exposed sort is the head's (n >> k points) and the rest is sorted while the head accumulates; the price is one more
+    // bucket stage and host fold.  A commitment is a sum over coefficients: same group element.
+    static const int head_split = getenv("SWM_HEAD_SPLIT") ? std::min(6, std::max(0, atoi(getenv("SWM_HEAD_SPLIT")))) : 0;
+    static const size_t head_min = getenv("SWM_HEAD_MIN") ? (size_t)std::max(2l, atol(getenv("SWM_HEAD_MIN"))) : (size_t)1 << 18;
+    job->has_head = false;
+    if (first_of_round && head_split && ctx->shard_world <= 1 && n >= head_min && (n >> head_split) > 0) {
+        const size_t h = n >> head_split;
+        job->has_head = true;
+        commit_enqueue(ctx, lane, pk, 0, coeffs, h, &job->head);
+        commit_enqueue(ctx, lane, pk, h, coeffs + h, n - h, &job->plain);
+    } else {
+        commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
+    }
     if (has_bound) commit_enqueue(ctx, lane, pk, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
 }
 // The blinding half of pc_commit_end: the draws (plain first, then shifted) and the hiding terms sum_j r_j gamma^j G —
@@ -672,6 +712,7 @@ void pc_commit_end_round(swm_ctx* ctx, const swm_pk& pk, std::initializer_list<C
         if (!job->blinded) pc_commit_blind(pk, job, *rng, *pr);
         G1XYZZ plain = commit_wait(ctx, &job->plain);
         if (job->has_extra) g1_add(plain, job->extra);
+        if (job->has_head) g1_add(plain, commit_wait(ctx, &job->head));
         if (job->hiding) g1_add(plain, job->blind_plain);
         pts.push_back(plain);
         where.push_back({idx, false});
@@ -929,6 +970,29 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     // points are known to lie in the prime-order subgroup: SRS powers generated here are multiples of the generator,
     // deserialised keys went through the checks of their codec, an imported SRS is checked at import)
     rc_check(ctx, msm_install_bases(ctx, pk.d_powers, n_powers, in_subgroup, &pk.d_powers28, &pk.d_powers_te, &pk.tab_c));
+    // prefix tables (swm_pk::prefix_tab; SWM_MSM_PREFIX_TABLES=1): not for a rank of a sharded proof (its tables are narrower already
+    // and its commitments are split by blocks over the whole range)
+    // MEASURED r05, and off by default: 2^18 constraints 18.2 vs 18.0 ms without, Merkle circuit 18.0 vs 15.5 ms — these jobs are
+    // bound by the LATENCY of their chains, not by work: fewer buckets mean fewer, longer accumulation segments on a chip they do
+    // not fill (accumulation +14 % per launch), and the joint stage takes what its longest chain takes either way.
+    static const bool prefix_on = getenv("SWM_MSM_PREFIX_TABLES") && atoi(getenv("SWM_MSM_PREFIX_TABLES")) != 0;
+    if (prefix_on && pk.d_powers_te && ctx->shard_world <= 1 && pk.H) {
+        const size_t want[2] = {(size_t)pk.H + 1, (size_t)std::max<uint64_t>(2 * pk.H, pk.K) + 1};
+        int k = 0;
+        for (size_t np : want) {
+            if (np < 4096 || 2 * np > n_powers || (k && np <= pk.prefix_tab[k - 1].n)) continue;
+            if (msm_table_width(np) == 0 || msm_table_width(np) >= pk.tab_c) continue;
+            swm_pk::PrefixTab t;
+            t.n = np;
+            rc_check(ctx, msm_install_bases(ctx, pk.d_powers, np, in_subgroup, &t.d28, &t.te, &t.c));
+            if (!t.te || t.c >= pk.tab_c) {  // no room for it, or no narrower after all: the main table serves
+                if (t.te) (void)hipFree(t.te);
+                if (t.d28) (void)hipFree(t.d28);
+                continue;
+            }
+            pk.prefix_tab[k++] = t;
+        }
+    }
     if (n_shifted) {
         rc_check(ctx, msm_install_bases(ctx, pk.d_shifted, n_shifted, in_subgroup, &pk.d_shifted28, &pk.d_shifted_te, &pk.shtab_c));
     } else {
@@ -1113,9 +1177,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // transforms cost.
     static const bool commit_early = getenv("SWM_COMMIT_LATE") == nullptr;
     std::vector<std::function<void()>> late;
-    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job) {
+    // which commitments start with no accumulation in flight (bit = tag: 0 mask, 1 w, 2 z_A / z_B, 3 t, 4 h_1, 5 g_1, 6 g_2, 7 h_2)
+    static const unsigned head_mask = getenv("SWM_HEAD_MASK") ? (unsigned)strtoul(getenv("SWM_HEAD_MASK"), nullptr, 0) : 0xd9u;
+    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job, int tag) {
         if (commit_early) {
-            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
+            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job, (head_mask >> tag) & 1);
         } else {
             late.push_back([&, coeffs, n, has_bound, bound, hiding, job] {
                 pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
@@ -1152,17 +1218,28 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     auto draw_mask = [&] {
         Fr* mp = mask.p;
         if (mask_pieces > 1) {
-            // thirds of |H| coefficients in stream order (the candidates are consumed exactly as by one draw of 3|H|: a draw stops
-            // right behind the candidate that completes it); three pieces: [1, H) | [H, 2H) | [2H, 3H), two: [1, H) | [H, 3H)
+            // ONE draw of 3|H| coefficients; whenever the host learns how many are in place (sample_fr_bulk: `progress`) the pieces
+            // that are complete are committed: [1, H) | [H, 2H) | [2H, 3H) (three pieces; two: [1, H) | [H, 3H)).  One draw, not
+            // three: every draw ends with a geometric tail of ever shorter runs (a run may not reach beyond the candidate that
+            // completes the draw), ~1.5 ms each.
             j1[3].has_bound = false;
             j1[3].hiding = false;
-            sample_fr_bulk(ctx, zk, mp, H, mask_late);
-            commit_enqueue(ctx, &lane, pk, 1, mp + 1, H - 1, &j1[3].plain);
-            sample_fr_bulk(ctx, zk, mp + H, H, true);   // (marked: the destination is the buffer marked above, nothing else touches it)
-            if (mask_pieces == 3) commit_enqueue(ctx, &lane, pk, H, mp + H, H, &mask_part[0]);
-            sample_fr_bulk(ctx, zk, mp + 2 * H, H, true);
-            if (mask_pieces == 3) commit_enqueue(ctx, &lane, pk, 2 * H, mp + 2 * H, H, &mask_part[1]);
-            else commit_enqueue(ctx, &lane, pk, H, mp + H, 2 * H, &mask_part[0]);
+            unsigned done_pieces = 0;
+            hipEvent_t piece_ev = nullptr;
+            hip_check(ctx, hipEventCreateWithFlags(&piece_ev, hipEventDisableTiming), "event");
+            auto enqueue_piece = [&](unsigned pc) {  // the elements of the piece are written by kernels already on the copy stream
+                hip_check(ctx, hipEventRecord(piece_ev, ctx->copy_stream), "record");
+                hip_check(ctx, hipStreamWaitEvent(ctx->stream, piece_ev, 0), "wait");
+                if (pc == 0) commit_enqueue(ctx, &lane, pk, 1, mp + 1, H - 1, &j1[3].plain);
+                else if (mask_pieces == 3) commit_enqueue(ctx, &lane, pk, pc * H, mp + pc * H, H, &mask_part[pc - 1]);
+                else if (pc == 2) commit_enqueue(ctx, &lane, pk, H, mp + H, 2 * H, &mask_part[0]);
+            };
+            const std::function<void(size_t)> progress = [&](size_t have) {
+                while (done_pieces < 2 && have >= (size_t)(done_pieces + 1) * H) enqueue_piece(done_pieces++);
+            };
+            sample_fr_bulk(ctx, zk, mp, mask_len, mask_late, &progress);
+            while (done_pieces < 3) enqueue_piece(done_pieces++);  // (after the draw ctx->stream waits for all of it anyway)
+            (void)hipEventDestroy(piece_ev);
         } else {
             sample_fr_bulk(ctx, zk, mask.p, mask_len, mask_late);
         }
@@ -1171,14 +1248,14 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
         });
         P_mask.p = mask.p; P_mask.n = mask_len;
-        if (mask_pieces == 1 && mask_commit_at == 0) begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+        if (mask_pieces == 1 && mask_commit_at == 0) begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3], 0);
     };
     // (experiment, built-in generator: the mask is sampled at the start either way — the draw fixes the generator's position for
     // the blinding draws — but its 3|H|-point commitment can be enqueued behind w's (1) or behind z_B's (2) instead of first (0):
     // an accumulation in flight starves the small kernels that prepare w, z_A and z_B)
     auto commit_mask_at = [&](int where) {
         if (!mask_late && mask_pieces == 1 && mask_commit_at == where && where != 0)
-            begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3]);
+            begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3], 0);
     };
     if (mask_late) sample_fr_ext_mark(ctx);  // the transfers of the late draw only wait for what precedes the allocation
     else draw_mask();
@@ -1279,7 +1356,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const Fr* w_coeffs = w_poly.p + X;  // quotient[j] = s[j + X]
     const size_t w_len = H + 1 - X;
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
-    begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0]);
+    begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0], 1);
     commit_mask_at(1);
     DVec za_poly = dv_zeros(ctx, H + 1), zb_poly = dv_zeros(ctx, H + 1);
     // sharded form of "interpolate, add rho v_H, commit" for one of the two polynomials
@@ -1319,8 +1396,12 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
     P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
     if (!shard_r1) {
-        begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1]);
-        begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2]);
+        // (enqueue order only: the results are awaited and blinded in label order.  SWM_R1_ORDER=1: z_B's commitment ahead of
+        // z_A's — an MSM whose scalars are almost all zero has an accumulation too short to hide the sort of the job behind it)
+        static const bool zb_first = getenv("SWM_R1_ORDER") && atoi(getenv("SWM_R1_ORDER")) == 1;
+        if (zb_first) begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2], 2);
+        begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1], 2);
+        if (!zb_first) begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2], 2);
     }
     commit_mask_at(2);
     tr.mark("round 1 polynomials");
@@ -1481,7 +1562,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     tr.tick("r2: t polynomial enqueued");
     CommitJob j2[3];
     P_t.p = t_poly.p; P_t.n = H;
-    begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0]);  // overlaps the 4|H|-domain work below
+    begin_commit(P_t.p, P_t.n, false, 0, false, &j2[0], 3);  // overlaps the 4|H|-domain work below
     DVec q1(ctx, Mloc);  // the whole product domain, or the rank's share of it (shard_r2)
     {
         if (!ra_closed_form) {
@@ -1554,8 +1635,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     {
         P_g1.p = g1x.p + 1; P_g1.n = H - 1; P_g1.has_bound = true; P_g1.bound = H - 2; P_g1.hiding = true;
         P_h1.p = h1.p; P_h1.n = 2 * H + 1;  // degree <= 2|H| + 2 zk_bound - 2 (higher slots are zero)
-        begin_commit(P_h1.p, P_h1.n, false, 0, false, &j2[2]);  // largest first
-        begin_commit(P_g1.p, P_g1.n, true, H - 2, true, &j2[1]);
+        begin_commit(P_h1.p, P_h1.n, false, 0, false, &j2[2], 4);  // largest first
+        begin_commit(P_g1.p, P_g1.n, true, H - 2, true, &j2[1], 5);
         flush_commits();
         // the sumcheck remainder check needs a download; do it while the MSMs run
         Fr rem0 = g1x.download(0, 1)[0];
@@ -1599,7 +1680,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     CommitJob j3[2];
     P_g2.p = f.p + 1; P_g2.n = K - 1; P_g2.has_bound = true; P_g2.bound = K - 2;
-    begin_commit(P_g2.p, P_g2.n, true, K - 2, false, &j3[0]);  // overlaps the 4|K|-domain work below
+    begin_commit(P_g2.p, P_g2.n, true, K - 2, false, &j3[0], 6);  // overlaps the 4|K|-domain work below
     // h_2 = (a - b f) / v_K via evaluations on the 4K domain
     DVec h2(ctx, 3 * K);
     // Round 3 over G ranks, the same way as round 2 (shard_r2 above): f into the 4|K| domain, the pointwise form a - b f (the key's
@@ -1685,7 +1766,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     tr.mark("round 3 polynomials");
     std::vector<Commitment> comms3(2);
     P_h2.p = h2.p; P_h2.n = 3 * K >= 3 ? 3 * K - 3 : 0;  // degree <= 3|K| - 4
-    begin_commit(P_h2.p, P_h2.n, false, 0, false, &j3[1]);
+    begin_commit(P_h2.p, P_h2.n, false, 0, false, &j3[1], 7);
     flush_commits();
     // ================= evaluations, part 1: everything asked at beta depends on rounds 1-2 only, so it is enqueued here
     // and runs under the round-3 commitments

@@ -2379,6 +2379,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // 32 by 10 % at 2^20 and 2^22, loses at 2^16 where 45 k buckets cannot fill 196 k lane slots).
     uint32_t SEG = pl.NB >= 262144 ? SEG_MAX : 32;  // smaller bounds for small MSMs measured within run-to-run noise
     if (lat) SEG = 16;  // (8 below 2^16 points until r04: with four lanes per segment the chain per entry is 2 products, not 7)
+    // (r05, prefix tables: a job of |H| points on a table one bit narrower than before has ~14 entries per bucket — with 16-point
+    // segments a quarter of the buckets would split in two and the bucket stage walk 2.3 instead of 2 steps per bucket)
+    if (lat && total / pl.NB >= 10) SEG = 32;
     if (const char* e = getenv("SWM_MSM_SEG")) SEG = std::min<uint32_t>(SEG_MAX, std::max(1, atoi(e)));
     // segments per bucket above which a bucket is folded ahead of the bucket stage, and the lanes that fold one
     uint32_t big_nseg = BIG_NSEG;
@@ -2772,6 +2775,36 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
     return SWM_OK;
 }
 
+// Shape of a JOINT stage (r05): the jobs of one launch share the chip, so they share its 256 CUs — the smallest common number
+// of buckets per lane (a power of two from 4) with which the workgroups of all k jobs fit one per CU.  One job: 8 per lane on
+// every CU (the wide shape); two 2^19-bucket jobs: 16 per lane, 128 workgroups each; four: 32 per lane; a round of three
+// 2^17-bucket jobs and one of 2^19 (the Merkle circuit's round 1 with its prefix tables): 16 per lane, 32 + 32 + 32 + 128.
+// (r02 - r04: 64 workgroups per job whatever the job.)  SWM_MSM_JOINT_ADAPT=0: that rule.
+static void msm_joint_shape(MsmJob** jobs, size_t k) {
+    static const bool adapt = !(getenv("SWM_MSM_JOINT_ADAPT") && atoi(getenv("SWM_MSM_JOINT_ADAPT")) == 0);
+    if (!adapt || getenv("SWM_MSM_LOGM")) return;
+    for (size_t i = 0; i < k; i++)  // one-lane 256-chain stages over ONE bucket set, no bucket-range share
+        if (jobs[i]->rb != 256 || jobs[i]->quad || jobs[i]->pl.nwin != 1 || jobs[i]->blk_lo != 0 || jobs[i]->blk_low != 0 ||
+            jobs[i]->blk_hi != jobs[i]->red_blocks)
+            return;
+    for (unsigned log_m = 2; log_m <= 10; log_m++) {
+        unsigned total = 0;
+        bool ok = true;
+        for (size_t i = 0; i < k; i++) {
+            const unsigned nb = std::max(1u, ((jobs[i]->pl.maxB >> log_m) + 255u) / 256u);
+            ok = ok && nb <= jobs[i]->max_blocks;
+            total += nb;
+        }
+        if (!ok || total > 256) continue;
+        for (size_t i = 0; i < k; i++) {
+            jobs[i]->log_m = log_m;
+            jobs[i]->red_blocks = std::max(1u, ((jobs[i]->pl.maxB >> log_m) + 255u) / 256u);
+            jobs[i]->blk_hi = jobs[i]->red_blocks;
+        }
+        return;
+    }
+}
+
 // Launches the deferred bucket stages (all jobs enqueued with defer_tail since the last flush), TAIL_MAX per launch.
 int msm_flush_tails(swm_ctx* ctx) {
     SWM_TRY(msm_launch_lazy_tail(ctx, true));  // nothing follows it before the round's results are awaited
@@ -2782,6 +2815,7 @@ int msm_flush_tails(swm_ctx* ctx) {
         while (i + k < jobs.size() && k < TAIL_MAX && jobs[i + k]->rb == jobs[i]->rb && jobs[i + k]->te == jobs[i]->te &&
                jobs[i + k]->quad == jobs[i]->quad && jobs[i + k]->low == jobs[i]->low)
             k++;
+        msm_joint_shape(jobs.data() + i, k);
         SWM_TRY(msm_launch_tails(ctx, jobs.data() + i, (int)k));
         i += k;
     }

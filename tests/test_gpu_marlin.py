@@ -639,7 +639,10 @@ def test_sharded_prover_with_window_tables_2p17(M, S, W, world, monkeypatch):
         adds = [r[2]["msm_adds"] for r in ranks]
         assert max(adds) < 2.2 * sum(adds) / world            # the shares are of the same order (uniform scalars)
         totals.append(sum(adds))
-    assert totals[0] == totals[1] == totals[2] >= work1["msm_adds"], (totals, work1["msm_adds"])   # narrower tables: more windows per point
+    # every split accumulates the same digits; the single context is of the same order (its commitments of |H| coefficients take
+    # a narrower PREFIX table — more windows per point —, a rank of eight takes narrower tables for everything)
+    assert totals[0] == totals[1] == totals[2], totals
+    assert 0.85 * work1["msm_adds"] < totals[0] < 1.25 * work1["msm_adds"], (totals, work1["msm_adds"])
     assert M.verify_proof(S.deserialize_verifying_key(vk1), public, S.deserialize_proof(proof1), M.generate_rand())
 
 

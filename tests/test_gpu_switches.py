@@ -70,6 +70,12 @@ def test_switches_select_equivalent_paths():
                 {"SWM_MSM_TAILS": "2", "SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
                 {"SWM_MSM_JOINT_BLOCKS": "16", "SWM_MASK_COMMIT": "2"},
                 {"SWM_SORT_NARROW": "2", "SWM_MSM_LAT_BELOW": "0"},   # 256-lane partition and bin sort (co-resident with an accumulation)
+                {"SWM_MSM_PREFIX_TABLES": "1"},                        # narrower tables over prefixes of the powers (|H| + 1 points)
+                {"SWM_MSM_JOINT_ADAPT": "0", "SWM_R1_ORDER": "1"},     # 64 workgroups per job in a joint stage; z_B committed ahead of z_A
                 # the caller-owned generator's draw: one piece / two pieces of the mask commitment, every run counted on the host
-                {"SWM_MASK_PIECES": "1", "SWM_EXT_COUNT_ALL": "1"}, {"SWM_MASK_PIECES": "2"}):
+                {"SWM_MASK_PIECES": "1", "SWM_EXT_COUNT_ALL": "1"}, {"SWM_MASK_PIECES": "2"},
+                {"SWM_EXT_READBACK": "1", "SWM_EXT_RING": "2"},   # stream-synchronising read-backs of the device's total; two host chunks
+                {"SWM_REC_LAZY": "0", "SWM_BINV_LAZY": "0"},      # recurrences and batch inversion on the 8 x 32-bit Comba multiplier
+                # the first commitment of a round (w, t, h_1, g_1, g_2, h_2 with mask 0xfa: at most 8 MSMs in flight) as two MSMs, also for the small circuits
+                {"SWM_HEAD_SPLIT": "2"}, {"SWM_HEAD_SPLIT": "3", "SWM_HEAD_MASK": "0xfa", "SWM_HEAD_MIN": "64"}):
         assert _run(env) == ref, env

@@ -9,10 +9,12 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --steps 10 --warmup 2 > $out/bench_prove.json 2> $out/bench_prove.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in > $out/bench_prove_driver_flags.json 2>> $out/bench_prove.err   # the driver's flags
+python3 bench.py --log-n 22 --steps 4 --warmup 1 --no-cpu-baseline --no-drop-in > $out/bench_prove_2p22.json 2>> $out/bench_prove.err
 python3 bench.py --circuit merkle --steps 10 --warmup 2 > $out/bench_merkle.json 2> $out/bench_merkle.err
 python3 bench.py --workload msm --steps 12 --warmup 2 > $out/bench_msm.json 2> $out/bench_msm.err
 python3 bench.py --workload msm --log-n 22 --steps 8 --warmup 2 --cpu-log-n 18 > $out/bench_msm_2p22.json 2> $out/bench_msm22.err
-rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_prove.log 2>&1
+SWM_PROOF_MARKS=1 rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_prove.log 2>&1
 python3 tools/trace_share.py $out/prof_prove/run_kernel_trace.csv > $out/timeline_share.txt 2>&1
 python3 tools/trace_dump.py $out/prof_prove/run_kernel_trace.csv 15 > $out/trace_dump.txt 2>&1
 python3 tools/rocprof_region.py $out/prof_prove/run_kernel_trace.csv msm_accumulate 75 > $out/region_prove.json
@@ -53,3 +55,11 @@ for lg in "20 8" "22 3"; do
 done
 SWM_SHARD_EMULATE=1 python3 tools/ubench/ntt_sharded_one.py 22 24 > $out/ntt_sharded_one.jsonl 2> $out/ntt_sharded_one.err
 ls -R $out | head -40
+# r05: what the issue priorities (csrc/ff.cuh SWM_LIGHT_PRIO / SWM_TAIL_PRIO) are worth — the same sources built with both at 0
+# (build/libswmarlin_p0.so: bash tools/buildvar.sh p0 -DSWM_LIGHT_PRIO=0 -DSWM_TAIL_PRIO=0), alternating on this box; and
+# the joint bucket stage / the low-LDS kernel at the mid sizes
+if [ -f build/libswmarlin_p0.so ]; then
+  bash tools/envab.sh 3 "" "SWM_LIB_PATH=$PWD/build/libswmarlin_p0.so" 2>&1 | sed "s|$PWD/||" > $out/prio_ab.log
+  ROUNDS=2 bash tools/sweep_mid.sh $out/mid_sweep.log "16 18 merkle" "" "SWM_MSM_BATCH_BELOW=200000" "SWM_MSM_LOW=1" "SWM_MSM_LOW=1 SWM_MSM_JOINT_BLOCKS=128" "SWM_LIB_PATH=$PWD/build/libswmarlin_p0.so" > /dev/null 2>&1
+  sed -i "s|$PWD/||" $out/mid_sweep.log
+fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel durations (rocprofv3 --kernel-trace --stats) of the bucket stage and the accumulation inside proofs of one size under a
-# list of environment settings:   bash tools/kstats.sh <outdir> <log_n> "<ENV A>" "<ENV B>" ...
+# list of environment settings:   [KSTATS_MORE=batch_inverse,ntt_pass] bash tools/kstats.sh <outdir> <log_n> "<ENV A>" "<ENV B>" ...
 o=$1; lg=$2; shift 2
 mkdir -p $o
 i=0
@@ -12,7 +12,7 @@ for e in "$@"; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if any(k in n for k in ("bucket_reduce", "msm_accumulate", "big_bucket")):
+    if any(k in n for k in ("bucket_reduce", "msm_accumulate", "big_bucket") + tuple(filter(None, __import__("os").environ.get("KSTATS_MORE", "").split(",")))):
         print("    %-46s calls %4s  avg %8.1f us  total %8.2f ms" % (n.split("(")[0].replace("swm::", "").replace("void ", "")[:46], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 P
   rm -rf $o/k$i
