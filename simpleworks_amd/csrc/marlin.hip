@@ -1647,7 +1647,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         commit_gather(ctx, {&j2[0].plain, &j2[1].plain, &j2[1].shifted, &j2[2].plain});
         pc_commit_end_round(ctx, pk, {&j2[0], &j2[1], &j2[2]}, {nullptr, &zk, nullptr}, {&P_t.rand, &P_g1.rand, &P_h1.rand},
                             comms2.data());
-        if (unsat) throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
+        // (SWM_SHARD_EMULATE, measurement hook of tools/ubench/shard_emulate.py: one context plays a rank and its device exchanges
+        // hand back its own chunks — the values are wrong by construction and only the time is of interest)
+        static const bool emulated = getenv("SWM_SHARD_EMULATE") != nullptr;
+        if (unsat && !(emulated && ctx->shard_world > 1))
+            throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
     }
     tr.mark("round 2 commitments");
     fs_absorb_commitments(fs, comms2);
@@ -1838,7 +1842,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         const Fr& pt = std::string(q.point) == "beta" ? beta : gamma;
         Fr v = provider(q.label, lcs.at(q.label), pt);
         if (lc_has_zero_eval(q.label)) {
-            if (!fp_is_zero(v)) throw MarlinError(SWM_ERR_UNSATISFIED, std::string(q.label) + " does not evaluate to zero: constraint system is not satisfied");
+            static const bool emulated = getenv("SWM_SHARD_EMULATE") != nullptr;  // (see the outer sumcheck's check)
+            if (!fp_is_zero(v) && !(emulated && ctx->shard_world > 1))
+                throw MarlinError(SWM_ERR_UNSATISFIED, std::string(q.label) + " does not evaluate to zero: constraint system is not satisfied");
             continue;
         }
         evals.push_back({q.label, v});

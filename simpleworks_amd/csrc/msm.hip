@@ -1714,9 +1714,12 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
 //     stores behind it (te28_slot_add_sync) — the unified law reads all eight input coordinates before it writes any;
 //   * the weighted sum of a lane lives in HBM / L2 (job.acc: touched once per bucket, 384 B per step against ~4 400
 //     instructions) and moves into the lane's LDS slot with the step that folds the suffix into it; the tree runs there;
-// (256 + 1) x 192 B = 49 KB per workgroup: three workgroups per CU, three waves per SIMD (156 VGPRs) — the issue port is kept
-// busy by the other workgroups' chains, and a stage no longer owns its CU.  Same micro-operations in the same order per lane as
-// msm_bucket_reduce<RB, FormTE>: the same limbs, the same workgroup results.
+// (256 + 1) x 192 B = 49 KB per workgroup, 171 VGPRs: two workgroups per CU by registers (three: 35 spills, slower), and a stage
+// no longer owns its CU.  Same micro-operations in the same order per lane as msm_bucket_reduce<RB, FormTE>: the same limbs, the
+// same workgroup results.
+// Where it is used (measured, CHANGELOG r05): in the JOINT stage of a round's deferred jobs (up to 10^6 points each), one
+// workgroup per CU — 0.1 - 0.3 ms per mid-size proof; NOT for the thin stages that run beside the accumulations of large jobs
+// (two workgroups per CU there: each step 2.2x slower, +0.8 ms at 2^20).  SWM_MSM_LOW = 2 (default) / 1 (everywhere) / 0 (never).
 #ifndef SWM_LOW_WAVES
 #define SWM_LOW_WAVES 2  // waves per SIMD the register budget allows (3: 168 VGPRs, spills 37 of them)
 #endif
@@ -2178,10 +2181,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const bool quad = lat && te && quad_on && flat_rb != 64 && pl.maxB <= quad_maxb;
     const unsigned rb = quad ? (quad_rb == 256 ? 256u : (quad_rb == 128 ? 128u : 64u)) : (flat ? (flat_rb == 64 ? 64u : 256u) : 256u);
     job->quad = quad;
-    // One-lane twisted Edwards stages take the low-LDS kernel (msm_bucket_reduce_low: 49 KB per workgroup, three per CU);
-    // SWM_MSM_LOW=0: the 144-KB kernel of r02 - r04.  SWM_MSM_LOW_BLOCKS: workgroups a stage may be cut into (result slot:
+    // One-lane twisted Edwards stages may take the low-LDS kernel (msm_bucket_reduce_low: 49 KB per workgroup);
+    // SWM_MSM_LOW=0: always the 144-KB kernel of r02 - r04.  SWM_MSM_LOW_BLOCKS: workgroups a stage may be cut into (result slot:
     // up to 1024 (A, R) pairs; the host folds them in groups of 16).
-    static const bool low_on = getenv("SWM_MSM_LOW") && atoi(getenv("SWM_MSM_LOW")) != 0;  // (off: measured r05, see msm_bucket_reduce_low)
+    // r05, last collection: in the JOINT stage of deferred jobs (shaped by msm_joint_shape) it is worth 0.1 - 0.3 ms per mid-size
+    // proof (2^16 7.2 -> 7.07, 2^18 17.2 -> 16.9, Merkle circuit 15.0 -> 14.7 ms); for the thin stages of large jobs it costs
+    // 0.8 ms at 2^20 (two workgroups per CU).  SWM_MSM_LOW: 2 (default) = joint stages only, 1 = every one-lane stage, 0 = never.
+    static const int low_mode = getenv("SWM_MSM_LOW") ? atoi(getenv("SWM_MSM_LOW")) : 2;
+    const bool low_on = low_mode == 1 || (low_mode == 2 && defer_tail);
     static const unsigned low_blocks = getenv("SWM_MSM_LOW_BLOCKS") ? (unsigned)std::min(1024, std::max(16, atoi(getenv("SWM_MSM_LOW_BLOCKS")))) : 256u;
     // (joint stages of small jobs: SWM_MSM_JOINT_BLOCKS workgroups per job — with the low-LDS kernel twelve waves per CU are resident)
     // 64 per job: the four stages of a round's launch are resident together, one workgroup per CU — in the low-latency schedule

@@ -4,7 +4,7 @@
 //!
 //! How arkworks values cross the boundary
 //! * `&mut StdRng`         -> through `swm_rng_from_callback` over a `fill_bytes` trampoline (the caller's stream, word for
-//!                            word, at the caller's speed: r05 measured 79 ms per 2^20 proof against the 50.6-ms headline, which
+//!                            word, at the caller's speed: r05 measured 77 - 79 ms per 2^20 proof against the 50-ms headline, which
 //!                            is the built-in generator — see `drop_in_rng` in the bench line); with the cargo feature
 //!                            `adopt-std-rng` by STATE — `swm_rng_from_chacha(seed, word position)`, position written back
 //!                            afterwards: the library then produces the ChaCha12 stream itself (on the GPU for the 3|H| mask

@@ -63,9 +63,9 @@ def test_switches_select_equivalent_paths():
                 {"SWM_MSM_QUAD_RB": "256", "SWM_MSM_QUAD_BLOCKS": "16"},
                 {"SWM_MSM_QUAD_ACC": "0", "SWM_FLAT_PART_TILE": "8192"},  # one lane per segment in small accumulations; 8 K-digit partition tiles
                 {"SWM_MSM_TABLE_C": "15"},      # narrower window tables (what a rank of a sharded proof takes)
-                # r05: the low-LDS bucket stage (joint launches of the 2^17 jobs; alone, re-shaped up to 512 workgroups, a barrier
+                # r05: the low-LDS bucket stage everywhere / nowhere (default: joint launches only; alone, re-shaped up to 512 workgroups, a barrier
                 # behind every step), two bucket-stage streams, smaller joint stages, the mask commitment enqueued last
-                {"SWM_MSM_LOW": "1"},
+                {"SWM_MSM_LOW": "1"}, {"SWM_MSM_LOW": "0"},
                 {"SWM_MSM_LOW": "1", "SWM_MSM_LOW_BLOCKS": "512", "SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0", "SWM_LOW_SYNC_ALL": "1"},
                 {"SWM_MSM_TAILS": "2", "SWM_MSM_LAT_BELOW": "0", "SWM_MSM_BATCH_BELOW": "0"},
                 {"SWM_MSM_JOINT_BLOCKS": "16", "SWM_MASK_COMMIT": "2"},

@@ -7,8 +7,11 @@ usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_RANGE
 import json, os, sys, time
 # the sharded rounds 1 and 2 exchange DATA the rest of the proof depends on (an emulated exchange makes the prover's own checks
 # fail): they are measured apart (tools/ubench/ntt_sharded_one.py); here every transform runs whole on the rank
-os.environ.setdefault("SWM_SHARD_R1_OFF", "1")
-os.environ.setdefault("SWM_SHARD_R2_OFF", "1")
+# (SWM_SHARD_EMULATE=1: try them sharded as well, with the library's device exchanges handing back this rank's own chunk)
+ROUNDS_SHARDED = bool(os.environ.get("SWM_SHARD_EMULATE"))
+if not ROUNDS_SHARDED:
+    os.environ.setdefault("SWM_SHARD_R1_OFF", "1")
+    os.environ.setdefault("SWM_SHARD_R2_OFF", "1")
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import simpleworks_amd as swm
@@ -43,7 +46,7 @@ for G in ([int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]):
         dt = (time.perf_counter() - t0) / steps
         ctx.profile_enable(False)
         prof = ctx.profile()
-        print(json.dumps({"log_n": lg, "split": mode, "ranks": G, "rank": rank, "ms_per_proof_on_this_rank": dt * 1e3,
+        print(json.dumps({"log_n": lg, "split": mode, "rounds": "sharded" if ROUNDS_SHARDED else "whole", "ranks": G, "rank": rank, "ms_per_proof_on_this_rank": dt * 1e3,
                           "msm_adds": ctx.last_work.get("msm_adds"), "accumulate_ms": prof.get("msm_accumulate", {}).get("total_ms", 0) / steps}),
               flush=True)
     pk.free()
