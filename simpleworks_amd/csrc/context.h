@@ -103,6 +103,9 @@ struct swm_ctx {
     hipStream_t copy_stream = nullptr;
     void* ext_pinned = nullptr;  // the ring's four host chunks (page-aligned host memory, registered with the runtime: see sample_fr_bulk)
     bool ext_registered = false;
+    // MSMs below this many points run sort, accumulation and bucket stage on ONE stream of their lane (0: the library's default,
+    // 131 072).  The prover sets it per proof: all of a small proof's commitments the same way (msm.hip, msm_enqueue)
+    size_t msm_pipe_min = 0;
     unsigned msm_since_wait = 0;  // MSM jobs enqueued since the last msm_finish*: 0 = nothing of this context is in flight
     uint32_t* ext_totals = nullptr;  // eight pinned words: the device's running total behind each of the last eight runs of a draw
     hipEvent_t ext_cnt_event[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and when each has arrived

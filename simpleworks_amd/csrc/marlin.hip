@@ -1161,6 +1161,16 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     std::vector<Fr> public_input(pr.inst.begin() + 1, pr.inst.end());
     FiatShamirRng fs;
     fs_init(fs, pk.vk, public_input);
+    // every commitment of a small proof on ONE stream of its lane (msm_enqueue: a proof that mixes single-stream and pipelined
+    // jobs runs them on aliasing streams); SWM_PROVE_ONE_STREAM_LOG: the largest log2 |H| this applies to
+    // (default 19, 0 = never; measured r05, alternating runs: 2^16 7.0 -> 6.5 ms, 2^17 11.2 -> 10.8, 2^18 17.7 -> 17.5, 2^19 29.4 -> 28.6,
+    // Merkle circuit 15.0 -> 14.7; at 2^20 the pipelined form is 1 ms ahead: 49.6 vs 50.6)
+    struct PipeMinScope {
+        swm_ctx* c;
+        ~PipeMinScope() { c->msm_pipe_min = 0; }
+    } pipe_scope{ctx};
+    static const unsigned one_stream_log = getenv("SWM_PROVE_ONE_STREAM_LOG") ? (unsigned)atoi(getenv("SWM_PROVE_ONE_STREAM_LOG")) : 19u;
+    ctx->msm_pipe_min = pk.logH <= one_stream_log ? ~(size_t)0 : 0;
 
     // ---- the zero-knowledge draws of round 1 do not depend on the witness: rho_w, rho_a, rho_b, then the mask polynomial
     // (arkworks' order).  The mask is sampled and its commitment — the largest MSM of the round, 3|H| points — enqueued

@@ -2218,7 +2218,13 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // (two accumulations may overlap: one alone leaves bubbles at the end of its length-sorted grid).  Small MSMs keep
     // the single stream: the extra event hops cost more than they hide.
     static const int pipe_mode = getenv("SWM_MSM_PIPE") ? atoi(getenv("SWM_MSM_PIPE")) : 2;
-    static const size_t pipe_min = getenv("SWM_MSM_PIPE_MIN") ? (size_t)atol(getenv("SWM_MSM_PIPE_MIN")) : 131072;
+    // r05: a proof whose commitments fall on both sides of the bound ran them on streams that alias (a small job's lane stream is
+    // a large job's accumulation or bucket-stage stream): at 2^16 constraints — 65 535-point and 196 608-point commitments — the
+    // opening's second sort waited for the first accumulation.  The prover therefore sets ctx->msm_pipe_min per proof (every
+    // commitment of a proof up to 2^19 constraints on one stream of its lane, four lanes: 2^16 7.05 -> 6.5 ms, 2^19 29.4 -> 28.6 ms;
+    // from 2^20 on the three-stage pipeline is ahead.  SWM_MSM_PIPE_MIN overrides both).
+    static const long pipe_env = getenv("SWM_MSM_PIPE_MIN") ? atol(getenv("SWM_MSM_PIPE_MIN")) : -1;
+    const size_t pipe_min = pipe_env >= 0 ? (size_t)pipe_env : (ctx->msm_pipe_min ? ctx->msm_pipe_min : (size_t)131072);
     const bool one_stream = pipe_mode == 0 || n < pipe_min;
     if (lane >= 0) {
         // small MSMs: four single-stream lanes (scratch sets 0 .. 3 on the streams 1, 2, 3, 0), so that the launch chains of

@@ -75,6 +75,7 @@ def test_switches_select_equivalent_paths():
                 # the caller-owned generator's draw: one piece / two pieces of the mask commitment, every run counted on the host
                 {"SWM_MASK_PIECES": "1", "SWM_EXT_COUNT_ALL": "1"}, {"SWM_MASK_PIECES": "2"},
                 {"SWM_EXT_READBACK": "1", "SWM_EXT_RING": "2"},   # stream-synchronising read-backs of the device's total; two host chunks
+                {"SWM_PROVE_ONE_STREAM_LOG": "0"},                 # commitments of small proofs pipelined over three streams from 131 072 points (r02 - r04)
                 {"SWM_REC_LAZY": "0", "SWM_BINV_LAZY": "0"},      # recurrences and batch inversion on the 8 x 32-bit Comba multiplier
                 # the first commitment of a round (w, t, h_1, g_1, g_2, h_2 with mask 0xfa: at most 8 MSMs in flight) as two MSMs, also for the small circuits
                 {"SWM_HEAD_SPLIT": "2"}, {"SWM_HEAD_SPLIT": "3", "SWM_HEAD_MASK": "0xfa", "SWM_HEAD_MIN": "64"}):

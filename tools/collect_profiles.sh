@@ -42,7 +42,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-include-regex spmv -d $out/pmc_spmv_write -o
 python3 tools/ubench/ntt_one.py 22 10 > $out/ntt_one.json 2> $out/ntt_one.err
 python3 tools/ubench/spmv_one.py 20 10 > $out/spmv_one.json 2> $out/spmv_one.err
 python3 tools/ubench/ntt_time.py > $out/ntt_time.log 2>&1
-python3 tools/small_proofs.py 10 12 14 16 18 > $out/small_proofs.log 2>&1
+python3 tools/small_proofs.py 10 12 14 16 17 18 19 > $out/small_proofs.log 2>&1
 # the Pedersen Merkle tree of config #5 (2^18 leaves) beside the CPU oracle on 2^14 leaves, and its kernel stats
 python3 tools/ubench/merkle_build.py 18 5 14 > $out/merkle_build.json 2> $out/merkle_build.err
 rocprofv3 --kernel-trace --stats -d $out/prof_merkle_build -o run --output-format csv -- python3 tools/ubench/merkle_build.py 18 3 0 > $out/prof_merkle_build.log 2>&1
@@ -64,6 +64,6 @@ ls -R $out | head -40
 # the joint bucket stage / the low-LDS kernel at the mid sizes
 if [ -f build/libswmarlin_p0.so ]; then
   bash tools/envab.sh 3 "" "SWM_LIB_PATH=$PWD/build/libswmarlin_p0.so" 2>&1 | sed "s|$PWD/||" > $out/prio_ab.log
-  ROUNDS=2 bash tools/sweep_mid.sh $out/mid_sweep.log "16 18 merkle" "" "SWM_MSM_LOW=0" "SWM_MSM_BATCH_BELOW=200000" "SWM_MSM_LOW=1 SWM_MSM_JOINT_BLOCKS=128" "SWM_LIB_PATH=$PWD/build/libswmarlin_p0.so" > /dev/null 2>&1
+  ROUNDS=2 bash tools/sweep_mid.sh $out/mid_sweep.log "16 18 merkle" "" "SWM_PROVE_ONE_STREAM_LOG=0" "SWM_MSM_LOW=0" "SWM_MSM_BATCH_BELOW=200000" "SWM_LIB_PATH=$PWD/build/libswmarlin_p0.so" > /dev/null 2>&1
   sed -i "s|$PWD/||" $out/mid_sweep.log
 fi

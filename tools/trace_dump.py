@@ -16,7 +16,7 @@ import os
 _mk = os.environ.get("TRACE_MARK") or ("swm_proof_begin" if any(x[2].startswith("swm_proof_begin") for x in ev) else "sample_candidates")
 marks = []
 for s, e, k, q in ev:
-    if k.startswith(_mk) and (not marks or s - marks[-1] > 10e6):
+    if k.startswith(_mk) and (not marks or s - marks[-1] > float(os.environ.get("TRACE_MARK_GAP_MS", "10")) * 1e6):  # (small proofs: 2)
         marks.append(s)
 t0, t1 = marks[-2], marks[-1]
 acc = [(s, e) for s, e, k, q in ev if k.startswith("msm_accumulate")]
