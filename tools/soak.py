@@ -1,3 +1,5 @@
+"""Soak: proofs of seven sizes (2^10 .. 2^20 constraints) interleaved on one context, 40 rounds, every proof verified; every fourth
+round draws through the caller-owned generator's callback.  usage: python3 tools/soak.py"""
 import sys, time
 sys.path.insert(0, ".")
 from simpleworks_amd import marlin as M, workloads as W
@@ -14,7 +16,8 @@ t0 = time.time(); cnt = 0; bad = 0
 for rep in range(40):
     for lg, cs, public, pk, vk in keys:
         if lg == 20 and rep % 2: continue
-        proof = M.generate_proof(cs, pk, rng)
+        # every fourth repetition through the fill_bytes callback (the caller-owned generator's path: host ring, mask in pieces)
+        proof = M.generate_proof(cs, pk, M.rng_behind_callback(M.generate_rand()) if rep % 4 == 3 else rng)
         ok = M.verify_proof(vk, public, proof, M.generate_rand())
         cnt += 1; bad += (not ok)
 print("soak: %d proofs, %d rejected, %.1f s" % (cnt, bad, time.time() - t0))
