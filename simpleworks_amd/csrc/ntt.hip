@@ -206,10 +206,7 @@ __device__ __forceinline__ Fr29 tile_get(const uint32_t* tile, unsigned idx) {
     return x;
 }
 template <int J>
-#ifndef SWM_NTT_MIN_BLOCKS
-#define SWM_NTT_MIN_BLOCKS 4  // waves per SIMD the register budget is cut for (4: 128 VGPRs allowed, 105 used)
-#endif
-__global__ void __launch_bounds__(NTT_THREADS, SWM_NTT_MIN_BLOCKS) ntt_pass_lazy(NttLazyArgs args) {
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_lazy(NttLazyArgs args) {
     SWM_LIGHT_KERNEL();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);  // [R][J] elements of 9 words
