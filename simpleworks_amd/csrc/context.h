@@ -106,6 +106,9 @@ struct swm_ctx {
     // MSMs below this many points run sort, accumulation and bucket stage on ONE stream of their lane (0: the library's default,
     // 131 072).  The prover sets it per proof: all of a small proof's commitments the same way (msm.hip, msm_enqueue)
     size_t msm_pipe_min = 0;
+    // largest size requested so far for each kind of per-slot MSM scratch (hist, bucket_off, seg_off, big_list, points, acc): a
+    // slot's buffer is always grown to that, not to what its current job needs (msm.hip, msm_enqueue)
+    size_t msm_slot_bytes[6] = {0, 0, 0, 0, 0, 0};
     unsigned msm_since_wait = 0;  // MSM jobs enqueued since the last msm_finish*: 0 = nothing of this context is in flight
     uint32_t* ext_totals = nullptr;  // eight pinned words: the device's running total behind each of the last eight runs of a draw
     hipEvent_t ext_cnt_event[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and when each has arrived

@@ -1944,8 +1944,11 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             });
         }
         // witness = p / (X - point) against the powers; degree-bounded members: shifted witnesses against the shifted powers
+        tr.tick(pi == 0 ? "open beta: combination enqueued" : "open gamma: combination enqueued");
         o.wq = div_linear(ctx, o.comb.p, plen, point);
+        tr.tick("  witness quotient enqueued");
         commit_enqueue(ctx, &lane, pk, 0, o.wq.work.p + 1, plen ? plen - 1 : 0, &o.wjob);
+        tr.tick("  witness commitment enqueued");
         o.sq.resize(o.shifted_terms.size());
         o.sjobs.resize(o.shifted_terms.size());
         for (size_t i = 0; i < o.shifted_terms.size(); i++) {
@@ -1955,10 +1958,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             Fr* q = o.sq[i].work.p;
             size_t qn = stt.lp->n ? stt.lp->n - 1 : 0;
             ew(ctx, "open_scale", qn, [=] __device__(size_t t) { q[t + 1] = fp_mul(q[t + 1], k); });
+            tr.tick("  shifted quotient enqueued");
             commit_enqueue(ctx, &lane, pk, pk.srs_max_degree - stt.lp->bound, q + 1, qn, &o.sjobs[i]);
+            tr.tick("  shifted commitment enqueued");
         }
     }
     commit_flush(ctx);  // both opening points: up to four bucket stages, one launch
+    tr.tick("open: bucket stages enqueued");
     // hiding terms of the two witnesses and the random evaluations: host work that does not depend on the MSMs in flight
     G1XYZZ hide[2];
     PcProof pps[2];

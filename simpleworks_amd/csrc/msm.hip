@@ -2380,6 +2380,14 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->stream = st;
     char nm[10][32];
     const char* base[10] = {"hist", "segs", "bucket_off", "seg_off", "digits", "sorted", "scan_tot", "big_list", "points", "pairs"};
+    // Per-slot buffers are sized by the LARGEST request any slot has seen, not by the job at hand (r05): the eight result slots
+    // rotate through the jobs of successive proofs (15 jobs per Merkle-circuit proof: a slot meets a different commitment every
+    // proof), and a slot that had only held 131 072-point jobs grew — all streams synchronised, hipFree, hipMalloc: 2.4 ms with
+    // the GPU idle — when a 786 432-point job reached it, somewhere in each of the first dozen proofs of a key.
+    auto slot_scratch = [&](int kind, size_t bytes) {
+        if (bytes > ctx->msm_slot_bytes[kind]) ctx->msm_slot_bytes[kind] = bytes;
+        return ctx->msm_slot_bytes[kind];
+    };
     // what the deferred bucket stage of a job still reads (histogram block with the status words, bucket / segment offsets,
     // big-bucket list, partial sums) is kept per result SLOT; the rest is per lane (stream-ordered reuse)
     for (int i = 0; i < 10; i++) {
@@ -2473,7 +2481,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
                               (flat ? (2 + 3 * (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 + 32 : 0);
     zero_words = (zero_words + 63) & ~(size_t)63;  // whole 256-byte lines: the runtime then clears them with one kernel, not two
-    SWM_TRY(scratch(ctx, nm[0], zero_words * 4, (void**)&hist));
+    SWM_TRY(scratch(ctx, nm[0], slot_scratch(0, zero_words * 4), (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
@@ -2492,24 +2500,24 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_TRY(scratch(ctx, nm[1], nseg_max * 12, (void**)&seg_start));
     seg_len = seg_start + nseg_max;
     order = seg_len + nseg_max;
-    SWM_TRY(scratch(ctx, nm[2], (pl.NB + 1) * 4ull, (void**)&bucket_off));
-    SWM_TRY(scratch(ctx, nm[3], (pl.NB + 1) * 4ull, (void**)&seg_off));
+    SWM_TRY(scratch(ctx, nm[2], slot_scratch(1, (pl.NB + 1) * 4ull), (void**)&bucket_off));
+    SWM_TRY(scratch(ctx, nm[3], slot_scratch(2, (pl.NB + 1) * 4ull), (void**)&seg_off));
     SWM_TRY(scratch(ctx, nm[4], total * 4, (void**)&digits));
     SWM_TRY(scratch(ctx, nm[5], total * 4, (void**)&sorted));
     const unsigned scan_tiles = (pl.NB + SCAN_TILE - 1) / SCAN_TILE;
     SWM_TRY(scratch(ctx, nm[6], (size_t)(scan_tiles + 1) * 8, (void**)&tot_cnt));
     tot_seg = tot_cnt + scan_tiles + 1;
-    SWM_TRY(scratch(ctx, nm[7], (size_t)pl.NB * 4, (void**)&big_list));
+    SWM_TRY(scratch(ctx, nm[7], slot_scratch(3, (size_t)pl.NB * 4), (void**)&big_list));
     // XYZZ scratch: partial[nseg_max] | wpart[nwin * red_blocks * 2]
     G1XYZZ *partial, *wpart;
     const size_t wpart_n = (size_t)rl.nwin * std::max(red_blocks, flat ? job->max_blocks : 0u) * 2;
-    SWM_TRY(scratch(ctx, nm[8], (nseg_max + wpart_n) * sizeof(G1XYZZ), (void**)&partial));
+    SWM_TRY(scratch(ctx, nm[8], slot_scratch(4, (nseg_max + wpart_n) * sizeof(G1XYZZ)), (void**)&partial));
     wpart = partial + nseg_max;
     job->d_acc = nullptr;
     if (low) {  // the lanes' weighted sums of the low-LDS bucket stage: one point per lane, per result slot like `partial`
         char nma[32];
         snprintf(nma, sizeof(nma), "msmS%d.acc", slot);
-        SWM_TRY(scratch(ctx, nma, (size_t)rl.nwin * job->max_blocks * 256 * sizeof(G1XYZZ), (void**)&job->d_acc));
+        SWM_TRY(scratch(ctx, nma, slot_scratch(5, (size_t)rl.nwin * job->max_blocks * 256 * sizeof(G1XYZZ)), (void**)&job->d_acc));
     }
 
     SWM_HIP(ctx, zero_fill_async(hist, zero_words * 4, ctx->stream));  // (a kernel with issue priority, not the runtime's fill: fill.cuh)
