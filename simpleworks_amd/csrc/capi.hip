@@ -55,6 +55,8 @@ void drain_streams(swm_ctx* ctx) {
 int scratch(swm_ctx* ctx, const char* name, size_t bytes, void** out) {
     DevBuf& b = ctx->scratch[name];
     if (b.cap < bytes) {
+        static const bool trace = getenv("SWM_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[swm scratch] %s grows %zu -> %zu%s\n", name, b.cap, bytes, b.p ? " (all streams synchronised)" : "");
         if (b.p) {
             // in-flight kernels — on this stream or on one of the MSM stage streams — may still read the old buffer
             SWM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -89,6 +91,8 @@ int pool_alloc(swm_ctx* ctx, size_t bytes, void** out, size_t* cap) {
         ctx->pool.erase(it);
         return SWM_OK;
     }
+    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[swm pool] miss: hipMalloc(%zu) (%zu cached blocks)\n", bytes, ctx->pool.size());
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {
         // release cached blocks and retry once
