@@ -77,3 +77,19 @@ def test_bench_times_an_r1cs_dump(tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "merkle_h4.r1cs" in line["config"]["workload"] and line["config"]["per_gpu_units"] == cs.pack().num_constraints
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_overlapped_contexts():
+    """`bench.py --overlap 2`: two contexts on the one GPU, a key and a host thread each, proving concurrently after the timed loop; the
+    line carries the `overlapped` object and `value` is still the one-proof-at-a-time figure."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-drop-in", "--overlap", "2"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ov = line["overlapped"]
+    assert ov["contexts"] == 2 and ov["proofs"] == 6 and ov["ms_per_proof"] > 0
+    assert abs(line["value"] - (1 << 14) / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
