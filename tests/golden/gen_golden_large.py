@@ -259,7 +259,8 @@ def case_simple_merkle_tree():
 CASES = {"synthetic_2p12": lambda: case_synthetic(12), "synthetic_2p16": lambda: case_synthetic(16),
          "merkle_h5": case_merkle_h5}
 # not part of the default run (tens of minutes and several GB of Python integers): python gen_golden_large.py synthetic_2p18
-EXTRA_CASES = {"synthetic_2p18": lambda: case_synthetic(18), "synthetic_2p19": lambda: case_synthetic(19), "synthetic_2p20": lambda: case_synthetic(20),
+EXTRA_CASES = {"synthetic_2p14": lambda: case_synthetic(14), "synthetic_2p17": lambda: case_synthetic(17),
+               "synthetic_2p18": lambda: case_synthetic(18), "synthetic_2p19": lambda: case_synthetic(19), "synthetic_2p20": lambda: case_synthetic(20),
                "simple_merkle_tree": case_simple_merkle_tree, "test_circuit": case_test_circuit}
 
 if __name__ == "__main__":

@@ -670,7 +670,7 @@ def test_proving_key_roundtrip_2p16_and_table_schedule(M, S, W):
 
 # ---- proof bytes at real sizes (BASELINE config #2: "2^16 ... bit-exact vs CPU").  tests/golden/marlin_large.json comes
 # from the independent Python prover with the C restatement of the arkworks kernels plugged in (gen_golden_large.py).
-@pytest.mark.parametrize("name", ["synthetic_2p12", "synthetic_2p16", "synthetic_2p18", "synthetic_2p19", "synthetic_2p20"])
+@pytest.mark.parametrize("name", ["synthetic_2p12", "synthetic_2p14", "synthetic_2p16", "synthetic_2p17", "synthetic_2p18", "synthetic_2p19", "synthetic_2p20"])
 def test_golden_proof_bytes_at_size(M, S, W, name):
     case = golden("marlin_large.json")[name]
     rng = M.generate_rand()
