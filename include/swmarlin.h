@@ -197,14 +197,44 @@ int swm_srs_power_of_g(swm_ctx *ctx, const swm_srs *srs, size_t i, uint64_t out_
 /* generate_proving_and_verifying_keys (src/marlin/mod.rs:88-94): MarlinInst::index_from_constraint_system */
 int swm_generate_proving_and_verifying_keys(swm_ctx *ctx, const swm_srs *srs, const swm_r1cs *cs, swm_pk **pk,
                                             swm_vk **vk);
+/* A proving key is resident per DEVICE, read-only once built, and reference-counted: the handle returned by
+ * swm_generate_proving_and_verifying_keys / swm_pk_deserialize carries one reference, and ANY context on the key's device may
+ * prove with it — several contexts (one per host thread) at the same time: scratch, streams and result slots are the
+ * context's, the key is only read.  One resident copy (committer key, window tables, index tables: 13 GB at 2^20
+ * constraints) serves every proving thread of the process, and outlives the context that built it.
+ *   swm_pk_retain    one more reference (a second owner of the same handle, e.g. a process-wide key cache);
+ *   swm_pk_attach    the same, after checking that `ctx` runs on the key's device (SWM_ERR_MISMATCH otherwise);
+ *   swm_pk_destroy   drops one reference (draining `ctx`, which may be NULL, first); the last one frees the key;
+ *   swm_pk_device / swm_pk_refcount   the key's device / its current reference count (diagnostics, tests). */
 void swm_pk_destroy(swm_ctx *ctx, swm_pk *pk);
+int swm_pk_retain(swm_pk *pk);
+int swm_pk_attach(swm_ctx *ctx, swm_pk *pk);
+int swm_pk_device(const swm_pk *pk);
+int swm_pk_refcount(const swm_pk *pk);
 void swm_vk_destroy(swm_vk *vk);
 
 /* generate_proof (src/marlin/mod.rs:70-77): MarlinInst::prove_from_constraint_system(&pk, cs, rng).
  * Writes the CanonicalSerialize bytes of the proof (<= 1024 B).  SWM_ERR_UNSATISFIED when the witness does not
- * satisfy the constraints (the reference panics on a debug assertion inside ark-marlin at this point). */
+ * satisfy the constraints (the reference panics on a debug assertion inside ark-marlin at this point).
+ * ASSIGNMENT ONLY: the prover reads num_instance, num_witness, num_constraints, instance and witness of `cs` and nothing
+ * else — the matrices are the key's (as in ark-marlin, whose prover_init takes them from the index and never calls
+ * to_matrices() at prove time), so the nine matrix pointers of `cs` may be NULL and a binding need not flatten A, B, C per
+ * proof.  A shape that does not match the key is SWM_ERR_MISMATCH (ark-marlin: InstanceDoesNotMatchIndex).  `ctx` must run
+ * on the key's device (SWM_ERR_MISMATCH otherwise); it need not be the context that built the key. */
 int swm_generate_proof(swm_ctx *ctx, const swm_pk *pk, const swm_r1cs *cs, swm_rng *rng, uint8_t *proof_out,
                        size_t cap, size_t *len);
+/* The same proof in the form CanonicalSerialize::serialize_uncompressed writes (flags = SWM_PROOF_UNCOMPRESSED; <= 2048 B): every
+ * G1 point as x, y with the infinity flag in the top bits of y's last byte, everything else unchanged.  For a binding that turns
+ * the bytes back into an arkworks `Proof` in the same process: `Proof::deserialize_unchecked` on this form costs microseconds,
+ * where the checked `Proof::deserialize` of the compressed form takes a square root and a subgroup check per commitment (~2.3 ms
+ * for a proof, measured on the library's own checked reader: `drop_in.proof_deserialize_proxy_ms` in the bench line) — the bytes
+ * come from this library, not from an untrusted peer.  flags = 0 is swm_generate_proof.
+ * swm_proof_recode converts between the two forms on the host (checked parse of the input form; out == NULL reports the length):
+ * serialize(deserialize_unchecked(uncompressed bytes)) on the Rust side gives the bytes swm_generate_proof would have written. */
+#define SWM_PROOF_UNCOMPRESSED 1u
+int swm_generate_proof_ex(swm_ctx *ctx, const swm_pk *pk, const swm_r1cs *cs, swm_rng *rng, unsigned flags,
+                          uint8_t *proof_out, size_t cap, size_t *len);
+int swm_proof_recode(const uint8_t *bytes, size_t len, int to_uncompressed, uint8_t *out, size_t cap, size_t *out_len);
 
 /* verify_proof (src/marlin/mod.rs:79-86).  public_inputs: n x 4 Montgomery limbs (without the leading one).
  * Host-only (two pairings); needs no GPU and no context. */
@@ -296,6 +326,8 @@ int swm_exchange_stats(swm_ctx *ctx, uint64_t *calls, uint64_t *bytes_per_rank);
  *  "work":{"msm_calls","msm_points","msm_digits" (points x windows),"msm_adds" (non-zero digits = mixed additions),
  *          "ntt_calls","ntt_elements","spmv_calls","spmv_rows","spmv_nnz"}} into buf. */
 int swm_profile_enable(swm_ctx *ctx, int on);
+/* hipMemGetInfo on the context's device: HBM free / total in bytes (what a resident key costs, tests and bench) */
+int swm_device_mem_info(swm_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 int swm_profile_reset(swm_ctx *ctx);
 int swm_profile_json(swm_ctx *ctx, char *buf, size_t buflen);
 

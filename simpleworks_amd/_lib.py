@@ -68,8 +68,15 @@ ABI = {
     "swm_srs_import": (_int, [_vp, _u64p, _sz, _u64p, _u64p, _u64p, ctypes.POINTER(_vp)]),
     "swm_generate_proving_and_verifying_keys": (_int, [_vp, _vp, ctypes.c_void_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "swm_pk_destroy": (None, [_vp, _vp]),
+    "swm_pk_retain": (_int, [_vp]),
+    "swm_pk_attach": (_int, [_vp, _vp]),
+    "swm_pk_device": (_int, [_vp]),
+    "swm_pk_refcount": (_int, [_vp]),
+    "swm_device_mem_info": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "swm_vk_destroy": (None, [_vp]),
     "swm_generate_proof": (_int, [_vp, _vp, ctypes.c_void_p, _vp, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
+    "swm_generate_proof_ex": (_int, [_vp, _vp, ctypes.c_void_p, _vp, ctypes.c_uint, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
+    "swm_proof_recode": (_int, [ctypes.c_void_p, _sz, _int, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
     "swm_verify_proof": (_int, [_vp, _u64p, _sz, ctypes.c_void_p, _sz, _vp, ctypes.POINTER(_int)]),
     "swm_vk_serialize": (_int, [_vp, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]),
     "swm_vk_deserialize": (_int, [ctypes.c_void_p, _sz, ctypes.POINTER(_vp)]),
@@ -195,6 +202,7 @@ class Context:
         if rc != 0:
             raise SwmError(rc, "swm_init")
         self.h = h
+        self.device = device
 
     def close(self):
         if self.h:
@@ -216,6 +224,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.swm_synchronize(self.h), "swm_synchronize")
+
+    def mem_info(self):
+        """swm_device_mem_info: (free, total) bytes of HBM on the context's device."""
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self.lib.swm_device_mem_info(self.h, ctypes.byref(free), ctypes.byref(total)), "swm_device_mem_info")
+        return free.value, total.value
 
     ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 

@@ -77,12 +77,21 @@ struct DBuf {
         return *this;
     }
     ~DBuf() { release(); }
+    // Hands the block over from the context's pool to its holder: a detached buffer belongs to no context (a proving key is
+    // resident per DEVICE and may outlive the context that built it, swm_pk) and goes back to the runtime when it is released.
+    // Every pool block is a hipMalloc of its own, so nothing else changes.  The methods below that enqueue on ctx->stream are
+    // not for detached buffers.
+    void detach() { ctx = nullptr; }
     void release() {
         if (p) {
-            // unwinding after a failure: kernels queued on the main or the auxiliary MSM streams may still read this
-            // block; wait for them before it returns to the pool (idle streams make this a no-op)
-            if (std::uncaught_exceptions() > 0) drain_streams(ctx);
-            pool_free(ctx, p, cap);
+            if (!ctx) {
+                (void)hipFree(p);
+            } else {
+                // unwinding after a failure: kernels queued on the main or the auxiliary MSM streams may still read this
+                // block; wait for them before it returns to the pool (idle streams make this a no-op)
+                if (std::uncaught_exceptions() > 0) drain_streams(ctx);
+                pool_free(ctx, p, cap);
+            }
         }
         p = nullptr;
     }

@@ -24,6 +24,10 @@ struct HDomain {
     unsigned log;
     Fr gen, gen_inv, size_inv, size_fr;
     explicit HDomain(uint64_t n) {
+        // Fr has two-adicity 47: ark-poly's Radix2EvaluationDomain::new returns None beyond that and ark-marlin turns it into
+        // PolynomialDegreeTooLarge.  Without the bound a size above 2^63 (a mutated verifying key's num_constraints: found by the
+        // r06 sanitizer run) overflows the doubling below into an endless loop.
+        if (n > (1ull << 47)) throw MarlinError(SWM_ERR_INVALID_ARG, "PolynomialDegreeTooLarge: no radix-2 domain of that size in Fr");
         size = 1;
         log = 0;
         while (size < n) {

@@ -87,7 +87,24 @@ struct ByteWriter {
         tb_g1(c.has_shifted ? c.shifted : g1_affine_identity());
     }
     // ---- CanonicalSerialize
+    // uncompressed = true: G1 points as serialize_uncompressed writes them [U: ark-ec 0.3 short_weierstrass_jacobian.rs] — x, then
+    // y with the flags in the top bits of ITS last byte: infinity (bit 6) or none (SWFlags::default() = NegativeY = no bit); the
+    // identity is GroupAffine::zero() = (0, 1, infinity).  Field elements, lengths and Option tags are the same in both forms.
+    bool uncompressed = false;
     void ser_g1(const G1Affine& p) {  // compressed: x with flags in the top bits of the last byte
+        if (uncompressed) {
+            uint8_t u[96];
+            if (g1_is_inf(p)) {
+                fp_to_bytes(fp_zero<Fq>(), u);
+                fp_to_bytes(fp_one<Fq>(), u + 48);
+                u[95] |= 0x40;
+            } else {
+                fp_to_bytes(p.x, u);
+                fp_to_bytes(p.y, u + 48);
+            }
+            raw(u, 96);
+            return;
+        }
         uint8_t t[48];
         if (g1_is_inf(p)) {
             memset(t, 0, 48);
@@ -120,6 +137,7 @@ struct ByteWriter {
 struct ByteReader {
     const uint8_t* p;
     size_t n, pos = 0;
+    bool uncompressed = false;  // G1 points in the serialize_uncompressed form (ByteWriter::uncompressed); still CHECKED here
     ByteReader(const uint8_t* d, size_t len) : p(d), n(len) {}
     const uint8_t* take(size_t k) {
         if (k > n - pos) throw MarlinError(SWM_ERR_SERIALIZATION, "unexpected end of input");  // (pos <= n always: no wrap for a huge k)
@@ -144,6 +162,19 @@ struct ByteReader {
         return r;
     }
     G1Affine g1() {
+        if (uncompressed) {  // deserialize_uncompressed: x, y | flags, then on-curve (this reader: always) and subgroup checks
+            uint8_t u[96];
+            memcpy(u, take(96), 96);
+            uint8_t fl = u[95] & 0xC0;
+            u[95] &= 0x3F;
+            if (fl == 0xC0) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 invalid flags");
+            G1Affine r;
+            if (!fp_from_bytes(u, &r.x) || !fp_from_bytes(u + 48, &r.y)) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 coordinate out of range");
+            if (fl & 0x40) return g1_affine_identity();
+            if (!fp_eq(fp_sqr(r.y), fp_add(fp_mul(fp_sqr(r.x), r.x), fp_one<Fq>()))) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 point not on curve");
+            if (!g1_is_inf(g1_mul_limbs(r, FrParams::P, 8))) throw MarlinError(SWM_ERR_SERIALIZATION, "G1 point not in the prime-order subgroup");
+            return r;
+        }
         uint8_t t[48];
         memcpy(t, take(48), 48);
         uint8_t flags = t[47] & 0xC0;
@@ -195,8 +226,9 @@ struct ByteReader {
 };
 
 // ------------------------------------------------------------------------------------------------ proof / vk codecs
-inline std::vector<uint8_t> serialize_proof(const Proof& pr) {
+inline std::vector<uint8_t> serialize_proof(const Proof& pr, bool uncompressed = false) {
     ByteWriter w;
+    w.uncompressed = uncompressed;
     w.u64(pr.commitments.size());
     for (auto& rnd : pr.commitments) {
         w.u64(rnd.size());
@@ -218,8 +250,9 @@ inline std::vector<uint8_t> serialize_proof(const Proof& pr) {
     return w.b;
 }
 
-inline Proof deserialize_proof(const uint8_t* data, size_t len) {
+inline Proof deserialize_proof(const uint8_t* data, size_t len, bool uncompressed = false) {
     ByteReader r(data, len);
+    r.uncompressed = uncompressed;
     Proof pr;
     uint64_t nr = r.u64();
     if (nr > 16) throw MarlinError(SWM_ERR_SERIALIZATION, "bad round count");

@@ -82,6 +82,20 @@ struct swm_pk {
             if (t.d28) (void)hipFree(t.d28);
         }
     }
+    // A key is resident per DEVICE, read-only once built and reference-counted (swm_pk_retain / swm_pk_attach /
+    // swm_pk_destroy): any context on that device proves with it, several at once — the prover takes it by const reference
+    // and every per-proof buffer, stream and result slot belongs to the context.  The key's device blocks are detached from
+    // the pool of the context that built them (own_blocks) so that the key may outlive that context.
+    int device = 0;
+    std::atomic<int> refs{1};
+    void own_blocks() {
+        for (DevCsr* m : {&a, &b, &c, &at, &bt, &ct}) {
+            m->rowptr.detach(); m->col.detach(); m->val.detach(); m->plan_chunks.detach(); m->plan_lrows.detach();
+        }
+        for (MatrixArith& m : ar)
+            for (DVec* v : {&m.row, &m.col, &m.val, &m.row_col, &m.row_K, &m.col_K, &m.val_K, &m.row_B, &m.col_B, &m.val_B, &m.row_col_B})
+                v->detach();
+    }
     IndexInfo info;
     uint64_t H = 0, K = 0, X = 0, B = 0;
     unsigned logH = 0, logK = 0, logX = 0, logB = 0;
@@ -1001,6 +1015,14 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     hip_check(ctx, hipStreamSynchronize(ctx->stream), "sync");
 }
 
+// A finished key leaves the context that built it: everything that context still has in flight for it is awaited (another
+// context's streams are not ordered behind this one's), and its blocks stop belonging to this context's pool.
+void pk_publish(swm_ctx* ctx, swm_pk& pk) {
+    drain_streams(ctx);
+    pk.device = ctx->device;
+    pk.own_blocks();
+}
+
 void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** out_pk, swm_vk** out_vk) {
     PaddedR1cs p = pad_and_square(cs);
     std::unique_ptr<swm_pk> pk(new swm_pk());
@@ -1066,6 +1088,7 @@ void index_impl(swm_ctx* ctx, const swm_srs* srs, const swm_r1cs* cs, swm_pk** o
     }
     std::unique_ptr<swm_vk> v(new swm_vk());
     v->vk = vk;
+    pk_publish(ctx, *pk);
     *out_pk = pk.release();
     *out_vk = v.release();
 }
@@ -1127,7 +1150,7 @@ void upload_small(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     }
     hip_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "h2d");
 }
-std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk) {
+std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk, bool uncompressed = false) {
     PhaseTrace tr(ctx);
     static const bool proof_marks = getenv("SWM_TRACE") != nullptr || getenv("SWM_PROOF_MARKS") != nullptr;
     if (proof_marks) hipLaunchKernelGGL(swm_proof_begin, dim3(1), dim3(1), 0, ctx->stream);
@@ -1999,7 +2022,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     }
     tr.mark("openings");
     proof.commitments = {comms1, comms2, comms3};
-    return serialize_proof(proof);
+    return serialize_proof(proof, uncompressed);
 }
 
 
@@ -2291,6 +2314,7 @@ swm_pk* pk_deserialize(swm_ctx* ctx, const uint8_t* bytes, size_t len) {
     pk->ct = upload_csr(ctx, transpose(pk->hc, ncols));
     const HostCsr* hm[3] = {&pk->ha, &pk->hb, &pk->hc};
     for (int i = 0; i < 3; i++) arithmetize(ctx, *pk, *hm[i], pk->ar[i]);
+    pk_publish(ctx, *pk);
     return pk.release();
 }
 
@@ -2418,17 +2442,56 @@ int swm_generate_proving_and_verifying_keys(swm_ctx* ctx, const swm_srs* srs, co
 }
 void swm_pk_destroy(swm_ctx* ctx, swm_pk* pk) {
     if (!pk) return;
-    swm::DeviceGuard g(ctx);
-    if (ctx) drain_streams(ctx);
+    {
+        swm::DeviceGuard g(ctx);
+        if (ctx) drain_streams(ctx);  // what THIS holder still has in flight on the key
+    }
+    if (pk->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;  // other holders remain
+    // last holder: the blocks go back to the runtime.  Every holder drained its own context when it let go; a holder that
+    // passed ctx == NULL did not, so the device is awaited once here (destroying a multi-GB key is not a hot path)
+    const int dev = pk->device;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    const bool there = hipSetDevice(dev) == hipSuccess;
+    if (there) (void)hipDeviceSynchronize();
     delete pk;
+    if (there && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+}
+int swm_pk_retain(swm_pk* pk) {
+    if (!pk) return SWM_ERR_INVALID_ARG;
+    pk->refs.fetch_add(1, std::memory_order_relaxed);
+    return SWM_OK;
+}
+int swm_pk_attach(swm_ctx* ctx, swm_pk* pk) {
+    if (!ctx || !pk) return SWM_ERR_INVALID_ARG;
+    if (ctx->device != pk->device)
+        return set_err(ctx, SWM_ERR_MISMATCH, "swm_pk_attach: the key is resident on device %d, the context runs on device %d", pk->device,
+                       ctx->device);
+    pk->refs.fetch_add(1, std::memory_order_relaxed);
+    return SWM_OK;
+}
+int swm_pk_device(const swm_pk* pk) { return pk ? pk->device : SWM_ERR_INVALID_ARG; }
+int swm_pk_refcount(const swm_pk* pk) { return pk ? pk->refs.load(std::memory_order_relaxed) : SWM_ERR_INVALID_ARG; }
+int swm_device_mem_info(swm_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return SWM_ERR_INVALID_ARG;
+    SWM_ON_DEVICE(ctx);
+    SWM_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return SWM_OK;
 }
 
 int swm_generate_proof(swm_ctx* ctx, const swm_pk* pk, const swm_r1cs* cs, swm_rng* rng, uint8_t* proof_out, size_t cap,
                        size_t* len) {
-    if (!ctx || !pk || !cs || !rng || !proof_out || !len) return SWM_ERR_INVALID_ARG;
+    return swm_generate_proof_ex(ctx, pk, cs, rng, 0, proof_out, cap, len);
+}
+int swm_generate_proof_ex(swm_ctx* ctx, const swm_pk* pk, const swm_r1cs* cs, swm_rng* rng, unsigned flags, uint8_t* proof_out,
+                          size_t cap, size_t* len) {
+    if (!ctx || !pk || !cs || !rng || !proof_out || !len || (flags & ~(unsigned)SWM_PROOF_UNCOMPRESSED)) return SWM_ERR_INVALID_ARG;
+    if (ctx->device != pk->device)
+        return set_err(ctx, SWM_ERR_MISMATCH, "swm_generate_proof: the key is resident on device %d, the context runs on device %d",
+                       pk->device, ctx->device);
     SWM_ON_DEVICE(ctx);
     SWM_GUARD(ctx, {
-        std::vector<uint8_t> bytes = prove_impl(ctx, *pk, cs, rng->r);
+        std::vector<uint8_t> bytes = prove_impl(ctx, *pk, cs, rng->r, (flags & SWM_PROOF_UNCOMPRESSED) != 0);
         *len = bytes.size();
         if (bytes.size() > cap) throw MarlinError(SWM_ERR_INVALID_ARG, "proof buffer too small");
         memcpy(proof_out, bytes.data(), bytes.size());

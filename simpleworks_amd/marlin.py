@@ -210,6 +210,10 @@ class ConstraintSystem:
         """Flat arrays in the layout of struct swm_r1cs (kept alive by the returned object)."""
         return PackedR1cs(_to_mont_limbs(self.instance), _to_mont_limbs(self.witness), *[self._csr(r) for r in self.rows])
 
+    def pack_assignment(self):
+        """What swm_generate_proof reads: the two assignment vectors and the shape, no matrices (NULL pointers)."""
+        return AssignmentOnly(_to_mont_limbs(self.instance), _to_mont_limbs(self.witness), self.num_constraints)
+
     def is_satisfied(self, ctx=None):
         """ConstraintSystem::is_satisfied on the GPU (K3): A z o B z == C z."""
         return self.pack().is_satisfied(ctx)
@@ -251,6 +255,9 @@ class PackedR1cs:
     def pack(self):
         return self
 
+    def pack_assignment(self):
+        return AssignmentOnly(self.instance, self.witness, self.num_constraints)
+
     def is_satisfied(self, ctx=None):
         ctx = ctx or default_context()
         ok = ctypes.c_int(0)
@@ -259,6 +266,31 @@ class PackedR1cs:
         _check(ctx.lib.swm_r1cs_is_satisfied(ctx.h, ctypes.byref(s), ctypes.byref(ok), ctypes.byref(bad)),
                "swm_r1cs_is_satisfied", ctx)
         return bool(ok.value)
+
+
+class AssignmentOnly:
+    """instance + witness assignment and the number of constraints: everything swm_generate_proof reads from a constraint
+    system (include/swmarlin.h).  The nine matrix pointers of struct swm_r1cs stay NULL."""
+
+    def __init__(self, instance, witness, num_constraints):
+        self.instance = np.ascontiguousarray(instance, dtype=np.uint64).reshape(-1, 4)
+        self.witness = np.ascontiguousarray(witness, dtype=np.uint64).reshape(-1, 4)
+        self.num_constraints = int(num_constraints)
+
+    def struct(self):
+        s = _R1csStruct()
+        s.num_instance = self.instance.shape[0]
+        s.num_witness = self.witness.shape[0]
+        s.num_constraints = self.num_constraints
+        s.instance = self.instance.ctypes.data
+        s.witness = self.witness.ctypes.data if self.witness.size else None
+        return s
+
+    def pack(self):
+        return self
+
+    def pack_assignment(self):
+        return self
 
 
 class UniversalSRS:
@@ -305,10 +337,23 @@ class UniversalSRS:
 
 
 class ProvingKey:
+    """A device-resident proving key (swm_pk): resident per DEVICE, read-only and reference-counted.  `ctx` is the context
+    this holder proves on; attach(other_ctx) gives another holder of the SAME resident key for a context of another host
+    thread on that device (swm_pk_attach) — one copy of the tables serves every proving thread."""
+
     def __init__(self, ctx, handle):
         self.ctx, self.h = ctx, handle
 
+    def attach(self, ctx):
+        _check(ctx.lib.swm_pk_attach(ctx.h, self.h), "swm_pk_attach", ctx)
+        return ProvingKey(ctx, self.h)
+
+    @property
+    def refcount(self):
+        return self.ctx.lib.swm_pk_refcount(self.h)
+
     def free(self):
+        """Drops this holder's reference; the last one frees the key."""
         if self.h:
             self.ctx.lib.swm_pk_destroy(self.ctx.h, self.h)
             self.h = None
@@ -355,15 +400,30 @@ def generate_proving_and_verifying_keys(universal_srs, constraint_system):
 
 
 def generate_proof(constraint_system, proving_key, rng):
-    """src/marlin/mod.rs:70-77.  Raises MarlinError(SWM_ERR_UNSATISFIED) for an unsatisfied witness."""
+    """src/marlin/mod.rs:70-77.  Raises MarlinError(SWM_ERR_UNSATISFIED) for an unsatisfied witness.  The prover reads only
+    the assignment and the shape of the constraint system (the matrices are the key's), so a constraint system that offers
+    pack_assignment() — an AssignmentOnly, or a ConstraintSystem — is not flattened into CSR per proof."""
     ctx = proving_key.ctx
-    packed = constraint_system.pack()
+    packed = constraint_system.pack_assignment() if hasattr(constraint_system, "pack_assignment") else constraint_system.pack()
     s = packed.struct()
     buf = (ctypes.c_uint8 * 2048)()
     n = ctypes.c_size_t(0)
     _check(ctx.lib.swm_generate_proof(ctx.h, proving_key.h, ctypes.byref(s), rng.h, buf, len(buf), ctypes.byref(n)),
            "swm_generate_proof", ctx)
     return MarlinProof(bytes(buf[: n.value]))
+
+
+def generate_proof_uncompressed(constraint_system, proving_key, rng):
+    """swm_generate_proof_ex(SWM_PROOF_UNCOMPRESSED): the proof as serialize_uncompressed bytes — what a binding that rebuilds an
+    arkworks `Proof` in the same process reads with deserialize_unchecked (no square roots, no subgroup checks)."""
+    ctx = proving_key.ctx
+    packed = constraint_system.pack_assignment() if hasattr(constraint_system, "pack_assignment") else constraint_system.pack()
+    s = packed.struct()
+    buf = (ctypes.c_uint8 * 4096)()
+    n = ctypes.c_size_t(0)
+    _check(ctx.lib.swm_generate_proof_ex(ctx.h, proving_key.h, ctypes.byref(s), rng.h, 1, buf, len(buf), ctypes.byref(n)),
+           "swm_generate_proof_ex", ctx)
+    return bytes(buf[: n.value])
 
 
 def verify_proof(verifying_key, public_inputs, proof, rng):

@@ -16,6 +16,18 @@ def deserialize_proof(bytes_proof):
     return MarlinProof(data)
 
 
+def proof_recode(data, to_uncompressed):
+    """swm_proof_recode: the proof between the compressed (CanonicalSerialize::serialize, what serialization.rs:5-17 moves) and
+    the uncompressed (serialize_uncompressed, what swm_generate_proof_ex(SWM_PROOF_UNCOMPRESSED) writes) forms; checked parse."""
+    data = bytes(data)
+    buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+    out = (ctypes.c_uint8 * 4096)()
+    n = ctypes.c_size_t(0)
+    _check(load_library().swm_proof_recode(buf, len(data), 1 if to_uncompressed else 0, out, len(out), ctypes.byref(n)),
+           "Error recoding proof")
+    return bytes(out[: n.value])
+
+
 def serialize_verifying_key(verifying_key):
     lib = load_library()
     n = ctypes.c_size_t(0)

@@ -51,12 +51,80 @@ pub fn g2_limbs(p: &G2Affine, out: &mut [u64]) {
 }
 
 /// `cs.to_matrices()` + the assignments, flattened to what `struct swm_r1cs` points at.  The buffers live as long as
-/// this value; `as_ffi` hands out pointers into them for the duration of one call.
+/// this value; `as_ffi` hands out pointers into them for the duration of one call.  What the INDEXER needs.
 pub struct PackedR1cs {
     instance: Vec<u64>,
     witness: Vec<u64>,
     mats: [(Vec<u32>, Vec<u32>, Vec<u64>); 3],
     num_constraints: usize,
+}
+
+/// What the PROVER needs from a live constraint system: the two assignment vectors and the shape — nothing else
+/// (`swm_generate_proof` reads num_instance, num_witness, num_constraints, instance, witness; the matrices are the key's, as
+/// in ark-marlin, whose `prover_init` never calls `to_matrices()` either).  No `finalize()` / `to_matrices()` / CSR copies
+/// per proof: at 2^20 constraints those were 3 x 2^20 `Vec` clones plus ~100 MB of copies on one host thread, more than
+/// the 49-ms GPU proof they fed.
+///
+/// The assignment itself is handed over WHERE IT IS when `Vec<Fr>` is what it looks like — `Fp256<P>(BigInteger256([u64; 4]),
+/// PhantomData)`: 32 bytes, 8-aligned, the four Montgomery limbs in order — which `fr_view_is_sound` checks once per
+/// process on known values; otherwise the vectors are flattened (a 32-MB copy at 2^20: ~3 ms).  The borrow of the
+/// `ConstraintSystem` is held for as long as this value lives, so the vectors cannot move under the pointers.
+pub struct AssignmentOnly<'a> {
+    borrow: std::cell::Ref<'a, ark_relations::r1cs::ConstraintSystem<Fr>>,
+    copies: Option<(Vec<u64>, Vec<u64>)>,
+    num_constraints: usize,
+}
+
+/// `size_of::<Fr>() == 32`, `align_of::<Fr>() == 8`, and the bytes of an `Fr` ARE its Montgomery limbs in order.
+pub fn fr_view_is_sound() -> bool {
+    use std::sync::OnceLock;
+    static OK: OnceLock<bool> = OnceLock::new();
+    *OK.get_or_init(|| {
+        if std::mem::size_of::<Fr>() != 32 || std::mem::align_of::<Fr>() != std::mem::align_of::<u64>() {
+            return false;
+        }
+        let probe: Vec<Fr> = vec![Fr::from(1u64), Fr::from(0x1234_5678_9abc_def0u64), -Fr::from(7u64)];
+        let view = unsafe { std::slice::from_raw_parts(probe.as_ptr() as *const u64, 4 * probe.len()) };
+        probe.iter().enumerate().all(|(i, f)| view[4 * i..4 * i + 4] == fr_limbs(f))
+    })
+}
+
+impl<'a> AssignmentOnly<'a> {
+    pub fn from_cs(cs: &'a ConstraintSystemRef<Fr>) -> Result<Self, SynthesisError> {
+        let num_constraints = cs.num_constraints();
+        let borrow = cs.borrow().ok_or(SynthesisError::MissingCS)?;
+        let copies = if fr_view_is_sound() {
+            None
+        } else {
+            let flat = |v: &[Fr]| -> Vec<u64> { v.iter().flat_map(|f| fr_limbs(f)).collect() };
+            Some((flat(&borrow.instance_assignment), flat(&borrow.witness_assignment)))
+        };
+        Ok(AssignmentOnly { borrow, copies, num_constraints })
+    }
+
+    /// `struct swm_r1cs` with the nine matrix pointers NULL (include/swmarlin.h: "ASSIGNMENT ONLY").
+    pub fn as_ffi(&self) -> ffi::swm_r1cs {
+        let (ni, nw) = (self.borrow.instance_assignment.len(), self.borrow.witness_assignment.len());
+        let (instance, witness) = match &self.copies {
+            Some((i, w)) => (i.as_ptr(), if w.is_empty() { std::ptr::null() } else { w.as_ptr() }),
+            None => (
+                self.borrow.instance_assignment.as_ptr() as *const u64,
+                if nw == 0 { std::ptr::null() } else { self.borrow.witness_assignment.as_ptr() as *const u64 },
+            ),
+        };
+        let z32 = std::ptr::null::<u32>();
+        let z64 = std::ptr::null::<u64>();
+        ffi::swm_r1cs {
+            num_instance: ni,
+            num_witness: nw,
+            num_constraints: self.num_constraints,
+            instance,
+            witness,
+            a_rowptr: z32, a_col: z32, a_val: z64,
+            b_rowptr: z32, b_col: z32, b_val: z64,
+            c_rowptr: z32, c_col: z32, c_val: z64,
+        }
+    }
 }
 
 fn csr(m: &Matrix<Fr>) -> (Vec<u32>, Vec<u32>, Vec<u64>) {

@@ -61,6 +61,10 @@ extern "C" {
     pub fn swm_generate_proving_and_verifying_keys(ctx: *mut swm_ctx, srs: *const swm_srs, cs: *const swm_r1cs,
                                                    pk: *mut *mut swm_pk, vk: *mut *mut swm_vk) -> c_int;
     pub fn swm_pk_destroy(ctx: *mut swm_ctx, pk: *mut swm_pk);
+    pub fn swm_pk_retain(pk: *mut swm_pk) -> c_int;
+    pub fn swm_pk_attach(ctx: *mut swm_ctx, pk: *mut swm_pk) -> c_int;
+    pub fn swm_pk_device(pk: *const swm_pk) -> c_int;
+    pub fn swm_pk_refcount(pk: *const swm_pk) -> c_int;
     pub fn swm_vk_destroy(vk: *mut swm_vk);
 
     // generate_proof (src/marlin/mod.rs:70-77) and verify_proof (:79-86)

@@ -9,13 +9,21 @@
 //!                            `adopt-std-rng` by STATE — `swm_rng_from_chacha(seed, word position)`, position written back
 //!                            afterwards: the library then produces the ChaCha12 stream itself (on the GPU for the 3|H| mask
 //!                            coefficients).  Opt-in because it views the StdRng through a layout rand does not guarantee.
-//! * `ConstraintSystemRef` -> `PackedR1cs::from_cs` (matrices + assignments as flat arrays).
+//! * `ConstraintSystemRef` -> the indexer takes `PackedR1cs::from_cs` (matrices + assignments as flat arrays); the PROVER takes
+//!                            `AssignmentOnly::from_cs`: the two assignment vectors where they are and the shape, no
+//!                            `to_matrices()`, no CSR copies (the matrices are the key's; `swm_generate_proof` accepts NULL
+//!                            matrix pointers).
 //! * `UniversalSRS`        -> `swm_srs_export` / `swm_srs_import` (the fields of kzg10::UniversalParams).
 //! * `ProvingKey`, `VerifyingKey`, `MarlinProof` -> their CanonicalSerialize bytes, which the library reads and writes
 //!                            (`swm_pk_*`, `swm_vk_*`, proof bytes) — the interchange format src/marlin/serialization.rs defines.
-//! Device-resident twins of keys and SRS are cached per thread — keys by a digest of their verifying key and committer-key
-//! shape, at most four at a time (least recently used evicted), SRS by their first powers — so `generate_proof(cs, proving_key, rng)` — which takes the key BY VALUE in the reference — pays the
-//! import (serialise + upload + re-derive tables) once per key and thread, not once per proof.
+//! Device-resident twins of keys are cached PER PROCESS AND DEVICE (`KEYS`: a mutex-guarded LRU of at most `PK_CACHE`
+//! reference-counted handles, by a digest of the verifying key and the committer-key shape): a key is resident per device,
+//! read-only, and every proving thread attaches its own context to the one copy (`swm_pk_attach`) — eight proving threads
+//! hold ONE 13-GB table set at 2^20 constraints, not eight, and the import (serialise + upload + re-derive tables) is paid
+//! once per key and process.  SRS twins stay per thread (they are only read by `index`), keyed by their first powers.
+//! `generate_proof(cs, proving_key, rng)` — which takes the key BY VALUE in the reference — therefore pays, per proof, a
+//! verifying-key digest, a cache lookup and the GPU proof (tests/native/dropin_harness.cpp measures exactly that sequence
+//! against the C ABI: `drop_in` in the bench line).
 use crate::convert::*;
 use crate::ffi::*;
 use anyhow::{anyhow, Result};
@@ -75,49 +83,65 @@ fn check(rc: c_int, what: &'static str, ctx: *mut swm_ctx) -> std::result::Resul
     Err(SwmError { code: rc, what, detail })
 }
 
+// ------------------------------------------------------------------------------------------------ resident keys: per process and device
+/// Resident keys of this process, most recently used last; at most `PK_CACHE` per device (each holds its committer key and
+/// MSM tables in HBM: 13 GB at 2^20 constraints).  The cache owns ONE reference per entry (`swm_pk` is reference-counted);
+/// a thread that proves with a key holds a reference of its own for the duration of the call (`swm_pk_attach` ..
+/// `swm_pk_destroy`), so evicting an entry another thread is proving with only drops the cache's reference — the key is freed
+/// when the last holder lets go.
+const PK_CACHE: usize = 4;
+struct SharedPk(*mut swm_pk);
+unsafe impl Send for SharedPk {} // an opaque, internally synchronised (atomic refcount, read-only) library handle
+struct KeyCache {
+    entries: Vec<(c_int, [u8; 32], SharedPk)>, // (device, digest, handle)
+}
+static KEYS: std::sync::Mutex<KeyCache> = std::sync::Mutex::new(KeyCache { entries: Vec::new() });
+impl KeyCache {
+    /// The cached handle with one more reference taken for the caller's context (`swm_pk_attach`), or None.
+    fn get_attached(&mut self, ctx: *mut swm_ctx, device: c_int, key: &[u8; 32]) -> std::result::Result<Option<*mut swm_pk>, SwmError> {
+        let i = match self.entries.iter().position(|(d, k, _)| *d == device && k == key) {
+            Some(i) => i,
+            None => return Ok(None),
+        };
+        let e = self.entries.remove(i);
+        let h = e.2 .0;
+        self.entries.push(e);
+        check(unsafe { swm_pk_attach(ctx, h) }, "swm_pk_attach", ctx)?;
+        Ok(Some(h))
+    }
+    /// Takes over the caller's reference to `h`.
+    fn put(&mut self, device: c_int, key: [u8; 32], h: *mut swm_pk) {
+        if let Some(i) = self.entries.iter().position(|(d, k, _)| *d == device && *k == key) {
+            let (_, _, old) = self.entries.remove(i);
+            unsafe { swm_pk_destroy(std::ptr::null_mut(), old.0) };
+        }
+        if self.entries.iter().filter(|(d, _, _)| *d == device).count() >= PK_CACHE {
+            let i = self.entries.iter().position(|(d, _, _)| *d == device).expect("counted above");
+            let (_, _, old) = self.entries.remove(i);
+            unsafe { swm_pk_destroy(std::ptr::null_mut(), old.0) };
+        }
+        self.entries.push((device, key, SharedPk(h)));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ per-thread state
 // A ConstraintSystemRef is Rc<RefCell<..>> (!Send): one proof is driven by one thread, and so is one context.
-/// Device-resident keys of this thread, most recently used last; at most `PK_CACHE` of them (each holds its committer key
-/// and MSM tables in HBM: multi-GB at 2^20 constraints), the least recently used one is destroyed on overflow.
-const PK_CACHE: usize = 4;
 struct State {
     ctx: *mut swm_ctx,
+    device: c_int,
     srs: HashMap<[u8; 32], *mut swm_srs>,
-    pks: Vec<([u8; 32], *mut swm_pk)>,
-}
-impl State {
-    fn pk_get(&mut self, key: &[u8; 32]) -> Option<*mut swm_pk> {
-        let i = self.pks.iter().position(|(k, _)| k == key)?;
-        let e = self.pks.remove(i);
-        self.pks.push(e);
-        Some(e.1)
-    }
-    fn pk_put(&mut self, key: [u8; 32], h: *mut swm_pk) {
-        if let Some(i) = self.pks.iter().position(|(k, _)| *k == key) {
-            let (_, old) = self.pks.remove(i);
-            unsafe { swm_pk_destroy(self.ctx, old) };
-        }
-        if self.pks.len() >= PK_CACHE {
-            let (_, old) = self.pks.remove(0);
-            unsafe { swm_pk_destroy(self.ctx, old) };
-        }
-        self.pks.push((key, h));
-    }
 }
 impl State {
     fn new() -> std::result::Result<Self, SwmError> {
         let device = std::env::var("SWM_DEVICE").ok().and_then(|s| s.parse::<c_int>().ok()).unwrap_or(0);
         let mut ctx = std::ptr::null_mut();
         check(unsafe { swm_init(device, &mut ctx) }, "swm_init", std::ptr::null_mut())?;
-        Ok(State { ctx, srs: HashMap::new(), pks: Vec::new() })
+        Ok(State { ctx, device, srs: HashMap::new() })
     }
 }
 impl Drop for State {
     fn drop(&mut self) {
         unsafe {
-            for (_, pk) in self.pks.drain(..) {
-                swm_pk_destroy(self.ctx, pk);
-            }
             for (_, srs) in self.srs.drain() {
                 swm_srs_destroy(self.ctx, srs);
             }
@@ -386,7 +410,8 @@ fn index(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(Pr
         let pk = ProvingKey::deserialize(&mut pk_bytes.as_slice()).map_err(de);
         match (pk, vk) {
             (Ok(pk), Ok(vk)) => {
-                st.pk_put(pk_key(&pk, &vk_bytes), pk_h);
+                // the process-wide cache takes over this thread's reference: any thread's generate_proof finds the twin
+                KEYS.lock().unwrap_or_else(|p| p.into_inner()).put(st.device, pk_key(&pk, &vk_bytes), pk_h);
                 Ok((pk, vk))
             }
             (Err(e), _) | (_, Err(e)) => {
@@ -397,18 +422,22 @@ fn index(srs: &UniversalSRS, cs: ConstraintSystemRef) -> std::result::Result<(Pr
     })
 }
 
+/// The resident twin of `pk` with one reference taken for this thread's context; the caller releases it with
+/// `swm_pk_destroy(st.ctx, h)` when its proof is done.
 fn resident_pk(st: &mut State, pk: &ProvingKey) -> std::result::Result<*mut swm_pk, SwmError> {
     let (_, vk_bytes) = vk_key(&pk.index_vk)?;
     let key = pk_key(pk, &vk_bytes);
-    if let Some(h) = st.pk_get(&key) {
+    if let Some(h) = KEYS.lock().unwrap_or_else(|p| p.into_inner()).get_attached(st.ctx, st.device, &key)? {
         return Ok(h);
     }
-    // a key this thread has not seen (deserialised from disk, built by arkworks): move it in through its bytes
+    // a key this process has not seen on this device (deserialised from disk, built by arkworks): move it in through its
+    // bytes — outside the lock (seconds at 2^20); two threads racing on the same new key both import, the second put wins
     let mut bytes = Vec::new();
     pk.serialize(&mut bytes).map_err(|e| SwmError { code: -7, what: "ProvingKey::serialize", detail: format!("{:?}", e) })?;
     let mut h = std::ptr::null_mut();
     check(unsafe { swm_pk_deserialize(st.ctx, bytes.as_ptr(), bytes.len(), &mut h) }, "swm_pk_deserialize", st.ctx)?;
-    st.pk_put(key, h);
+    check(unsafe { swm_pk_retain(h) }, "swm_pk_retain", st.ctx)?; // one reference for the cache, one for this call
+    KEYS.lock().unwrap_or_else(|p| p.into_inner()).put(st.device, key, h);
     Ok(h)
 }
 
@@ -422,14 +451,17 @@ pub fn generate_proof(
 }
 
 fn prove<R: RngCore + 'static>(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut R) -> std::result::Result<MarlinProof, SwmError> {
-    let packed = PackedR1cs::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "to_matrices", detail: format!("{:?}", e) })?;
+    // assignment only: no finalize() / to_matrices() / CSR copies at prove time (the matrices are the key's)
+    let packed = AssignmentOnly::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "ConstraintSystemRef::borrow", detail: format!("{:?}", e) })?;
     with_state(|st| {
         let ctx = st.ctx;
         let pk_h = resident_pk(st, pk)?;
         let r1cs = packed.as_ffi();
-        let mut buf = vec![0u8; 2048];
+        let mut buf = [0u8; 2048];
         let mut len = 0usize;
-        with_rng(rng, |r| check(unsafe { swm_generate_proof(ctx, pk_h, &r1cs, r, buf.as_mut_ptr(), buf.len(), &mut len) }, "swm_generate_proof", ctx))?;
+        let rc = with_rng(rng, |r| check(unsafe { swm_generate_proof(ctx, pk_h, &r1cs, r, buf.as_mut_ptr(), buf.len(), &mut len) }, "swm_generate_proof", ctx));
+        unsafe { swm_pk_destroy(ctx, pk_h) }; // this call's reference; the cache keeps the key resident
+        rc?;
         MarlinProof::deserialize(&mut &buf[..len]).map_err(|e| SwmError { code: -7, what: "Proof::deserialize", detail: format!("{:?}", e) })
     })
 }

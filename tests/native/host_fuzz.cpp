@@ -196,6 +196,31 @@ int main(int argc, char** argv) {
             if (exact != prb) FAIL("proof mutation %ld (kind %d) differs from the golden bytes and still verifies", i, kind);
         }
     }
+    // ---- the uncompressed proof form (swm_generate_proof_ex / swm_proof_recode): golden -> uncompressed -> golden, then a
+    // quarter as many mutations of the uncompressed bytes through the checked reader of that form
+    {
+        std::vector<uint8_t> unc(4096), back(4096);
+        size_t ul = 0, bl = 0;
+        if (swm_proof_recode(prb.data(), prb.size(), 1, unc.data(), unc.size(), &ul) != SWM_OK || ul <= prb.size()) FAIL("recode to uncompressed");
+        unc.resize(ul);
+        if (swm_proof_recode(unc.data(), unc.size(), 0, back.data(), back.size(), &bl) != SWM_OK || bl != prb.size() ||
+            memcmp(back.data(), prb.data(), bl))
+            FAIL("uncompressed -> compressed is not the golden proof");
+        if (swm_proof_recode(unc.data(), unc.size(), 0, back.data(), bl - 1, &bl) != SWM_ERR_INVALID_ARG) FAIL("short recode buffer not refused");
+        for (long i = 0; i < n_proof / 4; i++) {
+            int kind;
+            std::vector<uint8_t> m = mutate(unc, g, &kind);
+            std::vector<uint8_t> exact(m.begin(), m.end());
+            static const uint8_t empty_buf[1] = {0};
+            const uint8_t* p = exact.empty() ? empty_buf : exact.data();
+            std::vector<uint8_t> out(4096);
+            size_t ol = 0;
+            const int rc = swm_proof_recode(p, exact.size(), 0, out.data(), out.size(), &ol);
+            if (!status_ok(rc)) FAIL("uncompressed proof mutation %ld (kind %d): recode returned %d", i, kind, rc);
+            tally[0][rc == SWM_OK ? 0 : 1]++;
+            if (rc == SWM_OK && swm_proof_validate(out.data(), ol) != SWM_OK) FAIL("uncompressed proof mutation %ld: recoded bytes do not parse", i);
+        }
+    }
     // ---- mutated verifying keys: parse; survivors are re-serialised, re-parsed and used to verify the golden proof
     for (long i = 0; i < n_vk; i++) {
         int kind;

@@ -188,6 +188,40 @@ def test_deserialisers_are_the_checked_form():
     assert "prover message" in str(e.value)
 
 
+def test_uncompressed_proof_form_round_trips_and_is_checked():
+    """swm_proof_recode / swm_generate_proof_ex(SWM_PROOF_UNCOMPRESSED): serialize_uncompressed [U: ark-ec 0.3] writes a G1 point
+    as x || y with the infinity flag in the top bits of y's last byte; everything else is unchanged.  The uncompressed form of
+    every golden proof carries the compressed form's x, the root of x^3 + 1 its sign bit names, and converts back to the
+    golden bytes; the reader of that form checks curve and subgroup membership like the compressed one."""
+    from oracle_lib import Q
+    for name in ("manual_constraints", "synthetic_8", "random_sparse"):
+        raw = bytes.fromhex(golden("marlin.json")[name]["proof"])
+        unc = S.proof_recode(raw, True)
+        assert S.proof_recode(unc, False) == raw
+        assert (len(unc) - len(raw)) % 48 == 0 and len(unc) > len(raw)
+        assert unc[:16] == raw[:16]                      # round count, commitment count of round 1
+        cx = bytearray(raw[16:64])
+        positive = bool(cx[47] & 0x80)
+        cx[47] &= 0x3F
+        x = int.from_bytes(cx, "little")
+        assert int.from_bytes(unc[16:64], "little") == x
+        assert unc[111] & 0xC0 == 0                      # SWFlags::default(): no bit on a finite point
+        y = int.from_bytes(unc[64:112], "little")
+        assert (y * y - x * x * x - 1) % Q == 0 and (y > (Q - y) % Q) == positive
+        # an off-curve y is refused (the checked reader of the uncompressed form), so is the invalid flag pair
+        t = bytearray(unc)
+        t[64] ^= 1
+        with pytest.raises(M.MarlinError) as e:
+            S.proof_recode(bytes(t), False)
+        assert e.value.code == -7
+        t = bytearray(unc)
+        t[111] |= 0xC0
+        with pytest.raises(M.MarlinError):
+            S.proof_recode(bytes(t), False)
+        with pytest.raises(M.MarlinError):               # the two forms are not mistaken for each other
+            S.deserialize_proof(unc)
+
+
 def test_callback_rng_consumes_the_callers_stream():
     """swm_rng_from_callback: draws through the caller's fill_bytes are the draws of the built-in generator when the
     callback serves the same ChaCha12 stream (word for word: next_u64 = 8 bytes, Fr::rand = 32 bytes per candidate)."""
