@@ -143,6 +143,120 @@ def cpu_baseline_prove(calls, N, mats, z, log_shift_1t):
                                      "NTT %.1f s, mat-vec %.2f s" % (1 << log_shift_1t, N >> log_shift_1t, t1["msm"], t1["ntt"], t1["spmv"])}}
 
 
+def _run_sharded_children(args, sizes, rank, world, device_index, dist, torch, coll_dev):
+    """Parent side of the sharded leg: broadcast rank 0's ncclUniqueId, start this rank's child, collect one JSON line per size
+    under a deadline.  Returns a list (one entry per size) of per-rank result dicts, {"error": ...} from the first failure on."""
+    import queue
+    import subprocess
+    import threading
+    from simpleworks_amd._lib import rccl_unique_id
+    try:
+        idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
+        dist.broadcast(idt, 0)
+        id_hex = bytes(idt.cpu().numpy().tobytes()).hex()
+    except Exception as e:  # noqa: BLE001
+        return [{"error": "unique id: %r" % (e,)}]
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", id_hex, "--child-rank", str(rank), "--child-world", str(world),
+           "--child-device", str(device_index), "--sharded-log-n", ",".join(str(x) for x in sizes), "--circuit", args.circuit]
+    if args.r1cs:
+        cmd += ["--r1cs", args.r1cs]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SWM_BENCH_FORCE_DIST")}
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, text=True)
+    lines = queue.Queue()
+
+    def reader():  # (reads a pipe: no GPU, no collective — safe to leave behind)
+        for line in child.stdout:
+            lines.put(line)
+        lines.put(None)
+    threading.Thread(target=reader, daemon=True).start()
+    out = []
+    for lg_s in sizes:
+        budget = float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "300" if lg_s <= 20 else "480"))
+        try:
+            line = lines.get(timeout=budget)
+        except queue.Empty:
+            line = "TIMEOUT"
+        if line is None or line == "TIMEOUT":
+            out.append({"error": ("timed out after %.0f s" % budget) if line else "the child exited without a result (status %s)" % child.poll(),
+                        "log_n": lg_s})
+            break
+        try:
+            res = json.loads(line)
+        except ValueError:
+            res = {"error": "unparsable child output: %r" % line[:200]}
+        out.append(res)
+        if "error" in res:
+            break
+    if child.poll() is None:
+        if out and "error" in out[-1]:
+            child.kill()  # exactly the process started above
+        try:
+            child.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            child.kill()
+    return out
+
+
+def sharded_child(args):
+    """One rank of the sharded leg, in a process of its own: no torch, no process group — the library's communicator
+    (swm_rccl_init with the id the parent handed over) is the only thing that connects the ranks.  One JSON line per size."""
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)  # RCCL's banner goes to stderr
+    rank, world = args.child_rank, args.child_world
+    import simpleworks_amd as swm
+    from simpleworks_amd import marlin as M
+    from simpleworks_amd import workloads as W
+    from simpleworks_amd._lib import rccl_info
+
+    def emit(obj):
+        json_out.write(json.dumps(obj) + "\n")
+        json_out.flush()
+    try:
+        ctx = swm.Context(args.child_device)
+        M.set_default_context(ctx)
+        ctx.rccl_init(bytes.fromhex(args.sharded_child), rank, world)
+    except Exception as e:  # noqa: BLE001
+        emit({"error": "rank %d: %r [%s]" % (rank, e, rccl_info()[1])})
+        return 1
+    for lg_s in [int(x) for x in args.sharded_log_n.split(",") if x]:
+        try:
+            rng_s = M.generate_rand()
+            if args.r1cs:
+                scs, pub_s = W.load_r1cs(args.r1cs)
+            elif args.circuit == "merkle":
+                mcs_s, pub_s, _ = W.merkle_membership_circuit(leaf_u8=0xA7)
+                scs = mcs_s.pack()
+            else:
+                scs, pub_s = W.synthetic_r1cs(1 << lg_s, 0x1234567, 0x7654321)  # the SAME system on every rank
+            ns = scs.num_constraints
+            nv = scs.instance.shape[0] + scs.witness.shape[0]
+            srs_s = M.generate_universal_srs(ns, nv if (args.r1cs or args.circuit == "merkle") else ns,
+                                             max(int(m[0][-1]) for m in scs.mats), rng_s)
+            pk_s, vk_s = M.generate_proving_and_verifying_keys(srs_s, scs)
+            srs_s.free()
+            M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
+            c0, b0 = ctx.exchange_stats()
+            reps = 3
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pr = M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
+            ctx.synchronize()
+            dts = time.perf_counter() - t0
+            c1, b1 = ctx.exchange_stats()
+            emit({"constraints": ns, "seconds": dts, "reps": reps, "rccl": rccl_info()[1], "sha256": hashlib.sha256(pr.data).hexdigest(),
+                  "exchanges_per_proof": (c1 - c0) / reps, "bytes_per_rank_per_proof": (b1 - b0) / reps,
+                  "verifies": bool(M.verify_proof(vk_s, pub_s, pr, M.generate_rand()))})
+            pk_s.free()
+        except Exception as e:  # noqa: BLE001
+            emit({"error": "rank %d, 2^%d: %r [%s]" % (rank, lg_s, e, rccl_info()[1])})
+            return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +283,10 @@ def main():
                     help="N > 1, workload prove: sizes (comma-separated log2 of the constraint count) of the `sharded` leg — ONE proof "
                          "over all ranks through the library's RCCL exchange.  Default: the --log-n size, then 2^22 (BASELINE "
                          "configs[3]) when the headline size is 2^20")
+    ap.add_argument("--sharded-child", default=None, metavar="ID_HEX", help=argparse.SUPPRESS)  # internal: one rank of the sharded leg
+    ap.add_argument("--child-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--child-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in_rng proofs after the timed loop (profiling runs)")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
                     help="N = 1, workload prove: after the timed loop, K contexts on THIS GPU (all attached to the ONE resident key, one host "
@@ -180,6 +298,8 @@ def main():
                     help="bracket EVERY kernel launch with HIP events (per-kernel table in the JSON line; costs ~2 %% of a "
                          "2^20 proof) instead of the dominant kernel only")
     args = ap.parse_args()
+    if args.sharded_child:
+        sys.exit(sharded_child(args))
 
     # The contract is ONE JSON line on stdout.  RCCL prints a banner (hostname, library path, ...) to stdout when its
     # communicator comes up, so everything written to file descriptor 1 from here on is sent to stderr and the JSON line
@@ -396,18 +516,19 @@ def main():
             import dropin_lib
             binding = {}
             for mode in ("view", "copy"):
-                rep, _ = dropin_lib.run(pk, vk, cs.pack_assignment(), threads=1, proofs_per_thread=4, rng_key=M.TEST_RNG_SEED,
+                rep, _ = dropin_lib.run(pk, vk, cs.pack_assignment(), threads=1, proofs_per_thread=8, rng_key=M.TEST_RNG_SEED,
                                         rng_word_pos=0, pack_mode=mode)
                 binding[mode] = {k: rep[k] for k in ("ms_per_proof", "key_lookup_ms", "host_pack_ms", "prove_call_ms",
-                                                     "proof_deserialize_proxy_ms", "binding_overhead_ms")}
+                                                     "checked_deserialize_proxy_ms", "binding_overhead_ms")}
             binding["host_pack_ms"] = binding["view"]["host_pack_ms"]
             binding["binding_overhead_ms"] = binding["view"]["binding_overhead_ms"]
             binding["note"] = ("per proof, one thread, a context of its own on the key this bench proved with (swm_pk_attach): "
                                "binding_overhead_ms = key lookup (vk bytes -> Blake2s -> cache) + assignment pack; `view` = the "
                                "assignment vectors handed over where they are (Vec<Fr> = Montgomery limbs), `copy` = flattened per "
-                               "proof; no matrices cross the boundary at prove time.  proof_deserialize_proxy_ms = the library's own "
-                               "checked deserialisation of the proof bytes (swm_proof_validate), standing for Proof::deserialize "
-                               "on the Rust side")
+                               "proof; no matrices cross the boundary at prove time; the proof comes back as serialize_uncompressed bytes "
+                               "(swm_generate_proof_ex) for Proof::deserialize_unchecked.  checked_deserialize_proxy_ms (not part of the "
+                               "overhead): what the checked Proof::deserialize of the compressed bytes would add per proof, measured on "
+                               "the library's own checked reader (swm_proof_validate)")
         except Exception as e:  # noqa: BLE001 — a missing g++ on the bench box must not cost the headline line
             binding = {"error": "%s: %s" % (type(e).__name__, e)}
     overlapped = None
@@ -471,79 +592,38 @@ def main():
 
     # N > 1, workload prove: besides the replicas figure (value), ONE proof over all ranks through the library's own RCCL
     # exchange (swm_rccl_init; point-range sharded commitment MSMs, one ncclAllGather per prover round) is measured and
-    # reported as the `sharded` sub-object.  Runs in a watchdog thread: a stuck collective must not cost the headline line.
+    # reported as the `sharded` sub-object.  The leg runs in a FRESH CHILD PROCESS per rank (r06): this process only
+    # hands the ncclUniqueId over (a torch broadcast), starts `bench.py --sharded-child ...`, reads its JSON lines under a
+    # deadline and kills exactly that child when it is late — a stuck RCCL collective then dies with its process instead of
+    # being abandoned by a watchdog thread inside a process that still owns a GPU context and a process group.  The headline
+    # measurement above is complete before any of it starts; a failed leg is `sharded: {"error": ...}` in the line (and exit
+    # code 3 with SWM_BENCH_SHARDED_STRICT=1).
     sharded_info, sharded_more = None, []
     if use_dist and args.workload == "prove" and not os.environ.get("SWM_BENCH_NO_SHARDED"):
-        import threading
-        # sizes of the sharded leg: the headline size and BASELINE configs[3]'s 2^22 (the synthetic circuit only), each under
-        # its own watchdog; --sharded-log-n picks others.  The first size is `sharded`, the rest `sharded_more`.
         if args.sharded_log_n:
             sizes = [int(x) for x in args.sharded_log_n.split(",") if x]
         else:
             sizes = [args.log_n] + ([22] if args.circuit == "synthetic" and not args.r1cs and args.log_n == 20 and world > 1 else [])
-        state = {"comm": False}
-
-        def run_sharded(lg_s, box):
-            try:
-                if not state["comm"]:
-                    from simpleworks_amd._lib import rccl_unique_id
-                    idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-                    if rank == 0:
-                        idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
-                    dist.broadcast(idt, 0)
-                    ctx.rccl_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-                    state["comm"] = True
-                rng_s = M.generate_rand()
-                if args.r1cs:
-                    scs, pub_s = W.load_r1cs(args.r1cs)
-                    ns = scs.num_constraints
-                    srs_s = M.generate_universal_srs(ns, scs.instance.shape[0] + scs.witness.shape[0],
-                                                     max(int(m[0][-1]) for m in scs.mats), rng_s)
-                elif args.circuit == "merkle":
-                    mcs_s, pub_s, _ = W.merkle_membership_circuit(leaf_u8=0xA7)
-                    scs = mcs_s.pack()
-                    ns = scs.num_constraints
-                    srs_s = M.generate_universal_srs(ns, scs.instance.shape[0] + scs.witness.shape[0],
-                                                     max(int(m[0][-1]) for m in scs.mats), rng_s)
-                else:
-                    ns = 1 << lg_s
-                    srs_s = M.generate_universal_srs(ns, ns, ns, rng_s)
-                    scs, pub_s = W.synthetic_r1cs(ns, 0x1234567, 0x7654321)  # the SAME system on every rank
-                pk_s, vk_s = M.generate_proving_and_verifying_keys(srs_s, scs)
-                srs_s.free()
-                M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
-                c0, b0 = ctx.exchange_stats()
-                reps = 3
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    pr = M.generate_proof(scs, pk_s, M.rng_from_seed(bytes(32)))
-                sync()
-                dts = time.perf_counter() - t0
-                c1, b1 = ctx.exchange_stats()
-                h = torch.frombuffer(bytearray(hashlib.sha256(pr.data).digest()), dtype=torch.uint8).to(coll_dev)
-                hs = [torch.empty_like(h) for _ in range(world)]
-                dist.all_gather(hs, h)
-                tt2 = torch.tensor([dts], dtype=torch.float64, device=coll_dev)
-                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-                box["res"] = {"constraints": ns, "ms_per_proof": float(tt2.item()) / reps * 1e3, "constraints_per_s": ns * reps / float(tt2.item()),
-                              "ranks": world, "exchange": "ncclAllGather / grouped ncclSend+ncclRecv inside libswmarlin (swm_rccl_init)",
-                              "exchanges_per_proof": (c1 - c0) / reps, "bytes_per_rank_per_proof": (b1 - b0) / reps,
-                              "proof_bytes_identical_on_all_ranks": all(bool((x == hs[0]).all()) for x in hs),
-                              "proof_verifies": bool(M.verify_proof(vk_s, pub_s, pr, M.generate_rand()))}
-                pk_s.free()
-            except Exception as e:  # noqa: BLE001
-                box["res"] = {"error": repr(e)}
+        mine = _run_sharded_children(args, sizes, rank, world, device_index, dist, torch, coll_dev)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
         results = []
-        for lg_s in sizes:
-            box = {}
-            th = threading.Thread(target=run_sharded, args=(lg_s, box), daemon=True)
-            th.start()
-            th.join(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "240" if lg_s <= 20 else "360")))
-            results.append(box.get("res", {"error": "timed out", "log_n": lg_s}))
-            if "error" in results[-1]:
-                break  # a rank that gave up cannot take part in the next size's collectives
-        sharded_info, sharded_more = results[0], results[1:]
+        for k in range(len(sizes)):
+            per_rank = [g[k] if k < len(g) else {"error": "no result"} for g in gathered]
+            errs = [r["error"] for r in per_rank if "error" in r]
+            if errs:
+                results.append({"error": errs[0], "log_n": sizes[k]})
+                break  # (a rank that gave up took no part in the later sizes)
+            dts = max(r["seconds"] for r in per_rank)
+            r0 = per_rank[0]
+            results.append({"constraints": r0["constraints"], "ms_per_proof": dts / r0["reps"] * 1e3,
+                            "constraints_per_s": r0["constraints"] * r0["reps"] / dts, "ranks": world,
+                            "exchange": "ncclAllGather / grouped ncclSend+ncclRecv inside libswmarlin (swm_rccl_init), one child process per rank",
+                            "rccl": r0["rccl"], "rccl_same_on_all_ranks": len({r["rccl"] for r in per_rank}) == 1,
+                            "exchanges_per_proof": r0["exchanges_per_proof"], "bytes_per_rank_per_proof": r0["bytes_per_rank_per_proof"],
+                            "proof_bytes_identical_on_all_ranks": len({r["sha256"] for r in per_rank}) == 1,
+                            "proof_verifies": all(r["verifies"] for r in per_rank)})
+        sharded_info, sharded_more = (results[0] if results else None), results[1:]
 
     if rank == 0:
         dom = prof[dominant]
@@ -672,15 +752,11 @@ def main():
         json_out.flush()
     if use_dist:
         failed = [r for r in [sharded_info] + sharded_more if r is not None and "error" in r]
+        dist.destroy_process_group()  # (this process ran no sharded proof itself: nothing of it is stuck, whatever its children did)
         if failed:
-            # The headline (replicas) measurement is valid and its line is out with `sharded: {"error": ...}` in it: a failed or
-            # timed-out sharded leg must not turn that into a failed run.  A watchdog-abandoned collective may never return,
-            # so leave without the orderly teardown (which would wait for it) — with exit code 0.
-            sys.stdout.flush()
-            sys.stderr.write("bench: the sharded leg failed (reported in the JSON line, exit code stays 0): %s\n" % failed[0]["error"])
-            sys.stderr.flush()
-            os._exit(0)
-        dist.destroy_process_group()
+            sys.stderr.write("bench: the sharded leg failed (reported in the JSON line): %s\n" % failed[0]["error"])
+            if os.environ.get("SWM_BENCH_SHARDED_STRICT"):
+                sys.exit(3)
 
 
 if __name__ == "__main__":

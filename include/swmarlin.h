@@ -227,7 +227,7 @@ int swm_generate_proof(swm_ctx *ctx, const swm_pk *pk, const swm_r1cs *cs, swm_r
  * G1 point as x, y with the infinity flag in the top bits of y's last byte, everything else unchanged.  For a binding that turns
  * the bytes back into an arkworks `Proof` in the same process: `Proof::deserialize_unchecked` on this form costs microseconds,
  * where the checked `Proof::deserialize` of the compressed form takes a square root and a subgroup check per commitment (~2.3 ms
- * for a proof, measured on the library's own checked reader: `drop_in.proof_deserialize_proxy_ms` in the bench line) — the bytes
+ * for a proof, measured on the library's own checked reader: `drop_in.checked_deserialize_proxy_ms` in the bench line) — the bytes
  * come from this library, not from an untrusted peer.  flags = 0 is swm_generate_proof.
  * swm_proof_recode converts between the two forms on the host (checked parse of the input form; out == NULL reports the length):
  * serialize(deserialize_unchecked(uncompressed bytes)) on the Rust side gives the bytes swm_generate_proof would have written. */
@@ -306,8 +306,8 @@ int swm_set_msm_sharding(swm_ctx *ctx, unsigned rank, unsigned world, swm_allgat
 
 /* The same exchange through RCCL INSIDE the library (one process per GPU, backend RCCL over xGMI): the partial sums of
  * ALL commitments of a prover round travel in ONE ncclAllGather on the context's stream (k x 192 bytes per rank;
- * 3-4 exchanges per proof), no callback, no host framework in the data path.  librccl is resolved at run time (the copy
- * already loaded in the process if there is one, else librccl.so.1).
+ * 3-4 exchanges per proof), no callback, no host framework in the data path.  librccl is resolved at run time (swm_rccl_info:
+ * SWM_RCCL_PATH, else the copy already mapped in the process, else librccl.so.1).
  *   swm_rccl_unique_id  rank 0 creates the 128-byte ncclUniqueId and hands it to the other ranks by any means;
  *   swm_rccl_init       every rank: ncclCommInitRank(world, id, rank) for this context, then sharding is on;
  *   swm_set_rccl_comm   alternatively adopt a communicator the caller owns (same RCCL build); NULL switches back;
@@ -316,6 +316,12 @@ int swm_rccl_unique_id(uint8_t out[128]);
 int swm_rccl_init(swm_ctx *ctx, const uint8_t id[128], unsigned rank, unsigned world);
 int swm_set_rccl_comm(swm_ctx *ctx, void *nccl_comm, unsigned rank, unsigned world);
 int swm_exchange_stats(swm_ctx *ctx, uint64_t *calls, uint64_t *bytes_per_rank);
+/* Which RCCL carries the exchanges of this process, and how it was found: "librccl <path> version <ncclGetVersion> (<how>)", or why
+ * none is usable (the return value is then SWM_ERR_INTERNAL and buf says why).  Resolution is deterministic: (1) SWM_RCCL_PATH —
+ * that file or an error; (2) a librccl the process has ALREADY mapped (torch's copy when torch was imported first; read from
+ * /proc/self/maps) — never a second copy beside it; (3) librccl.so.1, then librccl.so, on the loader's search path.  The same
+ * string is part of every RCCL error message (swm_last_error) and of bench.py's `sharded` object. */
+int swm_rccl_info(char *buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------------- measurement
  * Per-kernel HIP-event log on the context's stream (SURVEY.md §5 "per-kernel event log"): when enabled every

@@ -28,6 +28,7 @@ ABI = {
     "swm_rccl_init": (_int, [_vp, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "swm_set_rccl_comm": (_int, [_vp, _vp, ctypes.c_uint, ctypes.c_uint]),
     "swm_selftest_exchange": (_int, [_vp, ctypes.c_void_p, ctypes.c_void_p, _sz, _int]),
+    "swm_rccl_info": (_int, [ctypes.c_char_p, _sz]),
     "swm_exchange_stats": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "swm_synchronize": (_int, [_vp]),
     "swm_malloc": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
@@ -101,6 +102,13 @@ ABI = {
     "swm_selftest_pairing": (_int, [ctypes.POINTER(ctypes.c_uint)]),
     "swm_selftest_fr_inv": (_int, [_u64p, _u64p, _sz, ctypes.POINTER(ctypes.c_uint)]),
 }
+
+
+def rccl_info():
+    """swm_rccl_info: (usable, description) of the RCCL this process would use / uses for the library's exchanges."""
+    buf = ctypes.create_string_buffer(1024)
+    rc = load_library().swm_rccl_info(buf, len(buf))
+    return rc == 0, buf.value.decode(errors="replace")
 
 
 def rccl_unique_id():

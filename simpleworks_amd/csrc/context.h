@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/swmarlin.h"
 #include "host/pool.h"
+#include "switches.h"
 
 namespace swm {
 
@@ -49,8 +50,8 @@ struct swm_ctx {
     size_t ntt_pass_table_bytes = 0;      // HBM held by the per-pass twiddle tables of the lazy transform (capped, ntt.hip)
     // asynchronous MSM lanes: auxiliary streams (the prover alternates between two of them), a fork event, pinned result slots with their completion events
     static constexpr int MSM_SLOTS = 8;
-    static constexpr int MSM_LANES = 5;  // sort | accumulation 0 | accumulation 1 | bucket stage | second bucket-stage stream (SWM_MSM_TAILS=2)
-    hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int MSM_LANES = 4;  // sort | accumulation 0 | accumulation 1 | bucket stage
+    hipStream_t aux_stream[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipStream_t> spare_streams;  // never used: placeholders / rejected candidates of the hardware-queue placement (msm_enqueue)
     hipEvent_t fork_event = nullptr;
     void* pinned = nullptr;
@@ -109,6 +110,7 @@ struct swm_ctx {
     // largest size requested so far for each kind of per-slot MSM scratch (hist, bucket_off, seg_off, big_list, points, acc): a
     // slot's buffer is always grown to that, not to what its current job needs (msm.hip, msm_enqueue)
     size_t msm_slot_bytes[6] = {0, 0, 0, 0, 0, 0};
+    bool emulated_exchange = false;  // set by an EMULATED device exchange (measurement builds only, -DSWM_MEASURE_HOOKS: capi.hip)
     unsigned msm_since_wait = 0;  // MSM jobs enqueued since the last msm_finish*: 0 = nothing of this context is in flight
     uint32_t* ext_totals = nullptr;  // eight pinned words: the device's running total behind each of the last eight runs of a draw
     hipEvent_t ext_cnt_event[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and when each has arrived

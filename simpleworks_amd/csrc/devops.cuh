@@ -261,77 +261,8 @@ struct RecConsts {
     Fr zstep[9];          // (z^8)^(2^k), k = 0..8
     Fr z256;              // z^256 (pass 1 Horner step)
 };
-static __global__ void __launch_bounds__(256) rec_tile_total(const Fr* __restrict__ a, size_t n, RecConsts rc,
-                                                             const Fr* __restrict__ zlow /* z^0..z^255 */,
-                                                             Fr* __restrict__ totals) {
-    SWM_LIGHT_KERNEL();
-    __shared__ Fr sm[256];
-    const size_t base = (size_t)blockIdx.x * RT_TILE;
-    const unsigned t = threadIdx.x;
-    Fr acc = fp_zero<Fr>();
-#pragma unroll 1
-    for (int j = RT_PER - 1; j >= 0; j--) {
-        size_t k = base + (size_t)j * 256 + t;
-        acc = fp_mul(acc, rc.z256);
-        if (k < n) acc = fp_add(acc, a[k]);
-    }
-    sm[t] = fp_mul(acc, zlow[t]);
-    __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
-        if (t < s) sm[t] = fp_add(sm[t], sm[t + s]);
-        __syncthreads();
-    }
-    if (t == 0) totals[blockIdx.x] = sm[0];
-}
+// (the 8 x 32-bit Comba forms of the two tiled passes, r02 - r04, were removed in r06: the passes below are the kernels)
 __device__ __forceinline__ unsigned rt_pad(unsigned i) { return i + i / RT_PER; }  // one 32-B pad slot per lane chunk
-static __global__ void __launch_bounds__(256) rec_tile_scan(Fr* __restrict__ a, size_t n, RecConsts rc,
-                                                            const Fr* __restrict__ tile_true /* S_b */, size_t ntiles) {
-    SWM_LIGHT_KERNEL();
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    Fr* tile = reinterpret_cast<Fr*>(smem_raw);      // RT_TILE + 256 padded slots
-    Fr* hs = tile + RT_TILE + 256;                   // 257 heads
-    const size_t b = blockIdx.x, base = b * RT_TILE;
-    const unsigned t = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < RT_PER; j++) {
-        unsigned e = j * 256 + t;
-        size_t k = base + e;
-        tile[rt_pad(e)] = k < n ? a[k] : fp_zero<Fr>();
-    }
-    __syncthreads();
-    // local scan of this lane's 8 consecutive elements (carry-in 0)
-    Fr loc[RT_PER];
-    Fr acc = fp_zero<Fr>();
-#pragma unroll
-    for (int i = RT_PER - 1; i >= 0; i--) {
-        acc = fp_add(tile[rt_pad(t * RT_PER + i)], fp_mul(acc, rc.zpow[1]));
-        loc[i] = acc;
-    }
-    hs[t] = acc;
-    if (t == 0) hs[256] = b + 1 < ntiles ? tile_true[b + 1] : fp_zero<Fr>();  // carry into the tile
-    __syncthreads();
-    // inclusive suffix scan of the heads with multiplier z^8 per lane step (Hillis-Steele, 257 entries)
-#pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-        unsigned d = 1u << k;
-        Fr v = hs[t];
-        bool has = t + d <= 256;
-        Fr o = has ? hs[t + d] : fp_zero<Fr>();
-        __syncthreads();
-        if (has) hs[t] = fp_add(v, fp_mul(rc.zstep[k], o));
-        __syncthreads();
-    }
-    Fr carry = hs[t + 1];  // true value at the first element of the next lane's chunk
-#pragma unroll
-    for (int i = 0; i < RT_PER; i++) tile[rt_pad(t * RT_PER + i)] = fp_add(loc[i], fp_mul(rc.zpow[RT_PER - i], carry));
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < RT_PER; j++) {
-        unsigned e = j * 256 + t;
-        size_t k = base + e;
-        if (k < n) a[k] = tile[rt_pad(e)];
-    }
-}
 
 // The two tiled passes on the transform's multiplier (r05; fr29.cuh: nine 29-bit lazy limbs, 197 instructions per product instead
 // of ~330, additions without a comparison against the modulus).  `rc` holds the constants in Montgomery form of radix 2^261 (times
@@ -436,15 +367,13 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     for (int k = 1; k < 9; k++) rc.zstep[k] = fp_sqr(rc.zstep[k - 1]);
     DVec zlow(ctx, 256), totals(ctx, ntiles);
     rc.z256 = dv_pow256(ctx, z, zlow.p);
-    static const bool lazy = !(getenv("SWM_REC_LAZY") && atoi(getenv("SWM_REC_LAZY")) == 0);  // 0: the 8 x 32-bit Comba kernels (r02 - r04)
     RecConsts rc29;  // the same constants in radix-2^261 form
     const Fr two5 = fp_from_u64<Fr>(32);
     for (int i = 0; i <= RT_PER; i++) rc29.zpow[i] = fp_mul(rc.zpow[i], two5);
     for (int k = 0; k < 9; k++) rc29.zstep[k] = fp_mul(rc.zstep[k], two5);
     rc29.z256 = fp_mul(rc.z256, two5);
     prof_begin(ctx, "rec_tile_total");
-    if (lazy) hipLaunchKernelGGL(rec_tile_total29, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc29, (const Fr*)zlow.p, totals.p);
-    else hipLaunchKernelGGL(rec_tile_total, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc, (const Fr*)zlow.p, totals.p);
+    hipLaunchKernelGGL(rec_tile_total29, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const Fr*)a, n, rc29, (const Fr*)zlow.p, totals.p);
     prof_end(ctx);
     hip_check(ctx, hipGetLastError(), "rec_tile_total");
     Fr ztile = rc.z256;
@@ -454,13 +383,11 @@ inline void suffix_recurrence_tiled(swm_ctx* ctx, Fr* a, size_t n, const Fr& z) 
     size_t lds = (size_t)(RT_TILE + 256 + 257) * sizeof(Fr);
     static std::atomic<bool> attr_set[64];  // per device: the attribute belongs to the device's copy of the kernel
     if (!attr_set[ctx->device & 63].load(std::memory_order_acquire)) {
-        hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
         hip_check(ctx, hipFuncSetAttribute((const void*)rec_tile_scan29, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attr");
         attr_set[ctx->device & 63].store(true, std::memory_order_release);
     }
     prof_begin(ctx, "rec_tile_scan");
-    if (lazy) hipLaunchKernelGGL(rec_tile_scan29, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc29, (const Fr*)totals.p, ntiles);
-    else hipLaunchKernelGGL(rec_tile_scan, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc, (const Fr*)totals.p, ntiles);
+    hipLaunchKernelGGL(rec_tile_scan29, dim3((unsigned)ntiles), dim3(256), lds, ctx->stream, a, n, rc29, (const Fr*)totals.p, ntiles);
     prof_end(ctx);
     hip_check(ctx, hipGetLastError(), "rec_tile_scan");
 }
@@ -876,7 +803,7 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
             void* ring = nullptr;
             if (posix_memalign(&ring, 4096, EXT_RING * EXT_CHUNK * sizeof(Fr)) != 0 || !ring) throw MarlinError(SWM_ERR_OOM, "sample: host ring");
             ctx->ext_pinned = ring;
-            static const bool reg = !(getenv("SWM_EXT_REGISTER") && atoi(getenv("SWM_EXT_REGISTER")) == 0);
+            static constexpr bool reg = true;
             if (reg && hipHostRegister(ring, EXT_RING * EXT_CHUNK * sizeof(Fr), hipHostRegisterDefault) != hipSuccess) (void)hipGetLastError();  // (not fatal: staged copies)
             else ctx->ext_registered = reg;
         }
@@ -894,8 +821,8 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         size_t have = 0, unc = 0;
         uint32_t* d_base = reinterpret_cast<uint32_t*>(dev + 2 * slot_bytes);
         hip_check(ctx, zero_fill_async(d_base, 4, cs), "clear");  // (the runtime's fill kernel waited 2 ms beside round 1's accumulations: fill.cuh)
-        static const bool trace = getenv("SWM_TRACE") != nullptr;
-        static const bool count_all = getenv("SWM_EXT_COUNT_ALL") != nullptr;  // (switch: the r02 - r04 behaviour, every run counted on the host)
+        static const bool trace = env_flag("SWM_TRACE");
+        static constexpr bool count_all = false;  // (true: the r02 - r04 behaviour, every run counted on the host: + 3.4 ms at 2^20, r05)
         double t_cb = 0, t_count = 0, t_wait = 0;
         int readbacks = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
@@ -910,7 +837,7 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         // a stream synchronisation where the bound got close: 3 - 4 round trips behind whatever the copy stream's kernels were
         // waiting for, 3.1 ms of a 3 x 2^20 draw (SWM_EXT_READBACK=1).  A helper thread counting beside the callback was tried
         // and dropped: the callback slowed from 33 to 48 ms (every line it writes is shared with the helper's core).
-        static const bool readback = getenv("SWM_EXT_READBACK") && atoi(getenv("SWM_EXT_READBACK")) != 0;
+        static constexpr bool readback = false;
         if (!ctx->ext_totals) hip_check(ctx, hipHostMalloc((void**)&ctx->ext_totals, EXT_TOTALS * sizeof(uint32_t), hipHostMallocDefault), "totals");
         for (auto& e : ctx->ext_cnt_event)
             if (!e) hip_check(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
@@ -926,7 +853,7 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
             dev_upto = i;
             dev_total = totals[i & (EXT_TOTALS - 1)];
         };
-        static const long ring = getenv("SWM_EXT_RING") ? std::min((long)EXT_RING, std::max(2l, atol(getenv("SWM_EXT_RING")))) : (long)EXT_RING;
+        static constexpr long ring = EXT_RING;  // (two chunks instead of four: the host waited 2.1 ms for the first run's copy, r05)
         for (;;) {
             const int hb = (int)(j % ring), b = (int)(j & 1);  // host chunk and device slot of the next run
             if (!readback) {
@@ -1035,7 +962,7 @@ inline void sample_fr_bulk(swm_ctx* ctx, ChaChaRng& rng, Fr* out, size_t need, b
         size_t m = (size_t)((double)want / 0.58 * 1.02) + 2048;
         // test hook: only as many candidates as elements still missing, so that the retry branch below runs several times
         // (the acceptance rate is r / 2^253 = 0.58) — tests/test_gpu_marlin.py pins it against the sequential stream
-        if (getenv("SWM_SAMPLE_TIGHT")) m = want;
+        if (env_flag("SWM_SAMPLE_TIGHT")) m = want;
         DVec cand(ctx, m);
         DBuf<uint32_t> flag(ctx, m), rank(ctx, m), last(ctx, 1);
         ChaChaKey key;

@@ -11,6 +11,7 @@
 #include "blake2s.h"
 #include "chacha.h"
 #include "marlin_types.h"
+#include "../switches.h"
 
 namespace swm {
 
@@ -212,7 +213,7 @@ LcSet construct_linear_combinations(const IndexInfo& info, const std::vector<Fr>
 // Marlin::verify + MarlinKZG10::check_combinations + KZG10::batch_check.  `rng` is the caller's generator
 // (the batch_check randomiser is drawn from it, as in arkworks).
 inline bool verify(const VerifyingKey& vk, std::vector<Fr> public_input, const Proof& proof, ChaChaRng& rng) {
-    const bool vtrace = getenv("SWM_TRACE") != nullptr;
+    const bool vtrace = env_flag("SWM_TRACE");
     auto vnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double vt0 = vnow();
     auto vmark = [&](const char* what) {

@@ -77,10 +77,6 @@ struct swm_pk {
         if (d_shifted28) (void)hipFree(d_shifted28);
         if (d_powers_te) (void)hipFree(d_powers_te);
         if (d_shifted_te) (void)hipFree(d_shifted_te);
-        for (auto& t : prefix_tab) {
-            if (t.te) (void)hipFree(t.te);
-            if (t.d28) (void)hipFree(t.d28);
-        }
     }
     // A key is resident per DEVICE, read-only once built and reference-counted (swm_pk_retain / swm_pk_attach /
     // swm_pk_destroy): any context on that device proves with it, several at once — the prover takes it by const reference
@@ -118,32 +114,12 @@ struct swm_pk {
     // flat schedule runs on them and d_*28 are the n-point scaled copies only
     G1TE* d_powers_te = nullptr;
     G1TE* d_shifted_te = nullptr;
-    // r05 experiment (SWM_MSM_PREFIX_TABLES=1, off by default — see install_committer_key): NARROWER tables over PREFIXES of the powers.  The width of a table follows the size of its base set, but a key's
-    // commitments are not all of that size: with |K| = 2 |H| (the Merkle circuit of BASELINE config #5) the powers are 3 |K| =
-    // 6 |H| points (width 20: 2^19 buckets) while w, z_A, z_B, t, g_1 have |H| coefficients — 3 entries per bucket, and a
-    // bucket stage that costs five times their accumulation.  A prefix [0, |H| + 1) and a prefix [0, max(2 |H|, |K|) + 1) get a
-    // table of their own, of the width the rule gives for THAT many points (18 / 19 for the Merkle circuit: a quarter / half
-    // of the buckets for one more window); an MSM takes the smallest prefix it fits.  Only prefixes whose width comes out below
-    // the main table's are built (none at |H| = |K| = 2^20: everything is 20 wide there).  ~1.4 GB for the Merkle key.
-    struct PrefixTab {
-        size_t n = 0;
-        unsigned c = 0;
-        G1TE* te = nullptr;
-        G1Affine* d28 = nullptr;
-    };
-    PrefixTab prefix_tab[2];
     // bases for an MSM of n points starting at SRS power `offset`
     void bases_at(size_t offset, size_t n, const G1Affine** b, const G1Affine** b28, MsmTable* tab) const {
         *tab = MsmTable();
         if (offset + n <= n_powers) {
             *b = d_powers + offset;
             *b28 = d_powers28 + offset;
-            for (const PrefixTab& t : prefix_tab)
-                if (t.te && offset + n <= t.n) {
-                    *b28 = t.d28 + offset;
-                    *tab = MsmTable{nullptr, t.n, t.c, offset, t.te};
-                    return;
-                }
             if (tab_c) *tab = MsmTable{d_powers_te ? nullptr : d_powers28, n_powers, tab_c, offset, d_powers_te};
         } else if (offset >= shift_base && offset + n <= shift_base + n_shifted) {
             *b = d_shifted + (offset - shift_base);
@@ -425,15 +401,15 @@ void shard_agree(swm_ctx* ctx, const swm_pk& pk) {
     struct Rec {
         uint32_t tab_c, shtab_c, te, switches, n_powers_lo, n_shifted_lo, world, env_hash;
     } mine;
-    auto on = [](const char* name) { return getenv(name) && atoi(getenv(name)) != 0 ? 1u : 0u; };
+    auto on = [](const char* name) { return env_flag(name) ? 1u : 0u; };
     mine.tab_c = pk.tab_c;
     mine.shtab_c = pk.shtab_c;
     mine.te = (pk.d_powers_te ? 1u : 0u) | (pk.d_shifted_te ? 2u : 0u);
     // bits 8 ..: the block size of the block-cyclic split as the process sets it (commit_enqueue clamps it by the polynomial's
     // length, the same on every rank): two ranks with different blocks would cover some coefficients twice and others never
-    const unsigned blk = getenv("SWM_SHARD_BLOCK_LOG") ? (unsigned)std::min(20, std::max(0, atoi(getenv("SWM_SHARD_BLOCK_LOG")))) : 12u;
-    mine.switches = on("SWM_SHARD_BUCKETS") | on("SWM_SHARD_RANGE") << 1 | (getenv("SWM_SHARD_R1_OFF") ? 4u : 0u) |
-                    (getenv("SWM_SHARD_R2_OFF") ? 8u : 0u) | (getenv("SWM_MSM_NO_TABLE") ? 16u : 0u) | blk << 8;
+    const unsigned blk = (unsigned)env_switch("SWM_SHARD_BLOCK_LOG", 12, 0, 20);
+    mine.switches = on("SWM_SHARD_BUCKETS") | on("SWM_SHARD_RANGE") << 1 | on("SWM_SHARD_R1_OFF") << 2 | on("SWM_SHARD_R2_OFF") << 3 |
+                    on("SWM_MSM_NO_TABLE") << 4 | blk << 8;
     mine.n_powers_lo = (uint32_t)pk.n_powers;
     mine.n_shifted_lo = (uint32_t)pk.n_shifted;
     mine.world = ctx->shard_world;
@@ -475,11 +451,10 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     const G1Affine *b = nullptr, *b28 = nullptr;
     MsmTable tab;
     if (n) pk.bases_at(offset, n, &b, &b28, &tab);
-    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 0;  // 0: msm_enqueue picks (two pipelined lanes, four for small MSMs)
     size_t lo = 0, hi = n;
     out->have_result = false;
     out->result = g1_xyzz_identity();  // an empty range (n = 0, or a rank's empty shard) contributes the identity
-    const bool force_exchange = getenv("SWM_SHARD_FORCE") != nullptr;  // test hook: exchange with a world of one
+    const bool force_exchange = env_flag("SWM_SHARD_FORCE");  // test hook: exchange with a world of one
     out->sharded = ctx->shard_world > 1 || (force_exchange && (ctx->rccl_comm || ctx->shard_allgather));
     // Split of a replicated polynomial's commitment over the ranks (every rank holds all n coefficients):
     //  * CYCLIC (default, table schedule): rank g takes the coefficients g, g + G, ... (strided scalars, table rows g + G j).
@@ -490,8 +465,8 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     //    AND bucket stage shrink with G.  Measured per rank on one GPU (tools/ubench/shard_emulate.py): it balances two ranks
     //    and loses at eight (1/8 of the buckets at full depth are too few lanes for the accumulation), so it is not the default.
     // (The switches are read per call: tests flip them.)
-    const bool by_bucket = getenv("SWM_SHARD_BUCKETS") && atoi(getenv("SWM_SHARD_BUCKETS")) != 0;
-    const bool by_range = getenv("SWM_SHARD_RANGE") && atoi(getenv("SWM_SHARD_RANGE")) != 0;
+    const bool by_bucket = env_flag("SWM_SHARD_BUCKETS");
+    const bool by_range = env_flag("SWM_SHARD_RANGE");
     const bool table_split = out->sharded && ctx->shard_world > 1 && n && msm_flat_applies(tab, n) && tab.contiguous();
     size_t first = 0, count = n;   // scalars coeffs[first + map(i)], i < count (map: the table's block map when the scalars are strided)
     if (table_split && by_bucket) {
@@ -504,7 +479,7 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
         // table rows are runs of 2^L x 192 B instead of every G-th row: the accumulation's gathers are sensitive to that
         // (per rank at 2^22 and G = 8: 5.4 G additions/s cyclic, 7 - 8 G/s for contiguous ranges: profiles/r04_shard_emulate.jsonl)
         const size_t G = ctx->shard_world, g = ctx->shard_rank;
-        unsigned L = getenv("SWM_SHARD_BLOCK_LOG") ? (unsigned)std::min(20, std::max(0, atoi(getenv("SWM_SHARD_BLOCK_LOG")))) : 12u;
+        unsigned L = (unsigned)env_switch("SWM_SHARD_BLOCK_LOG", 12, 0, 20);
         while (L > 0 && ((size_t)8 * G << L) > n) L--;
         const size_t B = (size_t)1 << L, nblocks = (n + B - 1) / B;
         const size_t mine = nblocks > g ? (nblocks - g + G - 1) / G : 0;            // blocks g, g + G, ... below nblocks
@@ -540,15 +515,16 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
     // the stage of a job takes as long as its accumulation), and one stage after the other on the tail stream — each a full chip of
     // lone waves — was the critical path; the stages of a round's jobs in ONE launch (64 workgroups each, 32 buckets per lane, all
     // resident together) share one chain latency: 2^18: 19.3 -> 17.1 ms, Merkle circuit 17.5 -> 15.1 ms (profiles/r05_*).
-    static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
+    // (SWM_MSM_BATCH_BELOW: the bound in points, 0 = every job keeps its own bucket stage; tests/test_gpu_switches.py)
+    static const long batch_env = env_switch("SWM_MSM_BATCH_BELOW", -1, 0, 1L << 31);
     const long batch_below = batch_env >= 0 ? batch_env : (tab.any() ? (tab.te ? 1000000 : 200000) : 32768);
     if (tab.scalar_stride != 1) {
-        rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, coeffs + first, count, 1, &out->job, MsmInfMask(),
+        rc_check(ctx, msm_enqueue(ctx, (*lane)++, b, b28, coeffs + first, count, 1, &out->job, MsmInfMask(),
                                   (long)count <= batch_below, tab));
         return;
     }
     tab.offset += lo;
-    rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
                               (long)(hi - lo) <= batch_below, tab));
 }
 // The same for coefficients that are ALREADY distributed: this rank holds coefficient rank + G j at local[j] (the CYCLIC
@@ -572,10 +548,9 @@ void commit_enqueue_cyclic(swm_ctx* ctx, int* lane, const swm_pk& pk, const Fr* 
     tab.offset += rank;
     tab.blk_log = 0;
     tab.bstride = G;
-    static const int nlanes = getenv("SWM_MSM_LANES") ? atoi(getenv("SWM_MSM_LANES")) : 0;
-    static const long batch_env = getenv("SWM_MSM_BATCH_BELOW") ? atol(getenv("SWM_MSM_BATCH_BELOW")) : -1;
+    static const long batch_env = env_switch("SWM_MSM_BATCH_BELOW", -1, 0, 1L << 31);
     const long batch_below = batch_env >= 0 ? batch_env : 200000;
-    rc_check(ctx, msm_enqueue(ctx, nlanes > 0 ? (*lane)++ % nlanes : (*lane)++, b, b28, local, n_local, 1, &out->job, MsmInfMask(),
+    rc_check(ctx, msm_enqueue(ctx, (*lane)++, b, b28, local, n_local, 1, &out->job, MsmInfMask(),
                               (long)n_local <= batch_below, tab));
 }
 // every commitment of a round is enqueued: run their bucket stages together
@@ -653,28 +628,14 @@ struct CommitJob {
     // the rest has been summed into `extra`
     bool has_extra = false;
     G1XYZZ extra;
-    // the first commitment of a round as two MSMs (SWM_HEAD_SPLIT, experiment): `head` covers the first n >> k coefficients
-    bool has_head = false;
-    AsyncMsm head;
 };
+// (the first commitment of a round as two MSMs, so that only a small head's sort runs with no accumulation in flight: measured
+// in r05 — 50.0 -> 52.3 ... 55.0 ms at 2^20 — and removed in r06)
 void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs, size_t n, bool has_bound, uint64_t bound,
-                     bool hiding, CommitJob* job, bool first_of_round = false) {
+                     bool hiding, CommitJob* job) {
     job->has_bound = has_bound;
     job->hiding = hiding;
-    // Experiment (r05): nothing hides the sort of a round's FIRST commitment — no accumulation is in flight yet.  Split, the
-    // exposed sort is the head's (n >> k points) and the rest is sorted while the head accumulates; the price is one more
-    // bucket stage and host fold.  A commitment is a sum over coefficients: same group element.
-    static const int head_split = getenv("SWM_HEAD_SPLIT") ? std::min(6, std::max(0, atoi(getenv("SWM_HEAD_SPLIT")))) : 0;
-    static const size_t head_min = getenv("SWM_HEAD_MIN") ? (size_t)std::max(2l, atol(getenv("SWM_HEAD_MIN"))) : (size_t)1 << 18;
-    job->has_head = false;
-    if (first_of_round && head_split && ctx->shard_world <= 1 && n >= head_min && (n >> head_split) > 0) {
-        const size_t h = n >> head_split;
-        job->has_head = true;
-        commit_enqueue(ctx, lane, pk, 0, coeffs, h, &job->head);
-        commit_enqueue(ctx, lane, pk, h, coeffs + h, n - h, &job->plain);
-    } else {
-        commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
-    }
+    commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
     if (has_bound) commit_enqueue(ctx, lane, pk, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
 }
 // The blinding half of pc_commit_end: the draws (plain first, then shifted) and the hiding terms sum_j r_j gamma^j G —
@@ -726,7 +687,6 @@ void pc_commit_end_round(swm_ctx* ctx, const swm_pk& pk, std::initializer_list<C
         if (!job->blinded) pc_commit_blind(pk, job, *rng, *pr);
         G1XYZZ plain = commit_wait(ctx, &job->plain);
         if (job->has_extra) g1_add(plain, job->extra);
-        if (job->has_head) g1_add(plain, commit_wait(ctx, &job->head));
         if (job->hiding) g1_add(plain, job->blind_plain);
         pts.push_back(plain);
         where.push_back({idx, false});
@@ -984,29 +944,9 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     // points are known to lie in the prime-order subgroup: SRS powers generated here are multiples of the generator,
     // deserialised keys went through the checks of their codec, an imported SRS is checked at import)
     rc_check(ctx, msm_install_bases(ctx, pk.d_powers, n_powers, in_subgroup, &pk.d_powers28, &pk.d_powers_te, &pk.tab_c));
-    // prefix tables (swm_pk::prefix_tab; SWM_MSM_PREFIX_TABLES=1): not for a rank of a sharded proof (its tables are narrower already
-    // and its commitments are split by blocks over the whole range)
-    // MEASURED r05, and off by default: 2^18 constraints 18.2 vs 18.0 ms without, Merkle circuit 18.0 vs 15.5 ms — these jobs are
-    // bound by the LATENCY of their chains, not by work: fewer buckets mean fewer, longer accumulation segments on a chip they do
-    // not fill (accumulation +14 % per launch), and the joint stage takes what its longest chain takes either way.
-    static const bool prefix_on = getenv("SWM_MSM_PREFIX_TABLES") && atoi(getenv("SWM_MSM_PREFIX_TABLES")) != 0;
-    if (prefix_on && pk.d_powers_te && ctx->shard_world <= 1 && pk.H) {
-        const size_t want[2] = {(size_t)pk.H + 1, (size_t)std::max<uint64_t>(2 * pk.H, pk.K) + 1};
-        int k = 0;
-        for (size_t np : want) {
-            if (np < 4096 || 2 * np > n_powers || (k && np <= pk.prefix_tab[k - 1].n)) continue;
-            if (msm_table_width(np) == 0 || msm_table_width(np) >= pk.tab_c) continue;
-            swm_pk::PrefixTab t;
-            t.n = np;
-            rc_check(ctx, msm_install_bases(ctx, pk.d_powers, np, in_subgroup, &t.d28, &t.te, &t.c));
-            if (!t.te || t.c >= pk.tab_c) {  // no room for it, or no narrower after all: the main table serves
-                if (t.te) (void)hipFree(t.te);
-                if (t.d28) (void)hipFree(t.d28);
-                continue;
-            }
-            pk.prefix_tab[k++] = t;
-        }
-    }
+    // (narrower tables over prefixes of the powers for the |H|-size commitments of mid-size keys: measured in r05 — 2^18 17.4 ->
+    // 17.6 ms, Merkle circuit 14.9 -> 17.4 ms: the widest bucket set IS the low-latency choice for jobs that do not fill the
+    // chip, CHANGELOG.md — and removed in r06)
     if (n_shifted) {
         rc_check(ctx, msm_install_bases(ctx, pk.d_shifted, n_shifted, in_subgroup, &pk.d_shifted28, &pk.d_shifted_te, &pk.shtab_c));
     } else {
@@ -1112,8 +1052,8 @@ struct PhaseTrace {
     bool host_only;  // SWM_TRACE=2: host timestamps only (no synchronisation: the schedule is left undisturbed)
     std::chrono::steady_clock::time_point start;
     explicit PhaseTrace(swm_ctx* c)
-        : ctx(c), on(getenv("SWM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()),
-          host_only(getenv("SWM_TRACE") && atoi(getenv("SWM_TRACE")) == 2), start(t0) {}
+        : ctx(c), on(env_switch("SWM_TRACE", 0, 0, 2) != 0), t0(std::chrono::steady_clock::now()),
+          host_only(env_switch("SWM_TRACE", 0, 0, 2) == 2), start(t0) {}
     void tick(const char* what) {
         if (!host_only) return;
         fprintf(stderr, "[swm host] %-34s at %8.3f ms\n", what,
@@ -1152,7 +1092,7 @@ void upload_small(swm_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* cs, ChaChaRng& zk, bool uncompressed = false) {
     PhaseTrace tr(ctx);
-    static const bool proof_marks = getenv("SWM_TRACE") != nullptr || getenv("SWM_PROOF_MARKS") != nullptr;
+    static const bool proof_marks = env_flag("SWM_TRACE") || env_flag("SWM_PROOF_MARKS");
     if (proof_marks) hipLaunchKernelGGL(swm_proof_begin, dim3(1), dim3(1), 0, ctx->stream);
     // padded shape (pad_input_for_indexer_and_prover + make_matrices_square); the witness itself is uploaded straight
     // from the caller's buffer, padding is filled on the device
@@ -1176,6 +1116,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         pr.inst.size() != pk.info.num_instance_variables)
         throw MarlinError(SWM_ERR_MISMATCH, "InstanceDoesNotMatchIndex");
     shard_agree(ctx, pk);  // one proof over several ranks: all of them split the work the same way, or none starts
+    ctx->emulated_exchange = false;
     const uint64_t H = pk.H, K = pk.K, X = pk.X, Bsz = pk.B;
     const uint64_t M = 4 * H;  // mul_domain = next_pow2(3|H| + 1)
     const unsigned logM = pk.logH + 2;
@@ -1192,7 +1133,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         swm_ctx* c;
         ~PipeMinScope() { c->msm_pipe_min = 0; }
     } pipe_scope{ctx};
-    static const unsigned one_stream_log = getenv("SWM_PROVE_ONE_STREAM_LOG") ? (unsigned)atoi(getenv("SWM_PROVE_ONE_STREAM_LOG")) : 19u;
+    static const unsigned one_stream_log = (unsigned)env_switch("SWM_PROVE_ONE_STREAM_LOG", 19, 0, 47);
     ctx->msm_pipe_min = pk.logH <= one_stream_log ? ~(size_t)0 : 0;
 
     // ---- the zero-knowledge draws of round 1 do not depend on the witness: rho_w, rho_a, rho_b, then the mask polynomial
@@ -1202,30 +1143,13 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const Fr rho_w = zk.rand_fr(), rho_a = zk.rand_fr(), rho_b = zk.rand_fr();
     LPoly P_w, P_za, P_zb, P_mask, P_t, P_g1, P_h1, P_g2, P_h2;
     int lane = 0;
-    // Every commitment MSM is enqueued as soon as its polynomial exists.  SWM_COMMIT_LATE=1 (experiment, r02): enqueue the
-    // commitments of a round together once ALL its polynomials are built.  The idea: an accumulation in flight holds every
-    // SIMD's register file (3 waves x 168 VGPRs) for ~1.5 ms per wave, so transforms issued beside it wait for retiring
-    // waves and run 3-5x slower than alone (25 ms of ntt_pass event time per 2^20 proof against 5 ms stand-alone).
-    // Measured: no gain (2^20: 77.6 vs 76.1 ms early, 2^18: 33.3 vs 32.2) — the early MSMs cover more than the slowed
-    // transforms cost.
-    static const bool commit_early = getenv("SWM_COMMIT_LATE") == nullptr;
-    std::vector<std::function<void()>> late;
-    // which commitments start with no accumulation in flight (bit = tag: 0 mask, 1 w, 2 z_A / z_B, 3 t, 4 h_1, 5 g_1, 6 g_2, 7 h_2)
-    static const unsigned head_mask = getenv("SWM_HEAD_MASK") ? (unsigned)strtoul(getenv("SWM_HEAD_MASK"), nullptr, 0) : 0xd9u;
-    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job, int tag) {
-        if (commit_early) {
-            pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job, (head_mask >> tag) & 1);
-        } else {
-            late.push_back([&, coeffs, n, has_bound, bound, hiding, job] {
-                pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
-            });
-        }
+    // Every commitment MSM is enqueued as soon as its polynomial exists (enqueueing a round's commitments together once ALL its
+    // polynomials are built — so that the transforms do not run beside an accumulation — measured no gain in r02 / r04: the early
+    // MSMs cover more than the slowed transforms cost; CHANGELOG.md).
+    auto begin_commit = [&](const Fr* coeffs, size_t n, bool has_bound, uint64_t bound, bool hiding, CommitJob* job, int /*tag*/) {
+        pc_commit_begin(ctx, pk, &lane, coeffs, n, has_bound, bound, hiding, job);
     };
-    auto flush_commits = [&] {
-        for (auto& f : late) f();
-        late.clear();
-        commit_flush(ctx);
-    };
+    auto flush_commits = [&] { commit_flush(ctx); };
     CommitJob j1[4];
     // mask polynomial: 3|H| uniform coefficients drawn from the caller's rng, H-sum forced to zero
     const size_t mask_len = 3 * H;  // degree 3|H| + 2 zk_bound - 3
@@ -1243,11 +1167,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // (mask_fix below): its term [c_0] g is one scalar multiplication on the host.  A commitment is a sum over coefficients, so
     // the pieces add up to the same group element: same bytes (test_callback_rng_reproduces_golden_bytes).  SWM_MASK_PIECES=1:
     // one piece (r02 - r04).  Sharded proofs keep one piece (their commitments are split over the ranks already).
-    static const unsigned mask_pieces_env = getenv("SWM_MASK_PIECES") ? (unsigned)std::min(3, std::max(1, atoi(getenv("SWM_MASK_PIECES")))) : 3u;
-    const unsigned mask_pieces = mask_late && ctx->shard_world <= 1 && commit_early && H >= 4096 ? mask_pieces_env : 1u;
+    static const unsigned mask_pieces_env = (unsigned)env_switch("SWM_MASK_PIECES", 3, 1, 3);
+    const unsigned mask_pieces = mask_late && ctx->shard_world <= 1 && H >= 4096 ? mask_pieces_env : 1u;
     AsyncMsm mask_part[2];
-    static const int mask_commit_env = getenv("SWM_MASK_COMMIT") ? std::min(2, std::max(0, atoi(getenv("SWM_MASK_COMMIT")))) : 0;
-    const int mask_commit_at = mask_late ? 0 : mask_commit_env;
     auto draw_mask = [&] {
         Fr* mp = mask.p;
         if (mask_pieces > 1) {
@@ -1258,8 +1180,14 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             j1[3].has_bound = false;
             j1[3].hiding = false;
             unsigned done_pieces = 0;
-            hipEvent_t piece_ev = nullptr;
-            hip_check(ctx, hipEventCreateWithFlags(&piece_ev, hipEventDisableTiming), "event");
+            struct PieceEvent {  // destroyed on every way out (commit_enqueue may throw from inside the draw's progress callback)
+                hipEvent_t e = nullptr;
+                ~PieceEvent() {
+                    if (e) (void)hipEventDestroy(e);
+                }
+            } piece_guard;
+            hip_check(ctx, hipEventCreateWithFlags(&piece_guard.e, hipEventDisableTiming), "event");
+            const hipEvent_t piece_ev = piece_guard.e;
             auto enqueue_piece = [&](unsigned pc) {  // the elements of the piece are written by kernels already on the copy stream
                 hip_check(ctx, hipEventRecord(piece_ev, ctx->copy_stream), "record");
                 hip_check(ctx, hipStreamWaitEvent(ctx->stream, piece_ev, 0), "wait");
@@ -1272,7 +1200,6 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             };
             sample_fr_bulk(ctx, zk, mp, mask_len, mask_late, &progress);
             while (done_pieces < 3) enqueue_piece(done_pieces++);  // (after the draw ctx->stream waits for all of it anyway)
-            (void)hipEventDestroy(piece_ev);
         } else {
             sample_fr_bulk(ctx, zk, mask.p, mask_len, mask_late);
         }
@@ -1281,14 +1208,8 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
             mp[0] = fp_neg(fp_add(mp[H], mp[2 * H]));
         });
         P_mask.p = mask.p; P_mask.n = mask_len;
-        if (mask_pieces == 1 && mask_commit_at == 0) begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3], 0);
-    };
-    // (experiment, built-in generator: the mask is sampled at the start either way — the draw fixes the generator's position for
-    // the blinding draws — but its 3|H|-point commitment can be enqueued behind w's (1) or behind z_B's (2) instead of first (0):
-    // an accumulation in flight starves the small kernels that prepare w, z_A and z_B)
-    auto commit_mask_at = [&](int where) {
-        if (!mask_late && mask_pieces == 1 && mask_commit_at == where && where != 0)
-            begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3], 0);
+        // (the mask's 3|H|-point commitment enqueued behind w's or behind z_B's instead of first: + 0.4 ... + 1.9 ms at 2^20, r05)
+        if (mask_pieces == 1) begin_commit(P_mask.p, P_mask.n, false, 0, false, &j1[3], 0);
     };
     if (mask_late) sample_fr_ext_mark(ctx);  // the transfers of the late draw only wait for what precedes the allocation
     else draw_mask();
@@ -1311,7 +1232,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const unsigned SG = ctx->shard_world;
     unsigned slog_g = 0;
     while ((1u << slog_g) < SG) slog_g++;
-    const bool shard_r1 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && pk.logH >= 2 * slog_g + 4 && !getenv("SWM_SHARD_R1_OFF") &&
+    const bool shard_r1 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && pk.logH >= 2 * slog_g + 4 && !env_flag("SWM_SHARD_R1_OFF") &&
                           commit_cyclic_possible(ctx, pk, H / SG);
     const size_t sm = H / (SG ? SG : 1);  // coefficients (evaluations) per rank
     DVec za_evals, zb_evals, za_loc, zb_loc;
@@ -1390,7 +1311,6 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     const size_t w_len = H + 1 - X;
     P_w.p = w_coeffs; P_w.n = w_len; P_w.hiding = true;
     begin_commit(P_w.p, P_w.n, false, 0, true, &j1[0], 1);
-    commit_mask_at(1);
     DVec za_poly = dv_zeros(ctx, H + 1), zb_poly = dv_zeros(ctx, H + 1);
     // sharded form of "interpolate, add rho v_H, commit" for one of the two polynomials
     auto sharded_interpolate_and_commit = [&](DVec& loc, const Fr& rho, DVec& poly, CommitJob* job) {
@@ -1429,14 +1349,10 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     P_za.p = za_poly.p; P_za.n = H + 1; P_za.hiding = true;
     P_zb.p = zb_poly.p; P_zb.n = H + 1; P_zb.hiding = true;
     if (!shard_r1) {
-        // (enqueue order only: the results are awaited and blinded in label order.  SWM_R1_ORDER=1: z_B's commitment ahead of
-        // z_A's — an MSM whose scalars are almost all zero has an accumulation too short to hide the sort of the job behind it)
-        static const bool zb_first = getenv("SWM_R1_ORDER") && atoi(getenv("SWM_R1_ORDER")) == 1;
-        if (zb_first) begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2], 2);
+        // (enqueue order only: the results are awaited and blinded in label order; z_B's ahead of z_A's: + 0.9 ms at 2^20, r05)
         begin_commit(P_za.p, P_za.n, false, 0, true, &j1[1], 2);
-        if (!zb_first) begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2], 2);
+        begin_commit(P_zb.p, P_zb.n, false, 0, true, &j1[2], 2);
     }
-    commit_mask_at(2);
     tr.mark("round 1 polynomials");
     std::vector<Commitment> comms1(4);
     if (!mask_late) flush_commits();  // round 1: all four commitments enqueued here; small ones share one bucket-stage launch
@@ -1447,7 +1363,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     // -> BLOCKS evaluations by ONE all-to-all each (ntt_sharded_run), pointwise on the blocks, BLOCKS -> CYCLIC back; the mask
     // and the division by v_H are local in the CYCLIC layout (G divides |H|: index j + k|H| stays on its rank).  h_1 and X g_1 are
     // all-gathered afterwards (4|H| x 32 B per proof): the openings work on whole polynomials.  SWM_SHARD_R2_OFF disables it.
-    const bool shard_r2 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && logM >= 2 * slog_g + 4 && !getenv("SWM_SHARD_R2_OFF");
+    const bool shard_r2 = SG > 1 && (1u << slog_g) == SG && SG <= 16 && logM >= 2 * slog_g + 4 && !env_flag("SWM_SHARD_R2_OFF");
     const size_t Mloc = shard_r2 ? M / SG : M, Mblk = shard_r2 ? Mloc / SG : M;
     const size_t s_rank = ctx->shard_rank, s_world = SG;
     auto on_mul_domain = [&](const Fr* coeffs, size_t n) {
@@ -1519,7 +1435,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
     {
         Fr a4h = alpha;
         for (unsigned i = 0; i < logM; i++) a4h = fp_sqr(a4h);
-        ra_closed_form = !fp_is_one(a4h) && !getenv("SWM_RALPHA_TRANSFORMS");
+        ra_closed_form = !fp_is_one(a4h) && !env_flag("SWM_RALPHA_TRANSFORMS");  // (test hook: the path of the 2^-231 case)
     }
     if (ra_closed_form && shard_r2) {
         // the rank's BLOCKS indices of the 4|H| domain for the product form; r(alpha, .) on H (every rank needs all of it for the
@@ -1680,10 +1596,9 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         commit_gather(ctx, {&j2[0].plain, &j2[1].plain, &j2[1].shifted, &j2[2].plain});
         pc_commit_end_round(ctx, pk, {&j2[0], &j2[1], &j2[2]}, {nullptr, &zk, nullptr}, {&P_t.rand, &P_g1.rand, &P_h1.rand},
                             comms2.data());
-        // (SWM_SHARD_EMULATE, measurement hook of tools/ubench/shard_emulate.py: one context plays a rank and its device exchanges
-        // hand back its own chunks — the values are wrong by construction and only the time is of interest)
-        static const bool emulated = getenv("SWM_SHARD_EMULATE") != nullptr;
-        if (unsat && !(emulated && ctx->shard_world > 1))
+        // (measurement builds only, -DSWM_MEASURE_HOOKS: a proof during which an EMULATED exchange actually ran — capi.hip — has wrong
+        // values by construction and only its time is of interest; the shipped library has no such path)
+        if (unsat && !ctx->emulated_exchange)
             throw MarlinError(SWM_ERR_UNSATISFIED, "outer sumcheck does not hold: constraint system is not satisfied");
     }
     tr.mark("round 2 commitments");
@@ -1875,8 +1790,7 @@ std::vector<uint8_t> prove_impl(swm_ctx* ctx, const swm_pk& pk, const swm_r1cs* 
         const Fr& pt = std::string(q.point) == "beta" ? beta : gamma;
         Fr v = provider(q.label, lcs.at(q.label), pt);
         if (lc_has_zero_eval(q.label)) {
-            static const bool emulated = getenv("SWM_SHARD_EMULATE") != nullptr;  // (see the outer sumcheck's check)
-            if (!fp_is_zero(v) && !(emulated && ctx->shard_world > 1))
+            if (!fp_is_zero(v) && !ctx->emulated_exchange)  // (see the outer sumcheck's check)
                 throw MarlinError(SWM_ERR_UNSATISFIED, std::string(q.label) + " does not evaluate to zero: constraint system is not satisfied");
             continue;
         }

@@ -71,8 +71,8 @@ bool msm_te_enabled();
 // HBM left for a table of `bytes` bytes? (hipMemGetInfo, keeping a quarter of the free memory for the prover's temporaries)
 bool msm_table_fits(size_t bytes);
 
-// a non-blocking stream for one role of the prover (SWM_PRIO_* experiment switches: msm.hip)
-hipError_t msm_create_stream(hipStream_t* out, const char* role_env);
+// a non-blocking stream for one role of the prover (msm.hip)
+hipError_t msm_create_stream(hipStream_t* out);
 // does msm_enqueue run the precomputed-window ("flat") schedule for n points on this table?  (callers that hand over a
 // strided layout have to know: only that schedule maps scalars to bases through MsmTable::blk_log / bstride)
 bool msm_flat_applies(const MsmTable& tab, size_t n);
@@ -101,7 +101,6 @@ struct MsmJob {
     G1XYZZ* host_dev = nullptr;          // the same slot as the device addresses it (the bucket stage writes there)
     uint32_t* host_flags_dev = nullptr;
     bool joint_tail = false;             // bucket stage launched together with the other jobs of its round
-    bool zero_copy = false;              // results written by the bucket stage into the pinned slot (no copies)
     const uint32_t* host_flags = nullptr;  // tail of the slot: [0] != 0 when a scalar was not a canonical field element
     hipEvent_t done = nullptr;
 };

@@ -54,10 +54,6 @@ WinLayout msm_plan(size_t n) {
     else if (n <= 98304) c = 12;
     else if (n <= 393216) c = 14;
     else c = 16;
-    if (const char* e = getenv("SWM_MSM_C")) {
-        int v = atoi(e);
-        if (v >= 2 && v <= 16) c = (unsigned)v;
-    }
     WinLayout L;
     L.nwin = (254 + c - 1) / c;
     unsigned base = 254 / L.nwin, extra = 254 % L.nwin;
@@ -100,7 +96,9 @@ WinLayout msm_table_layout(unsigned c) {
     return L;
 }
 unsigned msm_table_width(size_t n_bases) {
-    if (const char* e = getenv("SWM_MSM_TABLE_C")) return (unsigned)std::min(22, std::max(8, atoi(e)));
+    // SWM_MSM_TABLE_C: the width for every base set of the process (8 .. 22; tests/test_gpu_switches.py proves with 16 and 18)
+    static const long forced = env_switch("SWM_MSM_TABLE_C", 0, 8, 22);
+    if (forced) return (unsigned)forced;
     if (n_bases < 512) return 0;  // tiny base sets keep the per-window schedule
     // measured r02 (prove() at 2^10 .. 2^20 constraints, base sets of 3 x that): two bits above the size of the base
     // set up to 2^15 points — 4 .. 10 points per bucket for the MSMs of a proof, which keeps the accumulation chains
@@ -587,98 +585,6 @@ __global__ void __launch_bounds__(1024) msm_flat_partition(const uint32_t* __res
         tmp[gpos[b] + (i - start[b])] = e;
     }
 }
-// The same partition for a job whose sort runs BESIDE the accumulation of the job before it (r05).  That accumulation holds three
-// waves of 144 VGPRs on every SIMD: 80 registers per lane are free, i.e. room for ONE more wave per SIMD — a 256-lane workgroup
-// of at most 80 VGPRs becomes resident at once, while the 1024-lane kernel above (four waves per SIMD, 82 VGPRs) has to wait
-// until two of the three accumulation waves of all four SIMDs of a CU have retired (r05 timeline: 1 - 2.4 ms per partition beside
-// an accumulation, 0.2 ms alone, and the next accumulation waits for it).  Same tile (16 K digits, the pairs staged in 128 KB of
-// LDS: the accumulation uses none), same runs, same output; a lane takes 64 digits in rounds of 8 and reads them twice (the
-// second time from L2) instead of holding 16 in registers.  Alone on the chip it is the slower of the two (four waves per CU hide
-// less latency): the first job of a round, with nothing in flight, keeps the wide kernel.
-static constexpr uint32_t PARTN_THREADS = 256, PARTN_TILE = 16384, PARTN_U = 8;
-__global__ void __launch_bounds__(PARTN_THREADS, 6) msm_flat_partition_narrow(const uint32_t* __restrict__ digits, size_t n, uint32_t tstride,
-                                                                           uint32_t toff, unsigned blk_log, uint32_t bstride, unsigned fb,
-                                                                           uint32_t nbins, const uint32_t* __restrict__ win_off, uint32_t nwin,
-                                                                           uint32_t* __restrict__ bin_cursor, uint2* __restrict__ tmp) {
-    SWM_LIGHT_KERNEL();
-    extern __shared__ uint2 stage[];  // PARTN_TILE pairs | cnt, start, gpos (nbins words each, rounded up to 4) | scan words
-    const uint32_t nb4 = (nbins + 3) & ~3u;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PARTN_TILE);
-    uint32_t* start = cnt + nb4;
-    uint32_t* gpos = start + nb4;
-    uint32_t* scan = gpos + nb4;
-    const uint32_t w = blockIdx.y, t = threadIdx.x;
-    const size_t lo = (size_t)blockIdx.x * PARTN_TILE;
-    for (uint32_t b = t; b < nbins; b += PARTN_THREADS) cnt[b] = 0;
-    __syncthreads();
-    const uint32_t* d = digits + (size_t)w * n;
-#pragma unroll 1
-    for (uint32_t r = 0; r < PARTN_TILE / (PARTN_THREADS * PARTN_U); r++) {  // pass 1: counts per bin
-        uint32_t c[PARTN_U];
-#pragma unroll
-        for (int u = 0; u < (int)PARTN_U; u++) {
-            const size_t i = lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t;
-            c[u] = i < n ? d[i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < (int)PARTN_U; u++)
-            if (c[u]) atomicAdd(&cnt[((c[u] - 1) >> 1) >> fb], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of cnt over <= 4096 bins: 16 bins per lane in two halves of 8 (registers), shuffles inside a wave, the four
-    // wave totals through LDS
-    const uint32_t per = (nbins + PARTN_THREADS - 1) / PARTN_THREADS, b0 = t * per, b1 = min(b0 + per, nbins);
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += cnt[b];
-    uint32_t inc = sum;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t x = __shfl_up(inc, dd, 64);
-        if ((t & 63) >= (uint32_t)dd) inc += x;
-    }
-    if ((t & 63) == 63) scan[t >> 6] = inc;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (uint32_t wv = 0; wv < PARTN_THREADS / 64; wv++) {
-        const uint32_t x = scan[wv];
-        if (wv < (t >> 6)) before += x;
-        total += x;
-    }
-    uint32_t run = before + inc - sum;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t v = cnt[b];
-        start[b] = run;
-        cnt[b] = run;  // running cursor of the bin inside the staged tile
-        gpos[b] = v ? win_off[(size_t)b * FLAT_CUR_STRIDE + w] + atomicAdd(&bin_cursor[(size_t)b * FLAT_CUR_STRIDE + w], v) : 0u;
-        run += v;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t r = 0; r < PARTN_TILE / (PARTN_THREADS * PARTN_U); r++) {  // pass 2: the pairs, grouped by bin in the stage
-        uint32_t c[PARTN_U];
-#pragma unroll
-        for (int u = 0; u < (int)PARTN_U; u++) {
-            const size_t i = lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t;
-            c[u] = i < n ? d[i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < (int)PARTN_U; u++)
-            if (c[u]) {
-                const uint32_t bucket = (c[u] - 1) >> 1;
-                const uint32_t p = atomicAdd(&cnt[bucket >> fb], 1u);
-                const uint32_t i = (uint32_t)(lo + (size_t)(r * PARTN_U + u) * PARTN_THREADS + t);
-                const uint32_t row = w * tstride + toff + (i >> blk_log) * bstride + (i & ((1u << blk_log) - 1u));
-                stage[p] = make_uint2(row | (((c[u] - 1) & 1u) << 31), bucket);
-            }
-    }
-    __syncthreads();
-    for (uint32_t i = t; i < total; i += PARTN_THREADS) {
-        const uint2 e = stage[i];
-        const uint32_t b = e.y >> fb;
-        tmp[gpos[b] + (i - start[b])] = e;
-    }
-}
 // One workgroup per bin: bucket histogram of the bin, placement by bucket — and everything the accumulation and the bucket
 // stage need to know about the bin's buckets (r04; four launches — three scans over the histogram and a binary search per
 // segment — did this before): a bin is a contiguous bucket range whose first entry (bin_off) and first segment index
@@ -720,8 +626,6 @@ __device__ __forceinline__ void flat_seg_write(const FlatSegOut& o, uint32_t c, 
         atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
     }
 }
-// (BT lanes: 1024, or 256 for a sort that runs beside an accumulation — one more wave per SIMD fits next to its three, see
-// msm_flat_partition_narrow)
 template <int BT>
 __global__ void __launch_bounds__(BT) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
                                                                  const uint32_t* __restrict__ bin_off,
@@ -1550,7 +1454,6 @@ struct TailJob {
 };
 struct TailBatch {
     TailJob j[TAIL_MAX];
-    unsigned flags;  // bit 0 (msm_bucket_reduce_low, experiment SWM_LOW_SYNC_ALL): a barrier behind every step, walk steps included
 };
 // (RB = chains per workgroup; a chain is one lane, or Form::LANES of them: RB x LANES threads)
 template <int RB, class Form>
@@ -1839,8 +1742,8 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
         // barriers: the in-place scan needs its loads ahead of one and its stores behind it; a tree step and the fold are read by
         // other lanes in the NEXT step (trailing barrier); a walk step touches the lane's own slots only (the vote at the top
         // of the loop is the workgroup's only meeting point there)
-        const bool walk = phase == WALK && !(batch.flags & 1u);
-        te28_slot_add_sync(dst, pa, pq, act, phase == SCAN || (batch.flags & 1u));
+        const bool walk = phase == WALK;
+        te28_slot_add_sync(dst, pa, pq, act, phase == SCAN);
         if (!walk) __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1937,7 +1840,7 @@ int msm_table_build(swm_ctx* ctx, const G1Affine* d_points, size_t n, unsigned c
 }
 
 bool msm_te_enabled() {
-    static const bool on = !(getenv("SWM_MSM_TE") && atoi(getenv("SWM_MSM_TE")) == 0);
+    static const bool on = env_switch("SWM_MSM_TE", 1, 0, 1) != 0;  // 0: XYZZ tables everywhere (the form of sets outside the subgroup)
     return on;
 }
 bool msm_table_fits(size_t bytes) {
@@ -2025,14 +1928,14 @@ int msm_install_bases(swm_ctx* ctx, const G1Affine* d_points, size_t n, bool in_
     // replicated item: the table is as many bits narrower as the width rule gives for the rank's share of the set, at most
     // log2(G) - 1.  Measured per rank (tools/ubench/shard_emulate.py, same box): 2^20 constraints, G = 8: c = 20 / 18 / 17 ->
     // 23.7 / 20.9 / 20.9 ms; G = 4: flat; 2^22 constraints (1.5 M points per rank and more): 20 stays best (18: + 3 %).
-    if (*c > 12 && ctx->shard_world >= 4 && !getenv("SWM_MSM_TABLE_C")) {
+    if (*c > 12 && ctx->shard_world >= 4 && !env_switch("SWM_MSM_TABLE_C", 0, 8, 22)) {
         unsigned lg = 0;
         while ((2u << lg) <= ctx->shard_world) lg++;
         const unsigned share = msm_table_width(std::max<size_t>(n / ctx->shard_world, 512));
         const unsigned delta = share && share < *c ? std::min(*c - share, lg - 1) : 0;
         *c = std::max(12u, *c - delta);
     }
-    if (getenv("SWM_TRACE")) fprintf(stderr, "[swm] base set of %zu points: table width %u (world %u)\n", n, *c, ctx->shard_world);
+    if (env_flag("SWM_TRACE")) fprintf(stderr, "[swm] base set of %zu points: table width %u (world %u)\n", n, *c, ctx->shard_world);
     if (*c && (uint64_t)n * msm_table_windows(*c) >= (1ull << 31)) *c = 0;  // the sort addresses table rows with 31 bits
     const unsigned W = *c ? msm_table_windows(*c) : 0;
     if (*c && msm_te_enabled()) {
@@ -2102,19 +2005,11 @@ static int streams_concurrent(swm_ctx* ctx, hipStream_t x, hipStream_t y, bool* 
 // The prover alternates lanes, so that the latency-bound tail of one MSM (bucket fold, window reduction, download)
 // and the sort of the next overlap with the VALU-bound accumulation.  Scratch is per lane (stream-ordered reuse);
 // results land in per-job pinned host slots.
-// Stream of one of the roles main / sort / accumulation / tail.  SWM_PRIO_MAIN, _SORT, _ACC, _TAIL (experiment switches):
-// -1 = the device's highest stream priority, 1 = its lowest, unset / 0 = the default — the hardware scheduler then prefers the
-// waves of the higher-priority queue whenever a CU has room.
-hipError_t msm_create_stream(hipStream_t* out, const char* role_env) {
-    int lo = 0, hi = 0;  // lo: least priority (numerically largest), hi: greatest
-    const char* e = getenv(role_env);
-    const int want = e ? atoi(e) : 0;
-    if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
-        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, want < 0 ? hi : lo);
-}
+// Stream of one of the roles main / sort / accumulation / tail: non-blocking, default priority (stream priorities per role were
+// measured in r04 / r05 — every assignment slower, CHANGELOG.md — and are gone; what orders the kernels on the chip is s_setprio).
+hipError_t msm_create_stream(hipStream_t* out) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 bool msm_flat_applies(const MsmTable& tab, size_t n) {
-    static const bool no_table = getenv("SWM_MSM_NO_TABLE") != nullptr;
+    static const bool no_table = env_flag("SWM_MSM_NO_TABLE");  // the per-window schedule for every set (what table-less sets run)
     return tab.any() && !no_table && n >= ((size_t)1 << (tab.c > 8 ? tab.c - 8 : 0)) &&
            (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
 }
@@ -2146,7 +2041,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // a throughput problem): short segments (8 points), every bucket with more than two segments folded by a lane
     // group in msm_big_bucket_sum (a tree instead of the serial walk of the bucket stage), one bucket per lane in the
     // bucket stage
-    static const size_t lat_below = getenv("SWM_MSM_LAT_BELOW") ? (size_t)atol(getenv("SWM_MSM_LAT_BELOW")) : 262144;
+    static constexpr size_t lat_below = 262144;
     const bool lat = flat && n < lat_below;
     WinLayout pl = flat ? msm_table_layout(tab.c) : msm_plan(n);
     // rl: the layout the bucket stage and the host fold see — one window of 2^(c-1) buckets in the flat schedule
@@ -2163,23 +2058,17 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // workgroups of all jobs have to be resident together (one per CU: 96 KB of LDS each), which four buckets per lane allow
     unsigned log_m = pl.maxB <= 2048 ? (defer_tail ? 2 : 0) : 2;
     if (lat) log_m = 0;
-    if (const char* e = getenv("SWM_MSM_LOGM")) log_m = (unsigned)atoi(e);
     // (A, R) pairs per window that fit a result slot and that the host folds: 16 per window, or 256 for the single
     // window of the flat schedule (one workgroup per CU either way)
-    // workgroup width of the bucket stage: 256 lanes.  SWM_RED_LANES=64 (flat schedule only) switches to single-wave
-    // workgroups of 64 lanes (36 KB of LDS) that could be placed on ANY SIMD with room, i.e. beside accumulation waves,
-    // where the 256-lane form needs all four SIMDs of a CU at once — measured r02: the stage itself takes 1.00 instead of
-    // 0.72 ms (1024 workgroup results to fold instead of 256) and a 2^20 proof 82.7 instead of 77.4 ms: not the default.
-    static const unsigned flat_rb = getenv("SWM_RED_LANES") ? (unsigned)atoi(getenv("SWM_RED_LANES")) : 256u;
+    // workgroup width of the bucket stage: 256 lanes (single-wave workgroups of 64 lanes were measured in r02: the stage 1.00
+    // instead of 0.72 ms, a 2^20 proof 82.7 instead of 77.4 ms).
     // Low-latency schedule on twisted Edwards rows: every chain of the bucket stage is worked by a quad of lanes (FormTEQuad;
-    // SWM_MSM_QUAD=0: one lane per chain as for large jobs).  SWM_MSM_QUAD_RB: chains per workgroup (64 / 128 / 256, i.e. 256 /
-    // 512 / 1024 threads), SWM_MSM_QUAD_BLOCKS: workgroups per job at most.
-    static const bool quad_on = !getenv("SWM_MSM_QUAD") || atoi(getenv("SWM_MSM_QUAD")) != 0;
-    static const unsigned quad_rb = getenv("SWM_MSM_QUAD_RB") ? (unsigned)atoi(getenv("SWM_MSM_QUAD_RB")) : 128u;
-    static const unsigned quad_blocks = getenv("SWM_MSM_QUAD_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_QUAD_BLOCKS"))) : 64u;
-    static const unsigned quad_maxb = getenv("SWM_MSM_QUAD_MAXB") ? (unsigned)atoi(getenv("SWM_MSM_QUAD_MAXB")) : 32768u;
-    const bool quad = lat && te && quad_on && flat_rb != 64 && pl.maxB <= quad_maxb;
-    const unsigned rb = quad ? (quad_rb == 256 ? 256u : (quad_rb == 128 ? 128u : 64u)) : (flat ? (flat_rb == 64 ? 64u : 256u) : 256u);
+    // SWM_MSM_QUAD=0: one lane per chain as for large jobs): 128 chains per workgroup (512 threads), at most 64 workgroups per
+    // job, bucket sets up to 2^15 (r04 sweeps, CHANGELOG.md).
+    static const bool quad_on = env_switch("SWM_MSM_QUAD", 1, 0, 1) != 0;
+    static constexpr unsigned quad_rb = 128u, quad_blocks = 64u, quad_maxb = 32768u;
+    const bool quad = lat && te && quad_on && pl.maxB <= quad_maxb;
+    const unsigned rb = quad ? quad_rb : 256u;
     job->quad = quad;
     // One-lane twisted Edwards stages may take the low-LDS kernel (msm_bucket_reduce_low: 49 KB per workgroup);
     // SWM_MSM_LOW=0: always the 144-KB kernel of r02 - r04.  SWM_MSM_LOW_BLOCKS: workgroups a stage may be cut into (result slot:
@@ -2187,18 +2076,18 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // r05, last collection: in the JOINT stage of deferred jobs (shaped by msm_joint_shape) it is worth 0.1 - 0.3 ms per mid-size
     // proof (2^16 7.2 -> 7.07, 2^18 17.2 -> 16.9, Merkle circuit 15.0 -> 14.7 ms); for the thin stages of large jobs it costs
     // 0.8 ms at 2^20 (two workgroups per CU).  SWM_MSM_LOW: 2 (default) = joint stages only, 1 = every one-lane stage, 0 = never.
-    static const int low_mode = getenv("SWM_MSM_LOW") ? atoi(getenv("SWM_MSM_LOW")) : 2;
+    static const long low_mode = env_switch("SWM_MSM_LOW", 2, 0, 2);
     const bool low_on = low_mode == 1 || (low_mode == 2 && defer_tail);
-    static const unsigned low_blocks = getenv("SWM_MSM_LOW_BLOCKS") ? (unsigned)std::min(1024, std::max(16, atoi(getenv("SWM_MSM_LOW_BLOCKS")))) : 256u;
+    static constexpr unsigned low_blocks = 256u;
     // (joint stages of small jobs: SWM_MSM_JOINT_BLOCKS workgroups per job — with the low-LDS kernel twelve waves per CU are resident)
     // 64 per job: the four stages of a round's launch are resident together, one workgroup per CU — in the low-latency schedule
     // (r02) and for the larger jobs that join a round's launch since r05 (up to 10^6 points: 2^19 buckets -> 32 per lane).  With the
     // low-LDS kernel 128 per job (two workgroups per CU) measured SLOWER per launch: 1.43 against 1.06 ms for four 2^19-bucket jobs.
-    static const unsigned joint_blocks = getenv("SWM_MSM_JOINT_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("SWM_MSM_JOINT_BLOCKS"))) : 64u;
+    static constexpr unsigned joint_blocks = 64u;
     const bool low = te && !quad && rb == 256 && low_on;
     job->low = low;
     // (low-latency schedule: the bucket stages of a round's four MSMs run in one launch and have to be resident together)
-    const unsigned max_blocks = quad ? quad_blocks : (flat ? (rb == 64 ? 1024u : (defer_tail ? joint_blocks : (low ? low_blocks : 256u))) : 16u);
+    const unsigned max_blocks = quad ? quad_blocks : (flat ? (defer_tail ? joint_blocks : (low ? low_blocks : 256u)) : 16u);
     job->max_blocks = low ? std::max(max_blocks, low_blocks) : std::max(max_blocks, 256u);
     while (((pl.maxB >> log_m) + rb - 1) / rb > max_blocks) log_m++;
     unsigned red_blocks = ((pl.maxB >> log_m) + rb - 1) / rb;
@@ -2214,26 +2103,23 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // the accumulation that last read it has finished).  lane < 0: everything on the context's stream (K1 ABI).
     hipStream_t main_stream = ctx->stream;
     hipStream_t st_sort = main_stream, st_acc = main_stream, st_tail = main_stream;
-    // SWM_MSM_PIPE: 0 = lane is the stream for all three stages (r01 schedule), 1 = S | A | T, 2 = S | A0, A1 by lane | T
-    // (two accumulations may overlap: one alone leaves bubbles at the end of its length-sorted grid).  Small MSMs keep
-    // the single stream: the extra event hops cost more than they hide.
-    static const int pipe_mode = getenv("SWM_MSM_PIPE") ? atoi(getenv("SWM_MSM_PIPE")) : 2;
+    // S | A0, A1 by lane | T (two accumulations may overlap: one alone leaves bubbles at the end of its length-sorted grid).
+    // Small MSMs keep a single stream: the extra event hops cost more than they hide.
     // r05: a proof whose commitments fall on both sides of the bound ran them on streams that alias (a small job's lane stream is
     // a large job's accumulation or bucket-stage stream): at 2^16 constraints — 65 535-point and 196 608-point commitments — the
     // opening's second sort waited for the first accumulation.  The prover therefore sets ctx->msm_pipe_min per proof (every
     // commitment of a proof up to 2^19 constraints on one stream of its lane, four lanes: 2^16 7.05 -> 6.5 ms, 2^19 29.4 -> 28.6 ms;
-    // from 2^20 on the three-stage pipeline is ahead.  SWM_MSM_PIPE_MIN overrides both).
-    static const long pipe_env = getenv("SWM_MSM_PIPE_MIN") ? atol(getenv("SWM_MSM_PIPE_MIN")) : -1;
-    const size_t pipe_min = pipe_env >= 0 ? (size_t)pipe_env : (ctx->msm_pipe_min ? ctx->msm_pipe_min : (size_t)131072);
-    const bool one_stream = pipe_mode == 0 || n < pipe_min;
+    // from 2^20 on the three-stage pipeline is ahead).
+    const size_t pipe_min = ctx->msm_pipe_min ? ctx->msm_pipe_min : (size_t)131072;
+    const bool one_stream = n < pipe_min;
     if (lane >= 0) {
         // small MSMs: four single-stream lanes (scratch sets 0 .. 3 on the streams 1, 2, 3, 0), so that the launch chains of
         // all four commitments of a prover round proceed side by side; sets 0 and 1 are shared with the pipelined form,
         // whose accumulations run on the same streams 1 and 2 (stream order covers the reuse)
-        static const int small_lanes = getenv("SWM_MSM_SMALL_LANES") ? std::min(4, std::max(1, atoi(getenv("SWM_MSM_SMALL_LANES")))) : 4;
-        // scratch sets of the pipelined form: with two, the sort of job k + 2 waits for the accumulation of job k; with more
-        // (SWM_MSM_SETS, up to 4) the sorts of a round run further ahead of its accumulations (memory: ~110 B per digit and set)
-        static const int sets = getenv("SWM_MSM_SETS") ? std::min(4, std::max(2, atoi(getenv("SWM_MSM_SETS")))) : 2;
+        static constexpr int small_lanes = 4;
+        // scratch sets of the pipelined form: two — the sort of job k + 2 waits for the accumulation of job k (four sets, the
+        // sorts running further ahead, measured nothing in r04; memory: ~110 B per digit and set)
+        static constexpr int sets = 2;
         lane %= one_stream ? small_lanes : sets;
         if (!ctx->aux_stream[0]) {
             // Hardware-queue placement.  ROCm 7 hands its hardware queues (four by default) to streams in creation order,
@@ -2245,22 +2131,20 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             // cannot overlap, each fills the register files).  A placeholder stream before the tail stream gives that in the
             // usual creation history; the result is PROBED (streams_concurrent) and a stream that shares a queue with an
             // earlier role is replaced by a fresh one, a few times at most — whatever streams the host application created
-            // before.  SWM_MSM_QUEUE_ORDER=0 keeps the plain creation order and skips the probe.
-            static const bool steer = !(getenv("SWM_MSM_QUEUE_ORDER") && atoi(getenv("SWM_MSM_QUEUE_ORDER")) == 0);
+            // before.
+            static constexpr bool steer = true;
             // The four streams are created and probed into locals and published to the context only when all of it
             // succeeded: a failure half way must not leave aux_stream[0] set with the later entries null (every later MSM
             // would skip this block and silently run its tail on the legacy default stream).
-            hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            hipStream_t aux[swm_ctx::MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};
             auto setup = [&]() -> int {
-                static const char* role_env[swm_ctx::MSM_LANES] = {"SWM_PRIO_SORT", "SWM_PRIO_ACC", "SWM_PRIO_ACC", "SWM_PRIO_TAIL", "SWM_PRIO_TAIL"};
-                for (int i = 0; i < 3; i++) SWM_HIP(ctx, msm_create_stream(&aux[i], role_env[i]));
+                for (int i = 0; i < 3; i++) SWM_HIP(ctx, msm_create_stream(&aux[i]));
                 if (steer) {
                     hipStream_t ph = nullptr;
                     SWM_HIP(ctx, hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
                     ctx->spare_streams.push_back(ph);
                 }
-                SWM_HIP(ctx, msm_create_stream(&aux[3], role_env[3]));
-                SWM_HIP(ctx, msm_create_stream(&aux[4], role_env[4]));  // (not probed: shares a hardware queue with whatever the runtime picks)
+                SWM_HIP(ctx, msm_create_stream(&aux[3]));
                 if (steer) {
                     SWM_HIP(ctx, hipStreamSynchronize(main_stream));
                     const int roles[3] = {0, 1, 3};  // sort, accumulation 0, tail
@@ -2280,7 +2164,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                             if (!clash || budget-- <= 0) break;
                             ctx->spare_streams.push_back(aux[r]);  // kept alive: destroying it would free its slot
                             aux[r] = nullptr;
-                            SWM_HIP(ctx, msm_create_stream(&aux[r], role_env[r]));
+                            SWM_HIP(ctx, msm_create_stream(&aux[r]));
                         }
                         fixed.push_back(aux[r]);
                     }
@@ -2302,11 +2186,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
             st_sort = st_acc = st_tail = ctx->aux_stream[lane_stream[lane]];
         } else {
             st_sort = ctx->aux_stream[0];
-            st_acc = ctx->aux_stream[pipe_mode == 1 ? 1 : 1 + (lane & 1)];
-            // SWM_MSM_TAILS=2 (experiment): the bucket stages of consecutive jobs alternate between two streams, so that the thin
-            // stage of job k (beside the accumulation of job k + 1) does not hold back the stage of job k + 1
-            static const int tails = getenv("SWM_MSM_TAILS") ? std::min(2, std::max(1, atoi(getenv("SWM_MSM_TAILS")))) : 1;
-            st_tail = ctx->aux_stream[tails == 2 && (ctx->next_slot & 1) ? 4 : 3];
+            st_acc = ctx->aux_stream[1 + (lane & 1)];
+            st_tail = ctx->aux_stream[3];  // (a second bucket-stage stream: 51.4 -> 57.4 ms at 2^20, r05)
         }
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
@@ -2333,10 +2214,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     job->host_flags = reinterpret_cast<const uint32_t*>((char*)job->host + flags_off);
     job->host_dev = reinterpret_cast<G1XYZZ*>((char*)ctx->pinned_dev + slot_bytes * slot);
     job->host_flags_dev = reinterpret_cast<uint32_t*>((char*)job->host_dev + flags_off);
-    // the bucket stage writes its results straight into the pinned slot (see msm_bucket_reduce; SWM_MSM_ZERO_COPY=0: the
-    // stream-ordered copies — measured r02 on one box: 2^16 proofs 11.8 vs 11.4 ms, 2^20 75.7 vs 75.1 ms)
-    static const int zc_env = getenv("SWM_MSM_ZERO_COPY") ? atoi(getenv("SWM_MSM_ZERO_COPY")) : -1;
-    job->zero_copy = zc_env != 0;
+    // the bucket stage writes its results straight into the pinned slot (see msm_bucket_reduce; against stream-ordered copies,
+    // r02 on one box: 2^16 proofs 11.4 vs 11.8 ms, 2^20 75.1 vs 75.7 ms)
     job->done = ctx->slot_event[slot];
     if (!ctx->acc_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->acc_event[slot], hipEventDisableTiming));
     job->acc_done = ctx->acc_event[slot];
@@ -2403,7 +2282,6 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     // (r05, prefix tables: a job of |H| points on a table one bit narrower than before has ~14 entries per bucket — with 16-point
     // segments a quarter of the buckets would split in two and the bucket stage walk 2.3 instead of 2 steps per bucket)
     if (lat && total / pl.NB >= 10) SEG = 32;
-    if (const char* e = getenv("SWM_MSM_SEG")) SEG = std::min<uint32_t>(SEG_MAX, std::max(1, atoi(e)));
     // segments per bucket above which a bucket is folded ahead of the bucket stage, and the lanes that fold one
     uint32_t big_nseg = BIG_NSEG;
     unsigned log_g = 8;
@@ -2416,8 +2294,6 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         log_g = 2;
         while (log_g < 6 && ((size_t)1 << log_g) < 2 * per_bucket) log_g++;
     }
-    if (const char* e = getenv("SWM_MSM_LOGG")) log_g = std::min(8, std::max(0, atoi(e)));
-    if (const char* e = getenv("SWM_MSM_BIG_NSEG")) big_nseg = (uint32_t)std::max(1, atoi(e));
     job->big_nseg = big_nseg;
     // every bucket adds at most one short segment; the flat schedule hands out segment indices per coarse bin with the bin's
     // capacity (msm_flat_scan_bins): at most one more per bucket slot of the (padded) bins
@@ -2425,7 +2301,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     uint32_t *hist, *cursor, *big_count, *len_hist, *bucket_off, *seg_off, *digits, *sorted, *big_list, *tot_cnt, *tot_seg;
     uint32_t *seg_start, *seg_len, *order;
     // two-level scatter for large MSMs (see msm_partition): bins of ~8 k entries, sized per window
-    bool two_level = !flat && n >= 262144 && pl.maxB >= 8192 && !getenv("SWM_MSM_ONE_LEVEL");
+    bool two_level = !flat && n >= 262144 && pl.maxB >= 8192;
     BinPlan bp;
     memset(&bp, 0, sizeof(bp));
     if (two_level) {
@@ -2467,7 +2343,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (flat) {
         // as few bins as the LDS of msm_flat_bin_sort allows (FLAT_BIN_CAP entries): every (tile, bin) run of the partition
         // costs one global atomic, and with ~2 entries per run those atomics (27 M at 2^22 points) were the whole kernel
-        static const size_t bin_target = getenv("SWM_FLAT_BIN_TARGET") ? (size_t)atol(getenv("SWM_FLAT_BIN_TARGET")) : 28000;
+        static constexpr size_t bin_target = 28000;  // (14 000: 52.3 - 52.5 vs 51.4 ms at 2^20, r04)
         // (small MSMs: at least ~1024 bins as long as a bin keeps 1024 entries — 64 bins meant 64 workgroups in the bin
         // sort and 1024 lanes contending for 64 LDS counters in the coarse histogram)
         const size_t target = std::min(bin_target, std::max<size_t>(1024, total / 1024));
@@ -2534,26 +2410,16 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (pl.nwin > FLAT_CUR_STRIDE) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many windows for the flat sort");
         // digits per workgroup of the partition: 16 K (r04: half the (tile, bin) runs and reserving atomics of 8 K tiles, one
         // workgroup per CU instead of two — prove 2^20 51.6 -> 51.0 ms, and the transforms beside it run a quarter faster) as long
-        // as the pairs and the three per-bin arrays fit the 160 KB of LDS (up to 2 048 bins); 8 K above (SWM_FLAT_PART_TILE=8192: always)
-        static const bool tile16_ok = !getenv("SWM_FLAT_PART_TILE") || atoi(getenv("SWM_FLAT_PART_TILE")) >= 16384;
+        // as the pairs and the three per-bin arrays fit the 160 KB of LDS (up to 2 048 bins); 8 K above
         const size_t lds_bins = (3 * (size_t)((flat_bins + 3) & ~3u) + 1024) * 4;
-        const bool tile16 = tile16_ok && 16384 * sizeof(uint2) + lds_bins <= 160 * 1024;
+        const bool tile16 = 16384 * sizeof(uint2) + lds_bins <= 160 * 1024;
         const uint32_t part_tile = tile16 ? 16384u : 8192u;
         const size_t lds_part = (size_t)part_tile * sizeof(uint2) + lds_bins;
         SWM_TRY(allow_big_lds(ctx, tile16 ? 10 : 5, tile16 ? (const void*)msm_flat_partition<16> : (const void*)msm_flat_partition<8>, lds_part));
         const size_t lds_bin = ((size_t)FLAT_BIN_CAP + 2 * ((size_t)1 << flat_fb)) * 4;
         SWM_TRY(allow_big_lds(ctx, 6, (const void*)msm_flat_bin_sort<BIN_THREADS>, lds_bin));
-        SWM_TRY(allow_big_lds(ctx, 11, (const void*)msm_flat_bin_sort<256>, lds_bin));
-        // A sort that runs beside the accumulation of the job before it takes the 256-lane forms of the partition and the bin sort
-        // (resident at once next to the accumulation's three waves per SIMD); the first job after a wait — nothing in flight —
-        // the 1024-lane forms, which are faster alone.  SWM_SORT_NARROW=0: always the wide forms (r02 - r04), 2: always narrow.
-        // Measured r05 on top of the issue priorities (ff.cuh SWM_LIGHT_PRIO), alternating on one box: prove 2^20 50.8 ms wide, 51.15 ms
-        // with this rule, 52.0 ms always narrow — with s_setprio the wide kernels no longer wait long enough for the narrow ones'
-        // lower throughput to pay.  Default 0; kept as a switch (tests/test_gpu_switches.py).
-        static const int narrow_env = getenv("SWM_SORT_NARROW") ? atoi(getenv("SWM_SORT_NARROW")) : 0;
-        const bool narrow_sort = lane >= 0 && !lat && (narrow_env == 2 || (narrow_env == 1 && ctx->msm_since_wait > 0)) &&
-                                 (size_t)PARTN_TILE * sizeof(uint2) + lds_bins <= 160 * 1024;
-        if (narrow_sort) SWM_TRY(allow_big_lds(ctx, 12, (const void*)msm_flat_partition_narrow, (size_t)PARTN_TILE * sizeof(uint2) + lds_bins));
+        // (256-lane forms of the partition and the bin sort for sorts that run beside an accumulation: built and measured in r05 —
+        // 51.15 vs 50.8 ms at 2^20 with the issue priorities in place — and removed in r06)
         SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_coarse_hist, dim3((unsigned)((n + ctile - 1) / ctile), pl.nwin), dim3(SORT_THREADS), 0,
                    digits, n, flat_fb, flat_bins, ctile, flat_cnt);
         unsigned scan_threads = 64;
@@ -2565,11 +2431,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         else
             SWM_LAUNCH(ctx, "msm_flat_hist", msm_flat_scan_bins<4>, dim3(1), dim3(scan_threads), 0, flat_cnt, flat_bins, pl.nwin, flat_off, flat_win_off,
                    flat_fb, SEG, flat_seg_off);
-        if (narrow_sort)
-            SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition_narrow, dim3((unsigned)((n + PARTN_TILE - 1) / PARTN_TILE), pl.nwin),
-                   dim3(PARTN_THREADS), (size_t)PARTN_TILE * sizeof(uint2) + lds_bins, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset,
-                   tab.blk_log, (uint32_t)tab.bstride, flat_fb, flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
-        else if (tile16)
+        if (tile16)
             SWM_LAUNCH(ctx, "msm_flat_partition", msm_flat_partition<16>, dim3((unsigned)((n + part_tile - 1) / part_tile), pl.nwin),
                    dim3(1024), lds_part, digits, n, (uint32_t)tab.stride, (uint32_t)tab.offset, tab.blk_log, (uint32_t)tab.bstride, flat_fb,
                    flat_bins, flat_win_off, pl.nwin, flat_cur, pairs);
@@ -2580,16 +2442,11 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
         // the bin sort: no scans over the bucket histogram, no msm_seg_desc)
         const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg, te ? 1u : 0u};
-        if (narrow_sort)
-            SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<256>, dim3(flat_bins), dim3(256), lds_bin,
-                       (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
-        else
-            SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<BIN_THREADS>, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
-                       (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
+        SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<BIN_THREADS>, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
+                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
     } else {
         // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
-        uint32_t SORT_TILE = SORT_TILE_MIN;
-        if (const char* e = getenv("SWM_SORT_TILE_LOG")) SORT_TILE = 1u << atoi(e);
+        const uint32_t SORT_TILE = SORT_TILE_MIN;
         unsigned tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
         size_t lds_sort = (size_t)pl.maxB * 4;
         SWM_TRY(allow_big_lds(ctx, 0, (const void*)msm_hist, lds_sort));
@@ -2630,21 +2487,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
                dim3(ORD2_THREADS), 0, seg_len, seg_space, SEG,
                len_hist, order);
     unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
-    static const unsigned acc_cap = getenv("SWM_ACC_WGS") ? (unsigned)atoi(getenv("SWM_ACC_WGS")) : 0u;
-    if (acc_cap && lane >= 0) acc_grid = std::min(acc_grid, acc_cap);
     const dim3 big_grid(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512));
     if (te) {
-        // SWM_ACC_LDS: dynamic LDS bytes per accumulation workgroup — an occupancy cap for experiments (54 000: three
-        // workgroups per CU instead of the four its 121 VGPRs allow)
-        static const size_t acc_lds = getenv("SWM_ACC_LDS") ? (size_t)atol(getenv("SWM_ACC_LDS")) : 0;
-        // small jobs: four lanes per segment
-        // (SWM_MSM_QUAD_ACC: digits up to which a job takes it, 0 = never)
-        static const size_t quad_acc = getenv("SWM_MSM_QUAD_ACC") ? (size_t)atol(getenv("SWM_MSM_QUAD_ACC")) : 1048576;
-        if (lat && total <= quad_acc)
+        // small jobs (up to 2^20 digits: r04 sweep): four lanes per segment
+        static constexpr size_t quad_acc = 1048576;
+        if (lat && total <= quad_acc && quad_on)
             SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te_quad, dim3((unsigned)((nseg_max + 63) / 64)), dim3(256), 0, tab.te, sorted,
                        seg_start, seg_len, order, nseg_live, partial);
         else
-            SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), acc_lds, tab.te, sorted, seg_start,
+            SWM_LAUNCH(ctx, "msm_accumulate", msm_accumulate_te, dim3(acc_grid), dim3(256), 0, tab.te, sorted, seg_start,
                        seg_len, order, nseg_live, partial);
         SWM_LAUNCH(ctx, "msm_big_bucket_sum", msm_big_bucket_sum<FormTE>, big_grid, dim3(RED_BLOCK), RED_BLOCK * sizeof(G1XYZZ),
                    partial, seg_off, hist, SEG, big_count, big_list, log_g);
@@ -2675,8 +2526,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         ctx->pending_tails.push_back(job);
         return SWM_OK;
     }
-    static const bool lazy_on = !(getenv("SWM_MSM_LAZY_TAIL") && atoi(getenv("SWM_MSM_LAZY_TAIL")) == 0);
-    if (lazy_on && flat && !lat && lane >= 0 && rb == 256 && tab.shard_world <= 1 && !getenv("SWM_MSM_LOGM")) {
+    if (flat && !lat && lane >= 0 && rb == 256 && tab.shard_world <= 1) {
         ctx->lazy_tail = job;  // shaped and launched by the next msm_enqueue (thin) or by the flush of the round (wide)
         return SWM_OK;
     }
@@ -2692,10 +2542,9 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
 // on with the next job.  So: WIDE (m = 8, shortest chain) when the stage is exposed — the last job before a flush, i.e. of
 // a prover round —, THIN (m = 32) when another job follows.  The job's result slot takes up to 256 workgroup results either way.
 static void msm_tail_shape(MsmJob* j, bool wide) {
-    static const unsigned thin_log_m = getenv("SWM_MSM_LOGM_THIN") ? (unsigned)std::min(8, std::max(2, atoi(getenv("SWM_MSM_LOGM_THIN")))) : 5u;
-    // (SWM_MSM_LOGM_WIDE: log2 buckets per lane of the wide shape before the workgroup cap applies — 2; the cap is the job's
-    // max_blocks: 256, or SWM_MSM_LOW_BLOCKS with the low-LDS kernel)
-    static const unsigned wide_log_m = getenv("SWM_MSM_LOGM_WIDE") ? (unsigned)std::min(8, std::max(0, atoi(getenv("SWM_MSM_LOGM_WIDE")))) : 2u;
+    // log2 buckets per lane: thin 32 (16 / 8 per lane: 51.5 / 52.5 vs 52.0 ms, r05); wide 4 before the workgroup cap applies
+    // (the cap is the job's max_blocks: 256, which makes it 8 per lane for 2^19 buckets)
+    static constexpr unsigned thin_log_m = 5u, wide_log_m = 2u;
     unsigned log_m = wide ? wide_log_m : thin_log_m;
     while (((j->pl.maxB >> log_m) + j->rb - 1) / j->rb > j->max_blocks) log_m++;
     j->log_m = log_m;
@@ -2731,11 +2580,11 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         batch.j[i].seg_off = j->d_seg_off;
         batch.j[i].hist = j->d_hist;
         batch.j[i].seg = j->seg;
-        batch.j[i].out = j->zero_copy ? j->host_dev : j->d_wpart;
+        batch.j[i].out = j->host_dev;
         batch.j[i].acc = j->d_acc;
         batch.j[i].status = j->d_status;
         batch.j[i].entries = j->d_entries;
-        batch.j[i].host_flags = j->zero_copy ? j->host_flags_dev : nullptr;
+        batch.j[i].host_flags = j->host_flags_dev;
         batch.j[i].log_m = j->log_m;
         batch.j[i].red_blocks = j->red_blocks;
         batch.j[i].blk_lo = j->blk_lo;
@@ -2746,8 +2595,6 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         max_red = std::max(max_red, j->red_blocks);
         max_win = std::max(max_win, j->pl.nwin);
     }
-    static const bool low_sync_all = getenv("SWM_LOW_SYNC_ALL") != nullptr;
-    batch.flags = low_sync_all ? 1u : 0u;
     const bool te = jobs[0]->te;  // every job of a launch has the same point form (msm_flush_tails groups them)
     if (jobs[0]->quad) {
         const size_t lds = (3 * (size_t)jobs[0]->rb + 1) * sizeof(G1XYZZ);
@@ -2755,19 +2602,10 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         if (jobs[0]->rb == 256) {
             SWM_TRY(allow_big_lds(ctx, 8, (const void*)msm_bucket_reduce<256, FormTEQuad>, lds));
             SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormTEQuad>), grid, dim3(1024), lds, batch);
-        } else if (jobs[0]->rb == 128) {
+        } else {
             SWM_TRY(allow_big_lds(ctx, 9, (const void*)msm_bucket_reduce<128, FormTEQuad>, lds));
             SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<128, FormTEQuad>), grid, dim3(512), lds, batch);
-        } else {
-            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormTEQuad>), grid, dim3(256), lds, batch);
         }
-    } else if (jobs[0]->rb == 64) {
-        if (te)
-            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(64),
-                       (3 * 64 + 1) * sizeof(G1XYZZ), batch);
-        else
-            SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<64, FormXYZZ>), dim3(max_red, max_win, (unsigned)k), dim3(64),
-                       (3 * 64 + 1) * sizeof(G1XYZZ), batch);
     } else if (te && jobs[0]->low) {
         SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce_low<256>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
                    (RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
@@ -2781,15 +2619,6 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
                    (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
     }
     for (int i = 0; i < k; i++) {
-        MsmJob* j = jobs[i];
-        if (j->zero_copy) continue;
-        SWM_HIP(ctx, hipMemcpyAsync(j->host, j->d_wpart, (size_t)j->pl.nwin * j->red_blocks * 2 * sizeof(G1XYZZ),
-                                    hipMemcpyDeviceToHost, st));
-        SWM_HIP(ctx, hipMemcpyAsync((void*)j->host_flags, j->d_status, 4, hipMemcpyDeviceToHost, st));
-        SWM_HIP(ctx, hipMemcpyAsync((void*)(j->host_flags + 1), j->d_entries, 4, hipMemcpyDeviceToHost, st));
-        SWM_HIP(ctx, hipMemcpyAsync((void*)(j->host_flags + 2), j->d_status + 1, 4, hipMemcpyDeviceToHost, st));
-    }
-    for (int i = 0; i < k; i++) {
         SWM_HIP(ctx, hipEventRecord(jobs[i]->done, st));
         jobs[i]->tail_pending = false;
     }
@@ -2800,10 +2629,8 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
 // of buckets per lane (a power of two from 4) with which the workgroups of all k jobs fit one per CU.  One job: 8 per lane on
 // every CU (the wide shape); two 2^19-bucket jobs: 16 per lane, 128 workgroups each; four: 32 per lane; a round of three
 // 2^17-bucket jobs and one of 2^19 (the Merkle circuit's round 1 with its prefix tables): 16 per lane, 32 + 32 + 32 + 128.
-// (r02 - r04: 64 workgroups per job whatever the job.)  SWM_MSM_JOINT_ADAPT=0: that rule.
+// (r02 - r04: 64 workgroups per job whatever the job.)
 static void msm_joint_shape(MsmJob** jobs, size_t k) {
-    static const bool adapt = !(getenv("SWM_MSM_JOINT_ADAPT") && atoi(getenv("SWM_MSM_JOINT_ADAPT")) == 0);
-    if (!adapt || getenv("SWM_MSM_LOGM")) return;
     for (size_t i = 0; i < k; i++)  // one-lane 256-chain stages over ONE bucket set, no bucket-range share
         if (jobs[i]->rb != 256 || jobs[i]->quad || jobs[i]->pl.nwin != 1 || jobs[i]->blk_lo != 0 || jobs[i]->blk_low != 0 ||
             jobs[i]->blk_hi != jobs[i]->red_blocks)
@@ -2977,16 +2804,16 @@ static HostPool* host_pool_of(swm_ctx* ctx) {
         unsigned hw = std::thread::hardware_concurrency();
         unsigned want = hw > 1 ? std::min(hw - 1, hw >= 32 ? 15u : 7u) : 0u;
         unsigned ranks = std::max(1u, ctx->shard_world);
-        if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(ranks, (unsigned)std::max(1, atoi(e)));
+        ranks = std::max(ranks, (unsigned)env_switch("LOCAL_WORLD_SIZE", 1, 1, 4096));  // (torchrun's: ranks that share this host's cores)
         if (ranks > 1 && hw) want = std::min(want, std::max(1u, hw / ranks) - 1);
-        if (const char* e = getenv("SWM_POOL_WORKERS")) want = (unsigned)std::min(64, std::max(0, atoi(e)));
+        want = (unsigned)env_switch("SWM_POOL_WORKERS", (long)want, 0, 64);  // (diagnostic: the host fold's worker threads)
         ctx->host_pool = new HostPool(want);
     }
     return ctx->host_pool;
 }
 // how long the workers poll for the fold that follows a wait (microseconds; SWM_POOL_SPIN_US, 0 = they sleep)
 static unsigned pool_spin_us() {
-    static const unsigned us = getenv("SWM_POOL_SPIN_US") ? (unsigned)std::min(100000, std::max(0, atoi(getenv("SWM_POOL_SPIN_US")))) : 1500u;
+    static const unsigned us = (unsigned)env_switch("SWM_POOL_SPIN_US", 1500, 0, 100000);
     return us;
 }
 
@@ -2994,7 +2821,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
     *result = g1_xyzz_identity();
     ctx->msm_since_wait = 0;
     if (!job->active) return SWM_OK;
-    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    static const bool trace = env_flag("SWM_TRACE");
     auto tw0 = std::chrono::steady_clock::now();
     if (pool_spin_us()) host_pool_of(ctx)->arm(pool_spin_us());  // the fold follows the wait at once: the workers poll for it meanwhile
     SWM_TRY(msm_finish_wait(ctx, job));
@@ -3011,7 +2838,7 @@ int msm_finish(swm_ctx* ctx, MsmJob* job, G1XYZZ* result) {
 // per host worker (a fold is a serial chain of ~3 additions per workgroup result: four of them back to back were
 // ~0.25 ms between the last kernel of a round and its Fiat-Shamir challenge).
 int msm_finish_many(swm_ctx* ctx, MsmJob** jobs, int k, G1XYZZ* results) {
-    static const bool trace = getenv("SWM_TRACE") != nullptr;
+    static const bool trace = env_flag("SWM_TRACE");
     ctx->msm_since_wait = 0;
     auto tw0 = std::chrono::steady_clock::now();
     std::vector<int> live;

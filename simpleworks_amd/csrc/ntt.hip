@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) ntt_build_pass_tw(const Fr* __restrict__ 
 static int get_pass_table(swm_ctx* ctx, unsigned log_n, int inverse, unsigned log_ns, unsigned log_r, const NttTables* rt29,
                           const Fr** out) {
     *out = nullptr;
-    static const bool off = getenv("SWM_NTT_PASS_TABLES") && atoi(getenv("SWM_NTT_PASS_TABLES")) == 0;
+    static const bool off = env_switch("SWM_NTT_PASS_TABLES", 1, 0, 1) == 0;  // 0: twiddles from the two-level tables (what a transform beyond the table budget runs)
     if (off) return SWM_OK;
     const uint64_t key = (1ull << 51) | ((uint64_t)log_n << 20) | ((uint64_t)log_ns << 10) | ((uint64_t)log_r << 1) | (inverse ? 1 : 0);
     auto it = ctx->ntt_small.find(key);
@@ -488,12 +488,10 @@ int ntt_run_from(swm_ctx* ctx, void* d_data, unsigned log_n, int inverse, int co
     ctx->stat_ntt_elems += n;
     Fr* data = reinterpret_cast<Fr*>(d_data);
     // pass plan
-    unsigned maxr = NTT_MAX_LOG_R;
-    if (const char* e = getenv("SWM_NTT_MAXR")) maxr = (unsigned)atoi(e);
+    const unsigned maxr = NTT_MAX_LOG_R;
     // arithmetic: lazy 29-bit limbs (fr29.cuh, ntt_pass_lazy) unless SWM_NTT_LAZY=0 asks for the 32-bit-limb kernel of r01 / r02
-    static const bool lazy_env = !(getenv("SWM_NTT_LAZY") && atoi(getenv("SWM_NTT_LAZY")) == 0);
-    // (tiles of 2^11 / 2^12 elements — 76 / 152 KB of LDS, SWM_NTT_MAXR=11 / 12 — make 2^22 / 2^24 two passes: measured r04)
-    const bool lazy = lazy_env && maxr <= 12;
+    // (tiles of 2^11 / 2^12 elements — 76 / 152 KB of LDS — make 2^22 / 2^24 two passes: measured slower in r04, CHANGELOG.md)
+    static const bool lazy = env_switch("SWM_NTT_LAZY", 1, 0, 1) != 0;
     NttTables *rt = nullptr, *ct = nullptr;
     SWM_TRY(get_root_tables_form(ctx, log_n, inverse, lazy, &rt));
     if (coset) SWM_TRY(get_coset_tables(ctx, log_n, inverse, &ct, lazy));

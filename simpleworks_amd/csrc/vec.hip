@@ -30,54 +30,7 @@ __global__ void __launch_bounds__(256) vec_mul_kernel(const Fr* __restrict__ a, 
 // idle chip) take 4 elements per lane instead of 16: 4 + 8 products on a lane's chain instead of 16 + 32.
 static constexpr int BINV_CHUNK = 16, BINV_CHUNK_SMALL = 4;
 static constexpr int BINV_THREADS = 256;
-template <int BINV_CHUNK>
-__global__ void __launch_bounds__(BINV_THREADS) batch_inverse_kernel(Fr* __restrict__ v, size_t n) {
-    SWM_LIGHT_KERNEL();
-    __shared__ Fr sp[BINV_THREADS], ss[BINV_THREADS];
-    __shared__ Fr s_inv;
-    const unsigned tid = threadIdx.x;
-    size_t t = blockIdx.x * (size_t)blockDim.x + tid;
-    size_t lo = t * BINV_CHUNK;
-    size_t hi = lo + BINV_CHUNK < n ? lo + BINV_CHUNK : n;
-    Fr pref[BINV_CHUNK];
-    Fr acc = fp_one<Fr>();
-#pragma unroll
-    for (int i = 0; i < BINV_CHUNK; i++) {
-        pref[i] = acc;
-        if (lo + i < hi) {
-            Fr x = v[lo + i];
-            if (!fp_is_zero(x)) acc = fp_mul(acc, x);
-        }
-    }
-    sp[tid] = acc;
-    ss[tid] = acc;
-    __syncthreads();
-    for (unsigned d = 1; d < BINV_THREADS; d <<= 1) {  // inclusive prefix products in sp, inclusive suffix products in ss
-        const bool hp = tid >= d, hs = tid + d < BINV_THREADS;
-        Fr a = hp ? sp[tid - d] : acc, b = hs ? ss[tid + d] : acc;
-        Fr mp = sp[tid], ms = ss[tid];
-        __syncthreads();
-        if (hp) sp[tid] = fp_mul(mp, a);
-        if (hs) ss[tid] = fp_mul(ms, b);
-        __syncthreads();
-    }
-    if (tid == 0) s_inv = fr_inv_single(ss[0]);  // lane products are never zero (zeros are skipped), so neither is the total
-    __syncthreads();
-    Fr inv = s_inv;
-    if (tid > 0) inv = fp_mul(inv, sp[tid - 1]);
-    if (tid + 1 < BINV_THREADS) inv = fp_mul(inv, ss[tid + 1]);
-#pragma unroll
-    for (int i = BINV_CHUNK - 1; i >= 0; i--) {
-        if (lo + i < hi) {
-            Fr x = v[lo + i];
-            if (!fp_is_zero(x)) {
-                v[lo + i] = fp_mul(inv, pref[i]);
-                inv = fp_mul(inv, x);
-            }
-        }
-    }
-}
-
+// (the 8 x 32-bit Comba form of this kernel, r01 - r04, was removed in r06; what follows is the one kernel)
 // The same kernel on the transform's multiplier (r05): nine 29-bit lazy limbs, 197 instructions per product instead of ~330.
 // fr29_mul(a, b) = a b 2^-261, five bits more than the memory format's 2^-256 — and NO correction is needed: call lambda = 2^-5;
 // a product of k elements built by any tree of these multiplications carries lambda^(k-1), the exact inverse of such a product
@@ -144,19 +97,17 @@ int batch_inverse_run(swm_ctx* ctx, void* d, size_t n) {
     if (n == 0) return SWM_OK;
     // (r05: up to 2^20 elements — the inversions of proofs up to 2^18 constraints: a lane's chain is 29 instead of 65 products beside the
     // one inversion every workgroup waits for; 2^16 proofs 7.1 -> 6.9 ms, 2^14 4.15 -> 4.05, 2^18 unchanged; r04: 65 536)
-    static const size_t small_below = getenv("SWM_BINV_SMALL") ? (size_t)atol(getenv("SWM_BINV_SMALL")) : 1048576;
-    static const bool lazy = !(getenv("SWM_BINV_LAZY") && atoi(getenv("SWM_BINV_LAZY")) == 0);  // 0: the 8 x 32-bit Comba kernel (r01 - r04)
+    // (the kernel on the transform's 29-bit multiplier; the 8 x 32-bit Comba kernel of r01 - r04 is gone: r06)
+    static constexpr size_t small_below = 1048576;
     if (n <= small_below) {
         const size_t threads = (n + BINV_CHUNK_SMALL - 1) / BINV_CHUNK_SMALL;
         const dim3 grid((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS));
-        if (lazy) SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel29<BINV_CHUNK_SMALL>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
-        else SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel<BINV_CHUNK_SMALL>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
+        SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel29<BINV_CHUNK_SMALL>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
         return SWM_OK;
     }
     const size_t threads = (n + BINV_CHUNK - 1) / BINV_CHUNK;
     const dim3 grid((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS));
-    if (lazy) SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel29<BINV_CHUNK>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
-    else SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel<BINV_CHUNK>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
+    SWM_LAUNCH(ctx, "batch_inverse", batch_inverse_kernel29<BINV_CHUNK>, grid, dim3(BINV_THREADS), 0, (Fr*)d, n);
     return SWM_OK;
 }
 

@@ -13,6 +13,7 @@ use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 pub const SWM_OK: c_int = 0;
 pub const SWM_ERR_UNSATISFIED: c_int = -5;
+pub const SWM_PROOF_UNCOMPRESSED: c_uint = 1;
 
 /// struct swm_r1cs: a synthesised constraint system as flat arrays (instance[0] is the constant one).
 #[repr(C)]
@@ -70,6 +71,10 @@ extern "C" {
     // generate_proof (src/marlin/mod.rs:70-77) and verify_proof (:79-86)
     pub fn swm_generate_proof(ctx: *mut swm_ctx, pk: *const swm_pk, cs: *const swm_r1cs, rng: *mut swm_rng,
                               proof_out: *mut u8, cap: usize, len: *mut usize) -> c_int;
+    /// flags: SWM_PROOF_UNCOMPRESSED = 1 (the proof as serialize_uncompressed bytes, <= 2048 B)
+    pub fn swm_generate_proof_ex(ctx: *mut swm_ctx, pk: *const swm_pk, cs: *const swm_r1cs, rng: *mut swm_rng, flags: c_uint,
+                                 proof_out: *mut u8, cap: usize, len: *mut usize) -> c_int;
+    pub fn swm_proof_recode(bytes: *const u8, len: usize, to_uncompressed: c_int, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
     pub fn swm_verify_proof(vk: *const swm_vk, public_inputs: *const u64, n: usize, proof: *const u8, len: usize,
                             rng: *mut swm_rng, ok: *mut c_int) -> c_int;
 

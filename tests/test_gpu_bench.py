@@ -33,6 +33,7 @@ def test_bench_multi_rank_path_with_a_world_of_one():
     assert sh["proof_bytes_identical_on_all_ranks"] is True
     assert sh["ranks"] == 1 and sh["exchanges_per_proof"] >= 4   # the per-round all-gathers went through the library's communicator
     assert sh["ms_per_proof"] > 0
+    assert sh["rccl"].startswith("librccl ") and " version " in sh["rccl"], sh["rccl"]   # which library carried the exchange, and how it was found
 
 
 @pytest.mark.gpu

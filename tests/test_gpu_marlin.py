@@ -629,9 +629,13 @@ def test_sharded_prover_with_window_tables_2p17(M, S, W, world, monkeypatch):
     vk1, proof1, work1 = build(single_ctx)
     single_ctx.close()
     totals = []
-    for split in ({}, {"SWM_SHARD_RANGE": "1"}, {"SWM_SHARD_BUCKETS": "1"}):   # cyclic (default), point ranges, bucket ranges
-        for k in ("SWM_SHARD_RANGE", "SWM_SHARD_BUCKETS"):
+    # cyclic (default), point ranges, bucket ranges; then the plain cyclic split (blocks of one coefficient), and rounds 1 - 3 with
+    # every transform whole on the rank (the r03 / r04 form: SWM_SHARD_R1_OFF / _R2_OFF; a power-of-two world shards them by default)
+    for split in ({}, {"SWM_SHARD_RANGE": "1"}, {"SWM_SHARD_BUCKETS": "1"}, {"SWM_SHARD_BLOCK_LOG": "0"},
+                  {"SWM_SHARD_R1_OFF": "1", "SWM_SHARD_R2_OFF": "1"}):
+        for k in ("SWM_SHARD_RANGE", "SWM_SHARD_BUCKETS", "SWM_SHARD_R1_OFF", "SWM_SHARD_R2_OFF"):
             monkeypatch.setenv(k, split.get(k, "0"))
+        monkeypatch.setenv("SWM_SHARD_BLOCK_LOG", split.get("SWM_SHARD_BLOCK_LOG", "12"))
         ranks = _run_sharded(world, build)
         for vk_b, proof_b, _ in ranks:
             assert vk_b == vk1

@@ -38,12 +38,14 @@ def _free_port():
 
 _WORKER = r"""
 import json, os, sys, time
-root, rank, world, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+root, rank, world, idfile, torch_first = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
 sys.path[:0] = [root, os.path.join(root, "oracle"), os.path.join(root, "tests")]
+if torch_first:                             # torch maps ITS librccl: the library must then use that very copy, not a second one
+    import torch
 import numpy as np
 import simpleworks_amd as swm
 from simpleworks_amd import marlin as M, serialization as S, workloads as W
-from simpleworks_amd._lib import rccl_unique_id
+from simpleworks_amd._lib import rccl_unique_id, rccl_info
 from simpleworks_amd.dist import blocks_rows, cyclic_rows
 from oracle_lib import Oracle, golden, h2i
 from pyref.prng import fr_array
@@ -62,7 +64,8 @@ else:
         time.sleep(0.05)
     uid = open(idfile, "rb").read()
 ctx.rccl_init(uid, rank, world)             # ncclCommInitRank; sharding is on
-out = {"rank": rank, "ntt": True}
+out = {"rank": rank, "ntt": True, "rccl": rccl_info()[1],
+       "rccl_copies_mapped": len({l.split()[-1] for l in open("/proc/self/maps") if "librccl.so" in l})}
 orc = Oracle()
 log_n = 14
 n = 1 << log_n
@@ -98,15 +101,16 @@ print(json.dumps(out), flush=True)
 
 @needs_two_gpus
 @pytest.mark.gpu
+@pytest.mark.parametrize("torch_first", [0, 1])   # both resolution orders of librccl (swm_rccl_info): the loader's copy / torch's copy
 @pytest.mark.parametrize("world", sorted({2, min(NGPUS, 8)} if NGPUS >= 2 else {2}))
-def test_rccl_one_rank_per_gpu_sharded_ntt_and_golden_proof(tmp_path, world):
+def test_rccl_one_rank_per_gpu_sharded_ntt_and_golden_proof(tmp_path, world, torch_first):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     idfile = str(tmp_path / "rccl_id")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), idfile], env=env, stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), idfile, str(torch_first)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE) for r in range(world)]
     outs = []
     for p in procs:
@@ -125,6 +129,11 @@ def test_rccl_one_rank_per_gpu_sharded_ntt_and_golden_proof(tmp_path, world):
         # per-round partial sums (4) + round 1 (4) + rounds 2 and 3 (all-to-alls and all-gathers): as the thread-rank test counts them
         assert o["exchanges"] >= 4 + 4 + 6 + 3, o
     assert len({o["exchanges"] for o in outs}) == 1
+    # every rank names the library that carried its exchanges — the same one on all of them, and only ONE copy mapped per process
+    assert len({o["rccl"] for o in outs}) == 1 and outs[0]["rccl"].startswith("librccl "), [o["rccl"] for o in outs]
+    assert all(o["rccl_copies_mapped"] == 1 for o in outs), outs
+    if torch_first:
+        assert "already mapped" in outs[0]["rccl"], outs[0]["rccl"]
 
 
 @needs_two_gpus
@@ -147,6 +156,7 @@ def test_bench_through_the_launcher_one_rank_per_gpu_with_the_sharded_leg():
     assert sh and "error" not in sh, sh
     assert sh["ranks"] == 2 and sh["proof_bytes_identical_on_all_ranks"] is True and sh["proof_verifies"] is True
     assert sh["exchanges_per_proof"] >= 4
+    assert sh["rccl"].startswith("librccl ") and sh["rccl_same_on_all_ranks"] is True
 
 
 @pytest.mark.gpu

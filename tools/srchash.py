@@ -26,6 +26,8 @@ def include_closure(unit):
                 if os.path.isfile(q):
                     todo.append(q)
                     break
+    if not seen:  # the kernel's translation unit is not there (an installed tree without csrc/)
+        return None
     first = seen[0]
     return [os.path.relpath(first, ROOT)] + sorted(os.path.relpath(p, ROOT) for p in seen[1:])
 
@@ -33,10 +35,13 @@ def include_closure(unit):
 def unit_sha16(kernel):
     h = hashlib.sha256()
     try:
-        for rel in include_closure(UNITS[kernel]):
+        closure = include_closure(UNITS[kernel])
+        if closure is None:
+            return None
+        for rel in closure:
             h.update(rel.encode() + b"\0")
             h.update(open(os.path.join(ROOT, rel), "rb").read())
-    except OSError:
+    except (OSError, KeyError, IndexError):
         return None
     return h.hexdigest()[:16]
 

@@ -2,6 +2,18 @@
 size, the length-G cross transform), beside the whole transform on one GPU.  SWM_SHARD_EMULATE makes the library's device
 exchange hand back the rank's own chunk: wrong values, the right work.  Prints one JSON line per (log_n, G).
 usage: SWM_SHARD_EMULATE=1 python3 tools/ubench/ntt_sharded_one.py [log_n ...]"""
+# SWM_SHARD_EMULATE is a MEASUREMENT HOOK that makes proofs wrong by construction: it is compiled only into a second library
+# (-DSWM_MEASURE_HOOKS: `bash tools/buildvar.sh hooks -DSWM_MEASURE_HOOKS` -> build/libswmarlin_hooks.so), never into the shipped one
+def _use_hooks_library():
+    import os, subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+    lib = os.path.join(root, "build", "libswmarlin_hooks.so")
+    if os.environ.get("SWM_SHARD_EMULATE") and not os.environ.get("SWM_LIB_PATH"):
+        if not os.path.exists(lib):
+            subprocess.check_call(["bash", os.path.join(root, "tools", "buildvar.sh"), "hooks", "-DSWM_MEASURE_HOOKS"])
+        os.environ["SWM_LIB_PATH"] = os.path.abspath(lib)
+_use_hooks_library()
+
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)

@@ -4,6 +4,18 @@ of interest: everything a rank computes, with the exchange reduced to a host mem
 rank needs when the other G - 1 GPUs work beside it, i.e. the strong-scaling bound of the split (xGMI exchanges of 192 B x
 commitments per round are microseconds).  Prints one JSON line per (G, rank).
 usage: shard_emulate.py [log_n=20] [steps=5] [G ...]        env: SWM_SHARD_RANGE=1 / SWM_SHARD_BUCKETS=1 -> point-range / bucket-range split instead of the cyclic one, SWM_SHARD_R1_OFF"""
+# SWM_SHARD_EMULATE is a MEASUREMENT HOOK that makes proofs wrong by construction: it is compiled only into a second library
+# (-DSWM_MEASURE_HOOKS: `bash tools/buildvar.sh hooks -DSWM_MEASURE_HOOKS` -> build/libswmarlin_hooks.so), never into the shipped one
+def _use_hooks_library():
+    import os, subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+    lib = os.path.join(root, "build", "libswmarlin_hooks.so")
+    if os.environ.get("SWM_SHARD_EMULATE") and not os.environ.get("SWM_LIB_PATH"):
+        if not os.path.exists(lib):
+            subprocess.check_call(["bash", os.path.join(root, "tools", "buildvar.sh"), "hooks", "-DSWM_MEASURE_HOOKS"])
+        os.environ["SWM_LIB_PATH"] = os.path.abspath(lib)
+_use_hooks_library()
+
 import json, os, sys, time
 # the sharded rounds 1 and 2 exchange DATA the rest of the proof depends on (an emulated exchange makes the prover's own checks
 # fail): they are measured apart (tools/ubench/ntt_sharded_one.py); here every transform runs whole on the rank
