@@ -2551,6 +2551,12 @@ static void msm_tail_shape(MsmJob* j, bool wide) {
     j->red_blocks = std::max(1u, ((j->pl.maxB >> log_m) + j->rb - 1) / j->rb);
     j->blk_hi = j->red_blocks;  // (no bucket-range share on this path: blk_lo = 0, blk_low = 0)
 }
+// Measured in r06 and not kept (CHANGELOG.md): (i) the WIDE stage with four lanes per chain (msm_bucket_reduce<256, FormTEQuad>, 1024
+// threads per workgroup, four waves per SIMD on the same 144 KB): 554 instead of 462 us per 2^19-bucket job — the quad form's 12
+// products per addition and its lane exchanges cost more than the idle lanes of the tree steps; (ii) the second operand of every step
+// in registers, the partial sum of a lane's NEXT walk step requested from HBM while the current addition runs (the three flat-load
+// waits per "run += partial" step gone, 240 VGPRs): 524 instead of 467 us — the lone wave's cycles without an issue are not its
+// operand loads.
 int msm_launch_lazy_tail(swm_ctx* ctx, bool wide) {
     MsmJob* j = ctx->lazy_tail;
     if (!j) return SWM_OK;

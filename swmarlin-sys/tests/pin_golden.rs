@@ -24,7 +24,7 @@
 //!   proving_key_bytes                      `IndexProverKey` field order: the section (index_vk, index_comm_rands, index,
 //!                                          committer_key) of the first differing byte
 //!   larger_circuits_from_r1cs_files        synthetic 2^12 / 2^16, the Merkle circuit at height 5, examples/test-circuit.rs:
-//!                                          the circuits behind tests/golden/marlin_large.json and marlin_merkle.json, replayed
+//!                                          the circuits behind tests/golden/marlin_large.json, replayed
 //!                                          from SWMR1CS1 files (python3 tests/golden/gen_pin_circuits.py --r1cs-dir DIR;
 //!                                          SWM_PIN_R1CS_DIR=DIR) — and written back out (`dump_r1cs`) byte for byte
 //!   merkle_tree_verification_u8_dumps      (needs the simpleworks crate: see the test) the reference's REAL config-#5 circuit
@@ -67,6 +67,45 @@ fn golden(name: &str) -> Value {
     });
     let text = std::fs::read_to_string(dir.join(name)).unwrap_or_else(|e| panic!("{}: {}", name, e));
     serde_json::from_str(&text).unwrap()
+}
+// ------------------------------------------------------------------------------------------------ what arkworks produced, kept
+// One run of this kit is made PERMANENT (VERDICT r05 "next" #6): every test first RECORDS what arkworks itself produced — in the
+// schema of the golden file it is compared with (tests/golden/arkworks_schema.json names the keys) — into
+// tests/golden/arkworks/<file>.json, and only then asserts.  Committing that directory turns parity green for good: the library's
+// CPU tests (tests/test_arkworks_fixtures.py) and its GPU golden-bytes tests load it when present and compare the Python model AND
+// the HIP path against arkworks' own bytes.  A red run still leaves the fixtures behind: they then show what to fix.
+// SWM_ARKWORKS_OUT=DIR writes elsewhere; SWM_ARKWORKS_OUT=off switches the recorder off.
+fn arkworks_out_dir() -> Option<PathBuf> {
+    match std::env::var("SWM_ARKWORKS_OUT") {
+        Ok(v) if v == "off" => None,
+        Ok(v) => Some(PathBuf::from(v)),
+        Err(_) => Some(PathBuf::from(env!("CARGO_MANIFEST_DIR")).join("..").join("tests").join("golden").join("arkworks")),
+    }
+}
+static RECORD_LOCK: std::sync::Mutex<()> = std::sync::Mutex::new(());
+/// file[path[0]][path[1]]... = value (objects created on the way), read-modify-write under a process-wide lock: the tests of
+/// this file run on several threads and two of them write rng.json.
+fn record(file: &str, path: &[&str], value: Value) {
+    let dir = match arkworks_out_dir() {
+        Some(d) => d,
+        None => return,
+    };
+    let _g = RECORD_LOCK.lock().unwrap_or_else(|p| p.into_inner());
+    std::fs::create_dir_all(&dir).unwrap();
+    let at = dir.join(file);
+    let mut root: Value = std::fs::read_to_string(&at).ok().and_then(|t| serde_json::from_str(&t).ok()).unwrap_or_else(|| serde_json::json!({}));
+    {
+        let mut cur = &mut root;
+        for k in &path[..path.len() - 1] {
+            if !cur.get(*k).map(|v| v.is_object()).unwrap_or(false) {
+                cur[*k] = serde_json::json!({});
+            }
+            cur = cur.get_mut(*k).unwrap();
+        }
+        cur[path[path.len() - 1]] = value;
+    }
+    root["_generator"] = serde_json::json!("swmarlin-sys/tests/pin_golden.rs: arkworks 0.3 (ark-marlin fork use-constraint-system-directly), ark_std::test_rng()");
+    std::fs::write(&at, serde_json::to_string_pretty(&root).unwrap()).unwrap();
 }
 fn be_bytes(hex_str: &str) -> Vec<u8> {
     let h = hex_str.trim_start_matches("0x");
@@ -180,8 +219,11 @@ fn marlin_proof_and_verifying_key_bytes() {
         let mut rng = ark_std::test_rng();
         let srs = ArkMarlinInst::universal_setup(s[0], s[1], s[2], &mut rng).unwrap();
         let (pk, vk) = ArkMarlinInst::index(&srs, circuit.clone()).unwrap();
-        assert_eq!(hex::encode(ser(&vk)), case["vk"].as_str().unwrap(), "{}: verifying key bytes", name);
         let proof = ArkMarlinInst::prove(&pk, circuit.clone(), &mut rng).unwrap();
+        record("marlin.json", &[name, "srs"], case["srs"].clone());
+        record("marlin.json", &[name, "vk"], serde_json::json!(hex::encode(ser(&vk))));
+        record("marlin.json", &[name, "proof"], serde_json::json!(hex::encode(ser(&proof))));
+        assert_eq!(hex::encode(ser(&vk)), case["vk"].as_str().unwrap(), "{}: verifying key bytes", name);
         compare_proofs(name, &proof, &hex::decode(case["proof"].as_str().unwrap()).unwrap());
         assert!(ArkMarlinInst::verify(&vk, &circuit.instance, &proof, &mut rng).unwrap(), "{}: arkworks rejects its own proof", name);
         println!("pinned {}: proof {} B, vk {} B", name, ser(&proof).len(), ser(&vk).len());
@@ -207,6 +249,13 @@ fn proving_key_bytes() {
         let srs = ArkMarlinInst::universal_setup(s[0], s[1], s[2], &mut rng).unwrap();
         let (pk, _vk) = ArkMarlinInst::index(&srs, circuit).unwrap();
         let b = ser(&pk);
+        record("pk_bytes.json", &[name, "srs"], case["srs"].clone());
+        record("pk_bytes.json", &[name, "len"], serde_json::json!(b.len()));
+        record("pk_bytes.json", &[name, "head"], serde_json::json!(hex::encode(&b[..64])));
+        record("pk_bytes.json", &[name, "sha256"], serde_json::json!(hex::encode(Sha256::digest(&b))));
+        if case.get("bytes").is_some() {
+            record("pk_bytes.json", &[name, "bytes"], serde_json::json!(hex::encode(&b)));
+        }
         assert_eq!(b.len() as u64, case["len"].as_u64().unwrap(), "{}: proving key length", name);
         assert_eq!(hex::encode(&b[..64]), case["head"].as_str().unwrap(), "{}: proving key, first 64 bytes", name);
         if let Some(full) = case.get("bytes").and_then(|v| v.as_str()) {
@@ -230,6 +279,17 @@ fn proving_key_bytes() {
 #[test]
 fn test_rng_stream_and_field_draws() {
     let g = golden("rng.json");
+    {   // recorded first, from generators of their own (same seed): the schema of rng.json
+        let mut r = ark_std::test_rng();
+        let n = g["test_rng_u64"].as_array().unwrap().len();
+        record("rng.json", &["test_rng_u64"], serde_json::json!((0..n).map(|_| format!("{:#x}", r.next_u64())).collect::<Vec<_>>()));
+        let mut r = ark_std::test_rng();
+        let k = g["test_rng_fr"].as_array().unwrap().len();
+        record("rng.json", &["test_rng_fr"], serde_json::json!((0..k).map(|_| hex_int(&Fr::rand(&mut r))).collect::<Vec<_>>()));
+        record("rng.json", &["test_rng_then_fq"], serde_json::json!(hex_int(&Fq::rand(&mut r))));
+        record("rng.json", &["test_rng_then_bool"], serde_json::json!(bool::rand(&mut r)));
+        record("rng.json", &["test_rng_then_u128"], serde_json::json!(format!("{:#x}", u128::rand(&mut r))));
+    }
     let mut r = ark_std::test_rng();
     for (i, w) in g["test_rng_u64"].as_array().unwrap().iter().enumerate() {
         let want = u64::from_str_radix(w.as_str().unwrap().trim_start_matches("0x"), 16).unwrap();
@@ -284,6 +344,8 @@ fn pedersen_parameters_hashes_and_the_eight_leaf_tree() {
     let mut rng = ark_std::test_rng();
     let leaf_params = <LeafHash as CRH>::setup(&mut rng).unwrap();
     let two_params = <TwoToOneHash as TwoToOneCRH>::setup(&mut rng).unwrap();
+    record("pedersen.json", &["leaf_generators_sha256"], serde_json::json!(generators_sha256(&leaf_params.generators)));
+    record("pedersen.json", &["two_to_one_generators_sha256"], serde_json::json!(generators_sha256(&two_params.generators)));
     assert_eq!(generators_sha256(&leaf_params.generators), g["leaf_generators_sha256"].as_str().unwrap(), "LeafHash generators");
     assert_eq!(generators_sha256(&two_params.generators), g["two_to_one_generators_sha256"].as_str().unwrap(), "TwoToOneHash generators");
     let pt = |p: &EdwardsProjective| {
@@ -291,6 +353,21 @@ fn pedersen_parameters_hashes_and_the_eight_leaf_tree() {
         vec![hex_int(&a.x), hex_int(&a.y)]
     };
     let want = |k: &str| g[k].as_array().unwrap().iter().map(|v| v.as_str().unwrap().to_string()).collect::<Vec<_>>();
+    record("pedersen.json", &["leaf_generator_0_0"], serde_json::json!(pt(&leaf_params.generators[0][0])));
+    record("pedersen.json", &["leaf_generator_143_3"], serde_json::json!(pt(&leaf_params.generators[143][3])));
+    record("pedersen.json", &["two_to_one_generator_0_0"], serde_json::json!(pt(&two_params.generators[0][0])));
+    record("pedersen.json", &["two_to_one_generator_127_3"], serde_json::json!(pt(&two_params.generators[127][3])));
+    {
+        let digests = |key: &str, two: bool| {
+            g[key].as_array().unwrap().iter().map(|case| {
+                let input = hex::decode(case["input"].as_str().unwrap()).unwrap();
+                let d = if two { <TwoToOneHash as CRH>::evaluate(&two_params, &input).unwrap() } else { <LeafHash as CRH>::evaluate(&leaf_params, &input).unwrap() };
+                serde_json::json!({"input": case["input"].clone(), "digest": hex_int(&d)})
+            }).collect::<Vec<_>>()
+        };
+        record("pedersen.json", &["pedersen_hash"], serde_json::json!(digests("pedersen_hash", false)));
+        record("pedersen.json", &["two_to_one_hash"], serde_json::json!(digests("two_to_one_hash", true)));
+    }
     assert_eq!(pt(&leaf_params.generators[0][0]), want("leaf_generator_0_0"));
     assert_eq!(pt(&leaf_params.generators[143][3]), want("leaf_generator_143_3"));
     assert_eq!(pt(&two_params.generators[0][0]), want("two_to_one_generator_0_0"));
@@ -309,6 +386,9 @@ fn pedersen_parameters_hashes_and_the_eight_leaf_tree() {
     // examples/merkle-tree/main.rs:111-121: the tree over [1, 2, 3, 10, 9, 17, 70, 45], the path of leaf 4
     let leaves: Vec<[u8; 1]> = g["tree"]["leaves"].as_array().unwrap().iter().map(|v| [v.as_u64().unwrap() as u8]).collect();
     let tree = MerkleTree::<MerkleConfig>::new(&leaf_params, &two_params, &leaves).unwrap();
+    record("pedersen.json", &["tree", "leaves"], g["tree"]["leaves"].clone());
+    record("pedersen.json", &["tree", "index"], g["tree"]["index"].clone());
+    record("pedersen.json", &["tree", "root"], serde_json::json!(hex_int(&tree.root())));
     assert_eq!(hex_int(&tree.root()), g["tree"]["root"].as_str().unwrap(), "root of the eight-leaf tree");
     let path = tree.generate_proof(g["tree"]["index"].as_u64().unwrap() as usize).unwrap();
     assert!(path.verify(&leaf_params, &two_params, &tree.root(), &leaves[4]).unwrap());
@@ -321,11 +401,17 @@ fn fiat_shamir_rng_absorb_and_draws() {
     let mut seed = b"MARLIN-2019".to_vec();
     seed.extend(0u8..40);
     let mut fs = FS::initialize(&seed);
-    assert_eq!(hex_int(&Fr::rand(&mut fs)), g["fs_init_fr"].as_str().unwrap(), "first draw after FS::initialize (Blake2s seed -> ChaCha20)");
+    let a = hex_int(&Fr::rand(&mut fs));
     let more: Vec<u8> = (0u8..7).collect();
     fs.absorb(&more);
-    assert_eq!(hex_int(&Fr::rand(&mut fs)), g["fs_absorb_fr"].as_str().unwrap(), "first draw after FS::absorb (new bytes || old seed)");
-    assert_eq!(format!("{:#x}", u128::rand(&mut fs)), g["fs_then_u128"].as_str().unwrap(), "u128::rand from the FS generator");
+    let b = hex_int(&Fr::rand(&mut fs));
+    let c = format!("{:#x}", u128::rand(&mut fs));
+    record("rng.json", &["fs_init_fr"], serde_json::json!(a));
+    record("rng.json", &["fs_absorb_fr"], serde_json::json!(b));
+    record("rng.json", &["fs_then_u128"], serde_json::json!(c));
+    assert_eq!(a, g["fs_init_fr"].as_str().unwrap(), "first draw after FS::initialize (Blake2s seed -> ChaCha20)");
+    assert_eq!(b, g["fs_absorb_fr"].as_str().unwrap(), "first draw after FS::absorb (new bytes || old seed)");
+    assert_eq!(c, g["fs_then_u128"].as_str().unwrap(), "u128::rand from the FS generator");
 }
 
 /// `to_bytes!` layouts that enter the transcript (tests/golden/tobytes.json, tests/golden/gen_pin_circuits.py tobytes)
@@ -337,6 +423,11 @@ fn to_bytes_layouts() {
         x(&mut b);
         hex::encode(b)
     };
+    let gen0 = ark_bls12_377::G1Affine::prime_subgroup_generator();
+    record("tobytes.json", &["fr_5"], serde_json::json!(tb(&|b| Fr::from(5u64).write(b).unwrap())));
+    record("tobytes.json", &["fr_minus_1"], serde_json::json!(tb(&|b| (-Fr::from(1u64)).write(b).unwrap())));
+    record("tobytes.json", &["g1_generator"], serde_json::json!(tb(&|b| gen0.write(b).unwrap())));
+    record("tobytes.json", &["g1_zero"], serde_json::json!(tb(&|b| ark_bls12_377::G1Affine::default().write(b).unwrap())));
     assert_eq!(tb(&|b| Fr::from(5u64).write(b).unwrap()), g["fr_5"].as_str().unwrap(), "to_bytes!(Fr): 32 bytes, standard form, little-endian");
     assert_eq!(tb(&|b| (-Fr::from(1u64)).write(b).unwrap()), g["fr_minus_1"].as_str().unwrap(), "to_bytes!(-1)");
     let gen = ark_bls12_377::G1Affine::prime_subgroup_generator();
@@ -345,11 +436,13 @@ fn to_bytes_layouts() {
     // the index verifying key of the manual-constraints case, and the transcript seed built from it
     let case = &golden("marlin.json")["manual_constraints"];
     let vk = IndexVerifierKey::<Fr, MultiPC>::deserialize(&hex::decode(case["vk"].as_str().unwrap()).unwrap()[..]).unwrap();
+    record("tobytes.json", &["index_vk_manual_constraints"], serde_json::json!(tb(&|b| vk.write(b).unwrap())));
     assert_eq!(tb(&|b| vk.write(b).unwrap()), g["index_vk_manual_constraints"].as_str().unwrap(),
         "to_bytes!(IndexVerifierKey): index_info (3 x u64) || index_comms as to_bytes!(Commitment) = comm || bool || shifted");
     let publics: Vec<Fr> = case["public_input"].as_array().unwrap().iter().map(fr_of).collect();
     let protocol_name: &'static [u8] = b"MARLIN-2019";
     let seed = ark_ff::to_bytes![&protocol_name, &vk, &publics].unwrap(); // as ark-marlin's prover and verifier seed the transcript
+    record("tobytes.json", &["fs_seed_manual_constraints"], serde_json::json!(hex::encode(&seed)));
     assert_eq!(hex::encode(seed), g["fs_seed_manual_constraints"].as_str().unwrap(), "to_bytes![PROTOCOL_NAME, index_vk, public_input]");
 }
 
@@ -370,9 +463,8 @@ fn larger_circuits_from_r1cs_files() {
         }
     };
     let large = golden("marlin_large.json");
-    let merkle = golden("marlin_merkle.json");
     let cases: [(&str, &Value); 4] = [("synthetic_2p12", &large["synthetic_2p12"]), ("synthetic_2p16", &large["synthetic_2p16"]),
-                                      ("merkle_h5", &large["merkle_h5"]), ("test_circuit", &merkle["test_circuit"])];
+                                      ("merkle_h5", &large["merkle_h5"]), ("test_circuit", &large["test_circuit"])];
     for (name, case) in cases.iter() {
         let path = dir.join(format!("{}.r1cs", name));
         let bytes = std::fs::read(&path).unwrap_or_else(|e| panic!("{}: {}", path.display(), e));
@@ -388,8 +480,13 @@ fn larger_circuits_from_r1cs_files() {
         let mut rng = ark_std::test_rng();
         let srs = ArkMarlinInst::universal_setup(s[0], s[1], s[2], &mut rng).unwrap();
         let (pk, vk) = ArkMarlinInst::index(&srs, file.clone()).unwrap();
-        assert_eq!(hex::encode(ser(&vk)), case["vk"].as_str().unwrap(), "{}: verifying key bytes", name);
         let proof = ArkMarlinInst::prove(&pk, file.clone(), &mut rng).unwrap();
+        let out_file = "marlin_large.json";
+        record(out_file, &[name, "srs"], case["srs"].clone());
+        record(out_file, &[name, "num_constraints"], case["num_constraints"].clone());
+        record(out_file, &[name, "vk"], serde_json::json!(hex::encode(ser(&vk))));
+        record(out_file, &[name, "proof"], serde_json::json!(hex::encode(ser(&proof))));
+        assert_eq!(hex::encode(ser(&vk)), case["vk"].as_str().unwrap(), "{}: verifying key bytes", name);
         compare_proofs(name, &proof, &hex::decode(case["proof"].as_str().unwrap()).unwrap());
         assert!(ArkMarlinInst::verify(&vk, &file.public_inputs(), &proof, &mut rng).unwrap(), "{}: arkworks rejects its own proof", name);
         println!("pinned {} from {}", name, path.display());

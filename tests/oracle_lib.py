@@ -88,6 +88,87 @@ def golden(name):
         return json.load(f)
 
 
+# ---- what arkworks ITSELF produced (tests/golden/arkworks/, written by swmarlin-sys/tests/pin_golden.rs when someone with a Rust
+# toolchain runs it: `cargo test --features pin --test pin_golden`).  Absent in this repository until then: the oracle is unpinned.
+ARKWORKS_DIR = os.environ.get("SWM_ARKWORKS_GOLDEN") or os.path.join(GOLDEN, "arkworks")
+
+
+def arkworks_schema():
+    with open(os.path.join(GOLDEN, "arkworks_schema.json")) as f:
+        return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+
+
+def arkworks_golden(name, directory=None):
+    """The arkworks-generated twin of tests/golden/<name>, or None when nobody has run the pin kit yet."""
+    path = os.path.join(directory or ARKWORKS_DIR, name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+
+
+def _dotted(d, key):
+    for part in key.split("."):
+        d = d[part]
+    return d
+
+
+def arkworks_project(name, model):
+    """The part of the model's golden file `name` that the pin kit records: the arkworks schema applied to our own data (what a
+    fixture file produced by arkworks has to equal, key for key)."""
+    spec = arkworks_schema()[name]
+    if "per_case" in spec:
+        keys = spec["per_case"]["required"] + spec["per_case"].get("optional", [])
+        return {case: {k: v[k] for k in keys if k in v} for case, v in model.items() if isinstance(v, dict) and
+                all(k in v for k in spec["per_case"]["required"])}
+    out = {}
+    for key in spec["keys"]:
+        cur = out
+        parts = key.split(".")
+        for p in parts[:-1]:
+            cur = cur.setdefault(p, {})
+        cur[parts[-1]] = _dotted(model, key)
+    return out
+
+
+def arkworks_diff(name, model, theirs):
+    """Differences between the model's golden file and an arkworks fixture of the same name, as 'file: case.key' strings; a
+    fixture may hold a subset of the cases, but what it holds must carry every required key and agree."""
+    spec = arkworks_schema()[name]
+    diffs = []
+    if "per_case" in spec:
+        for case, rec in theirs.items():
+            if case not in model:
+                diffs.append("%s: case %s is not in the model's file" % (name, case))
+                continue
+            for k in spec["per_case"]["required"]:
+                if k not in rec:
+                    diffs.append("%s: %s.%s missing from the arkworks fixture" % (name, case, k))
+            for k, v in rec.items():
+                if k in model[case] and model[case][k] != v:
+                    diffs.append("%s: %s.%s differs (arkworks %s..., model %s...)" % (name, case, k, str(v)[:24], str(model[case][k])[:24]))
+    else:
+        for key in spec["keys"]:
+            try:
+                v = _dotted(theirs, key)
+            except (KeyError, TypeError):
+                continue
+            if _dotted(model, key) != v:
+                diffs.append("%s: %s differs (arkworks %s..., model %s...)" % (name, key, str(v)[:24], str(_dotted(model, key))[:24]))
+    return diffs
+
+
+def expected_bytes(name, case, key):
+    """[(source, hex)]: what a GPU golden-bytes test compares the HIP path with — the model's value, and arkworks' own when the
+    pin kit's fixtures are present."""
+    out = [("model", golden(name)[case][key])]
+    ark = arkworks_golden(name)
+    if ark is not None and case in ark and key in ark[case]:
+        out.append(("arkworks", ark[case][key]))
+    return out
+
+
+
 def h2i(s):
     return int(s, 16)
 
