@@ -112,15 +112,23 @@ unsigned msm_table_width(size_t n_bases) {
 // ---------------------------------------------------------------------------------------------- digits
 // Signed-digit recoding of a 253-bit standard-form scalar; calls f(window, bucket_index, negative) for every
 // non-zero digit.  Digit d in [-2^(c-1), 2^(c-1)]; bucket index |d| - 1.
+// (r06: the scalar is consumed as a shift register — the window's bits are the low bits of word 0, then the eight words move down by
+// the window's width with funnel shifts — instead of being indexed by the window's bit position: the dynamic index made the compiler
+// keep the scalar in LDS (promoted alloca), and msm_digits spent 76 % of its wave-cycles waiting, 81 % of its LDS cycles in bank
+// conflicts.  The windows are consecutive from bit 0 (msm_plan, msm_table_layout), 2 <= c <= 22.)
 template <class Fn>
 __device__ __forceinline__ void for_each_digit(const Fr& s, const WinLayout& L, Fn f) {
     uint32_t carry = 0;
+    uint32_t r[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = s.v[i];
     for (unsigned w = 0; w < L.nwin; w++) {
-        const unsigned c = L.c[w], bit = L.bit[w];
+        const unsigned c = L.c[w];
         const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-        unsigned limb = bit >> 5, off = bit & 31;
-        uint32_t v = limb < 8 ? (s.v[limb] >> off) : 0;
-        if (off + c > 32 && limb + 1 < 8) v |= s.v[limb + 1] << (32 - off);
+        const uint32_t v = r[0];
+#pragma unroll
+        for (int i = 0; i < 7; i++) r[i] = __funnelshift_r(r[i], r[i + 1], c);
+        r[7] >>= c;
         uint32_t d = (v & mask) + carry;
         uint32_t code = 0;  // 0 = zero digit, else ((bucket << 1) | negative) + 1
         if (d > half) {
@@ -152,6 +160,8 @@ __global__ void __launch_bounds__(256) msm_digits(const Fr* __restrict__ scalars
     // scalar i sits at scalars[(i >> sblk_log) * sbstride + (i & (2^sblk_log - 1))]: contiguous by default (sblk_log = 31), the
     // blocks a rank of a sharded proof takes of a polynomial every rank holds otherwise (MsmTable::scalar_stride, blk_log, bstride)
     const size_t smask = ((size_t)1 << sblk_log) - 1;
+    // (r06: two scalars per lane and trip, both loads issued before the first is recoded — 64.5 instead of 60.3 us per 2^20 points on
+    // the box that measured it: not kept)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr s = scalars[(i >> sblk_log) * sbstride + (i & smask)];
         bool ge = true;  // s >= r ?
@@ -994,45 +1004,47 @@ __global__ void __launch_bounds__(ORD_THREADS) msm_seg_desc(const uint32_t* __re
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD_THREADS)
         if (lh[i]) atomicAdd(&len_hist[i * LEN_STRIDE], lh[i]);
 }
-__global__ void __launch_bounds__(64) msm_seg_len_scan(uint32_t* len_hist /* SEG+1 counts -> exclusive offsets */, uint32_t SEG,
-                                                       uint32_t* __restrict__ nseg_live) {
-    SWM_LIGHT_KERNEL();
-    // one wave, three consecutive counters per lane (SEG <= SEG_MAX = 128: 129 counters at most), shuffle scan across the lanes
-    static_assert(SEG_MAX + 1 <= 3 * 64, "three counters per lane");
-    if (blockIdx.x) return;
-    const uint32_t l = threadIdx.x;
-    uint32_t c[3], sum = 0;
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-        const uint32_t i = 3 * l + u;
-        c[u] = i <= SEG ? len_hist[i * LEN_STRIDE] : 0u;
-        sum += c[u];
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t x = __shfl_up(inc, d, 64);
-        if (l >= (uint32_t)d) inc += x;
-    }
-    uint32_t run = inc - sum;
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-        const uint32_t i = 3 * l + u;
-        if (i <= SEG) len_hist[i * LEN_STRIDE] = run;
-        if (i == SEG) *nseg_live = run;  // class SEG holds the empty segments: everything ordered before it has entries
-        run += c[u];
-    }
-}
 // (4096 segments per workgroup — r04; 256 before: every workgroup reserves a run per length class with a returning global atomic,
 // and ~230 k of those on 129 addresses were the kernel's 24 us at 2^20 points)
 static constexpr int ORD2_THREADS = 1024, ORD2_U = 4;
+// r06: the exclusive scan of the SEG + 1 length counts — until r05 a single-wave kernel of its own between the sort and the
+// accumulation of every MSM (5 us + a launch gap on the path of every job whose accumulation waits for its sort) — is done by
+// every workgroup here for itself: three counters per lane of its first wave, a shuffle scan, the offsets in LDS.  The counts stay
+// as the sort wrote them; the runs a workgroup reserves come from a second, zeroed array of cursors.  Workgroup 0 writes
+// *nseg_live (the segments that hold entries: the lanes of work of the accumulation).
 __global__ void __launch_bounds__(ORD2_THREADS) msm_seg_order(const uint32_t* __restrict__ seg_len,
                                                               const uint32_t* __restrict__ nseg_ptr, uint32_t SEG,
-                                                              uint32_t* __restrict__ len_cursor /* offsets, advanced */,
-                                                              uint32_t* __restrict__ order) {
+                                                              const uint32_t* __restrict__ len_hist /* SEG + 1 counts */,
+                                                              uint32_t* __restrict__ len_cursor /* zeroed, advanced */,
+                                                              uint32_t* __restrict__ nseg_live, uint32_t* __restrict__ order) {
     SWM_LIGHT_KERNEL();
-    __shared__ uint32_t lh[SEG_MAX + 1];
+    __shared__ uint32_t lh[SEG_MAX + 1], loff[SEG_MAX + 1];
+    static_assert(SEG_MAX + 1 <= 3 * 64, "three counters per lane");
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD2_THREADS) lh[i] = 0;
+    if (threadIdx.x < 64) {
+        const uint32_t l = threadIdx.x;
+        uint32_t c[3], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const uint32_t i = 3 * l + u;
+            c[u] = i <= SEG ? len_hist[i * LEN_STRIDE] : 0u;
+            sum += c[u];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t x = __shfl_up(inc, d, 64);
+            if (l >= (uint32_t)d) inc += x;
+        }
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const uint32_t i = 3 * l + u;
+            if (i <= SEG) loff[i] = run;
+            if (i == SEG && blockIdx.x == 0) *nseg_live = run;  // class SEG holds the empty segments: everything before it has entries
+            run += c[u];
+        }
+    }
     __syncthreads();
     // *nseg_ptr bounds the segment INDICES in use; the flat schedule leaves indices without entries between the bins
     // (msm_flat_bin_sort): those are not handed to a lane
@@ -1050,7 +1062,7 @@ __global__ void __launch_bounds__(ORD2_THREADS) msm_seg_order(const uint32_t* __
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= SEG; i += ORD2_THREADS) {
         uint32_t v = lh[i];
-        if (v) lh[i] = atomicAdd(&len_cursor[i * LEN_STRIDE], v);  // reserve a run; lh[i] = its start
+        if (v) lh[i] = loff[i] + atomicAdd(&len_cursor[i * LEN_STRIDE], v);  // reserve a run; lh[i] = its start
     }
     __syncthreads();
 #pragma unroll
@@ -1353,7 +1365,25 @@ __device__ __forceinline__ void p28_slot_add(G1XYZZ* dst, const G1XYZZ* pa, cons
 // The two point forms of the bucket stage: XYZZ on the Weierstrass curve (per-window schedule, XYZZ tables) and extended
 // twisted Edwards (TE tables).  Each kernel below is instantiated once per form; a launch handles jobs of one form.
 // LANES: hardware lanes that share one chain of the bucket stage (msm_bucket_reduce); `q` = the lane's index among them.
+// One LDS slot of the bucket stage: a packed point PLUS 16 bytes (r06).  At 192 bytes the slots of consecutive lanes lie 48 dwords
+// = 16 banks apart, so the 128-bit reads and writes of a wave fall on 8 of the 32 banks: 87 % of the kernel's LDS cycles were bank
+// conflicts (SQ_LDS_BANK_CONFLICT 51.1 M of SQ_LDS_IDX_ACTIVE 58.7 M per launch) and the four lone waves of a workgroup queued up
+// behind one another's operand loads — the "26 % of wave-cycles parked" of profiles/r05_pmc_sq_msm_bucket_reduce_and_sort.json.
+// At 208 bytes (52 dwords: 20 banks) the 128-bit accesses of 8 consecutive lanes cover all 32 banks.  (3 x 256 + 1) x 208 B =
+// 159 952 B: just inside the 160 KB of a CU.
+struct alignas(16) RedSlot {
+    G1XYZZ p;
+    uint32_t pad[4];
+};
+static_assert(sizeof(RedSlot) == 208, "slot stride");
+// ... and the slot of the QUAD forms, where a lane reads ONE coordinate (48 bytes) of its chain's slot: there the plain 192 bytes
+// are the conflict-free stride (the sixteen 128-bit accesses of four chains fall on every 4-bank group exactly twice; 208 bytes
+// puts four of them on one group)
+struct alignas(16) PlainSlot {
+    G1XYZZ p;
+};
 struct FormXYZZ {
+    using Slot = RedSlot;
     static constexpr int LANES = 1;
     static constexpr bool QUAD_TREE = false;
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { p28_slot_add(dst, pa, pq); }
@@ -1363,6 +1393,7 @@ struct FormXYZZ {
     static __device__ __forceinline__ void store_384(G1XYZZ& m, const G1XYZZ& slot) { p28_store_384(m, p28_load(slot)); }
 };
 struct FormTE {
+    using Slot = RedSlot;
     static constexpr int LANES = 1;
     static constexpr bool QUAD_TREE = true;  // the narrow steps of the final tree switch to four lanes per sum
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned = 0) { te28_slot_add(dst, pa, pq); }
@@ -1374,6 +1405,7 @@ struct FormTE {
 // Twisted Edwards with every chain worked by a quad of lanes (te28_quad_add: three products per lane and step instead of
 // nine): the bucket stage of SMALL MSMs, where the chain's latency is all there is.
 struct FormTEQuad {
+    using Slot = PlainSlot;
     static constexpr int LANES = 4;
     static constexpr bool QUAD_TREE = false;
     static __device__ __forceinline__ void slot_add(G1XYZZ* dst, const G1XYZZ* pa, const G1XYZZ* pq, unsigned q) { te28_quad_add(dst, pa, pq, q); }
@@ -1459,6 +1491,7 @@ struct TailBatch {
 template <int RB, class Form>
 __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch batch) {
     SWM_TAIL_KERNEL();
+    using Slot = typename Form::Slot;
     const TailJob& job = batch.j[blockIdx.z];
     if (blockIdx.x >= job.red_blocks || blockIdx.y >= job.L.nwin) return;
     const G1XYZZ* __restrict__ partial = job.partial;
@@ -1470,20 +1503,20 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
     // LDS: three packed slots per lane — the running sum in two copies (the scan and the shift read a NEIGHBOUR's slot
     // while every lane rewrites its own, so those steps go from one copy to the other) and the weighted sum — plus one
     // slot for R_blk: (3 x 256 + 1) x 192 B = 144 KB per workgroup.
-    G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);
-    G1XYZZ* sm_alt = sm_run + RB;
-    G1XYZZ* sm_acc = sm_alt + RB;
-    G1XYZZ* sm_r = sm_acc + RB;
+    Slot* sm_run = reinterpret_cast<Slot*>(smem_raw);
+    Slot* sm_alt = sm_run + RB;
+    Slot* sm_acc = sm_alt + RB;
+    Slot* sm_r = sm_acc + RB;
     constexpr unsigned Q = Form::LANES;
     const uint32_t w = blockIdx.y, t = threadIdx.x / Q, q = threadIdx.x % Q;
     if (!((blockIdx.x >= job.blk_lo && blockIdx.x < job.blk_hi) || blockIdx.x < job.blk_low)) {
         // not a workgroup of this rank's bucket share: its buckets are empty here, the host fold sees the identity
-        if (threadIdx.x < Q) Form::store_identity(sm_run[0], q);
+        if (threadIdx.x < Q) Form::store_identity(sm_run[0].p, q);
         __syncthreads();
         if (threadIdx.x == 0) {
             size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
-            Form::store_384(out[o], sm_run[0]);
-            Form::store_384(out[o + 1], sm_run[0]);
+            Form::store_384(out[o], sm_run[0].p);
+            Form::store_384(out[o + 1], sm_run[0].p);
             if (blockIdx.x == 0 && w == 0 && job.host_flags) {
                 job.host_flags[0] = job.status[0];
                 job.host_flags[1] = *job.entries;
@@ -1495,8 +1528,8 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
-    Form::store_identity(sm_run[t], q);
-    Form::store_identity(sm_acc[t], q);
+    Form::store_identity(sm_run[t].p, q);
+    Form::store_identity(sm_acc[t].p, q);
     // phase-1 sequencer of this lane: buckets b = hi-1 .. lo; per bucket "run += partial[s]" for its segments, then
     // "acc += run"
     uint32_t b = min(lo + m, B), s = 0, e = 0;
@@ -1514,12 +1547,16 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
 #pragma unroll 1
     for (;;) {
         // one micro-operation per iteration: *dst = *pa + *pq (act), or *dst = *pa (copy: inactive lane of a scan step)
-        G1XYZZ* dst = &sm_run[t];
-        const G1XYZZ* pa = &sm_run[t];
-        const G1XYZZ* pq = &sm_run[t];
+        G1XYZZ* dst = &sm_run[t].p;
+        const G1XYZZ* pa = &sm_run[t].p;
+        const G1XYZZ* pq = &sm_run[t].p;
         bool act = false, copy = false;
         if (phase == WALK) {
-            if (!__syncthreads_or(walking)) {
+            // (r06) the walk has no meeting point but its end: a lane works on slots of its own, so every WAVE walks at its own
+            // pace — its LDS traffic no longer in step with the other three waves' — and meets the workgroup once, when none of
+            // its lanes has a bucket left (until r05: a workgroup-wide vote, three barriers, in front of every step)
+            if (__ballot(walking) == 0) {
+                __syncthreads();
                 phase = SCAN;
                 continue;
             }
@@ -1528,8 +1565,8 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
                 if (s < e) {
                     pq = &partial[s++];
                 } else {
-                    dst = &sm_acc[t];
-                    pa = &sm_acc[t];
+                    dst = &sm_acc[t].p;
+                    pa = &sm_acc[t].p;
                     if (b == lo) {
                         walking = false;
                     } else {
@@ -1545,26 +1582,26 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
                 phase = SHIFT;
                 continue;
             }
-            dst = &sm_alt[t];
+            dst = &sm_alt[t].p;
             act = t + d < RB;
             copy = !act;
-            if (act) pq = &sm_run[t + d];
+            if (act) pq = &sm_run[t + d].p;
             d <<= 1;
         } else if (phase == SHIFT) {  // run_t <- m Suffix_{t+1} (into the other copy); R_blk = Suffix_0 is parked
-            if (t + 1 < RB) Form::copy(&sm_alt[t], &sm_run[t + 1], q);
-            else Form::store_identity(sm_alt[t], q);
-            if (t == 0) Form::copy(&sm_r[0], &sm_run[0], q);
+            if (t + 1 < RB) Form::copy(&sm_alt[t].p, &sm_run[t + 1].p, q);
+            else Form::store_identity(sm_alt[t].p, q);
+            if (t == 0) Form::copy(&sm_r[0].p, &sm_run[0].p, q);
 #pragma unroll 1
-            for (unsigned i = 0; i < log_m; i++) Form::slot_dbl(&sm_alt[t], &sm_alt[t], q);
+            for (unsigned i = 0; i < log_m; i++) Form::slot_dbl(&sm_alt[t].p, &sm_alt[t].p, q);
             __syncthreads();
-            G1XYZZ* x = sm_run;
+            Slot* x = sm_run;
             sm_run = sm_alt;
             sm_alt = x;
             phase = FOLD;
             continue;
         } else if (phase == FOLD) {  // acc_t += m Suffix_{t+1}; summed over t this is A_blk
-            dst = &sm_acc[t];
-            pa = &sm_acc[t];
+            dst = &sm_acc[t].p;
+            pa = &sm_acc[t].p;
             act = true;
             phase = TREE;
             d = RB / 2;
@@ -1574,23 +1611,23 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
                 // a tree step with at most RB / 4 sums left: four lanes per sum (te28_quad_add), a third of the step's latency
                 if (d <= RB / 4) {
                     const uint32_t c = threadIdx.x >> 2;
-                    if (c < d) te28_quad_add(&sm_acc[c], &sm_acc[c], &sm_acc[c + d], threadIdx.x & 3u);
+                    if (c < d) te28_quad_add(&sm_acc[c].p, &sm_acc[c].p, &sm_acc[c + d].p, threadIdx.x & 3u);
                     __syncthreads();
                     d >>= 1;
                     continue;
                 }
             }
-            dst = &sm_acc[t];
-            pa = &sm_acc[t];
+            dst = &sm_acc[t].p;
+            pa = &sm_acc[t].p;
             act = t < d;
-            if (act) pq = &sm_acc[t + d];  // the lanes t + d .. are idle in this step: nobody rewrites what is read
+            if (act) pq = &sm_acc[t + d].p;  // the lanes t + d .. are idle in this step: nobody rewrites what is read
             d >>= 1;
         }
         if (act) Form::slot_add(dst, pa, pq, q);
         else if (copy) Form::copy(dst, pa, q);
-        __syncthreads();
-        if (dst == &sm_alt[t]) {  // a scan step went from one copy of the running sums to the other (uniform per step)
-            G1XYZZ* x = sm_run;
+        if (phase != WALK) __syncthreads();  // (a walk step touches the lane's own slots only)
+        if (dst == &sm_alt[t].p) {  // a scan step went from one copy of the running sums to the other (uniform per step)
+            Slot* x = sm_run;
             sm_run = sm_alt;
             sm_alt = x;
         }
@@ -1599,8 +1636,8 @@ __global__ void __launch_bounds__(RB * Form::LANES) msm_bucket_reduce(TailBatch 
         // `out` is the job's PINNED host slot (zero-copy: 384 B per workgroup over the fabric instead of three
         // stream-ordered copies per job after the kernel — ~25 us per job between a round's last kernel and its challenge)
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
-        Form::store_384(out[o], sm_acc[0]);
-        Form::store_384(out[o + 1], sm_r[0]);
+        Form::store_384(out[o], sm_acc[0].p);
+        Form::store_384(out[o + 1], sm_r[0].p);
         if (blockIdx.x == 0 && w == 0 && job.host_flags) {
             job.host_flags[0] = job.status[0];
             job.host_flags[1] = *job.entries;
@@ -1637,15 +1674,15 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
     const unsigned log_m = job.log_m;
     G1XYZZ* __restrict__ out = job.out;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    G1XYZZ* sm_run = reinterpret_cast<G1XYZZ*>(smem_raw);  // RB + 1 slots
-    G1XYZZ* sm_tree = sm_run + 1;
+    RedSlot* sm_run = reinterpret_cast<RedSlot*>(smem_raw);  // RB + 1 padded slots (RedSlot: no bank conflicts)
+    RedSlot* sm_tree = sm_run + 1;
     const uint32_t w = blockIdx.y, t = threadIdx.x;
     if (!((blockIdx.x >= job.blk_lo && blockIdx.x < job.blk_hi) || blockIdx.x < job.blk_low)) {
         if (t == 0) {
-            te28_store_identity(sm_run[0]);
+            te28_store_identity(sm_run[0].p);
             size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
-            te28_store_384(out[o], sm_run[0]);
-            te28_store_384(out[o + 1], sm_run[0]);
+            te28_store_384(out[o], sm_run[0].p);
+            te28_store_384(out[o + 1], sm_run[0].p);
             if (blockIdx.x == 0 && w == 0 && job.host_flags) {
                 job.host_flags[0] = job.status[0];
                 job.host_flags[1] = *job.entries;
@@ -1658,8 +1695,8 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
     const uint32_t B = 1u << (L.c[w] - 1), m = 1u << log_m;
     const uint32_t lo = (blockIdx.x * RB + t) << log_m;
     const uint32_t base = L.boff[w];
-    te28_store_identity(sm_run[t]);
-    if (t == 0) te28_store_identity(sm_run[RB]);
+    te28_store_identity(sm_run[t].p);
+    if (t == 0) te28_store_identity(sm_run[RB].p);
     te28_store_identity(*my_acc);
     uint32_t b = min(lo + m, B), s = 0, e = 0;
     bool walking = lo < B;
@@ -1675,12 +1712,16 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
     __syncthreads();
 #pragma unroll 1
     for (;;) {
-        G1XYZZ* dst = &sm_run[t];
-        const G1XYZZ* pa = &sm_run[t];
-        const G1XYZZ* pq = &sm_run[t];
+        G1XYZZ* dst = &sm_run[t].p;
+        const G1XYZZ* pa = &sm_run[t].p;
+        const G1XYZZ* pq = &sm_run[t].p;
         bool act = false;
         if (phase == WALK) {
-            if (!__syncthreads_or(walking)) {
+            // (r06) the walk has no meeting point but its end: a lane works on slots of its own, so every WAVE walks at its own
+            // pace — its LDS traffic no longer in step with the other three waves' — and meets the workgroup once, when none of
+            // its lanes has a bucket left (until r05: a workgroup-wide vote, three barriers, in front of every step)
+            if (__ballot(walking) == 0) {
+                __syncthreads();
                 phase = SCAN;
                 continue;
             }
@@ -1707,20 +1748,20 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
                 continue;
             }
             act = t + d < RB;
-            if (act) pq = &sm_run[t + d];
+            if (act) pq = &sm_run[t + d].p;
             d <<= 1;
         } else if (phase == SHIFT) {  // slot_t <- m Suffix_t for t >= 1, in place; slot 0 keeps R_blk = Suffix_0 (m Suffix_0 is never needed)
 #pragma unroll 1
-            for (unsigned i = 0; i < log_m; i++) te28_slot_add_sync(&sm_run[t], &sm_run[t], &sm_run[t], t >= 1, false);
+            for (unsigned i = 0; i < log_m; i++) te28_slot_add_sync(&sm_run[t].p, &sm_run[t].p, &sm_run[t].p, t >= 1, false);
             __syncthreads();  // the fold reads the NEIGHBOUR's doubled slot
             phase = FOLD;
             continue;
         } else if (phase == FOLD) {
             // slot_{t+1} <- acc_t + m Suffix_{t+1}: lane t reads and rewrites slot t + 1 alone (slot RB holds the identity for the
             // last lane), the weighted sums move into LDS, slot 0 is left alone; summed over t this is A_blk
-            dst = &sm_run[t + 1];
+            dst = &sm_run[t + 1].p;
             pa = my_acc;
-            pq = &sm_run[t + 1];
+            pq = &sm_run[t + 1].p;
             act = true;
             phase = TREE;
             d = RB / 2;
@@ -1728,15 +1769,15 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
             if (d == 0) break;
             if (d <= RB / 4) {  // narrow tree steps: four lanes per sum (te28_quad_add)
                 const uint32_t c = threadIdx.x >> 2;
-                if (c < d) te28_quad_add(&sm_tree[c], &sm_tree[c], &sm_tree[c + d], threadIdx.x & 3u);
+                if (c < d) te28_quad_add(&sm_tree[c].p, &sm_tree[c].p, &sm_tree[c + d].p, threadIdx.x & 3u);
                 __syncthreads();
                 d >>= 1;
                 continue;
             }
-            dst = &sm_tree[t];
-            pa = &sm_tree[t];
+            dst = &sm_tree[t].p;
+            pa = &sm_tree[t].p;
             act = t < d;
-            if (act) pq = &sm_tree[t + d];
+            if (act) pq = &sm_tree[t + d].p;
             d >>= 1;
         }
         // barriers: the in-place scan needs its loads ahead of one and its stores behind it; a tree step and the fold are read by
@@ -1748,8 +1789,8 @@ __global__ void __launch_bounds__(RB, SWM_LOW_WAVES) msm_bucket_reduce_low(TailB
     }
     if (threadIdx.x == 0) {
         size_t o = ((size_t)w * job.red_blocks + blockIdx.x) * 2;
-        te28_store_384(out[o], sm_tree[0]);
-        te28_store_384(out[o + 1], sm_run[0]);
+        te28_store_384(out[o], sm_tree[0].p);
+        te28_store_384(out[o + 1], sm_run[0].p);
         if (blockIdx.x == 0 && w == 0 && job.host_flags) {
             job.host_flags[0] = job.status[0];
             job.host_flags[1] = *job.entries;
@@ -2354,14 +2395,15 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         flat_bins = (pl.NB + (1u << flat_fb) - 1) >> flat_fb;
         if (flat_bins > FLAT_MAX_BINS) return set_err(ctx, SWM_ERR_INTERNAL, "msm: too many coarse bins");
     }
-    size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
+    size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + 2 * (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
                               (flat ? (2 + 3 * (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 + 32 : 0);
     zero_words = (zero_words + 63) & ~(size_t)63;  // whole 256-byte lines: the runtime then clears them with one kernel, not two
     SWM_TRY(scratch(ctx, nm[0], slot_scratch(0, zero_words * 4), (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
     len_hist = big_count + 4;
-    uint32_t* two_level_bad = len_hist + (SEG_MAX + 1) * LEN_STRIDE;  // one flag per window, then the per-(window, bin) cursors
+    uint32_t* len_cursor = len_hist + (SEG_MAX + 1) * LEN_STRIDE;       // the run cursors of msm_seg_order, one per length class
+    uint32_t* two_level_bad = len_cursor + (SEG_MAX + 1) * LEN_STRIDE;  // one flag per window, then the per-(window, bin) cursors
     uint32_t* bin_cursor = two_level_bad + MAX_WIN;
     // [windows x bins] counts (room for 32 windows) | [bins x 32] offsets | [bins x 32] cursors (one 128-byte line per bin each) |
     // [bins + 1] offsets | [bins + 1] first segment index
@@ -2482,10 +2524,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     if (!flat)
         SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_desc, dim3(grid_s), dim3(ORD_THREADS), 0, bucket_off, seg_off, pl.NB,
                    SEG, seg_start, seg_len, len_hist);
-    SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_len_scan, dim3(1), dim3(64), 0, len_hist, SEG, nseg_live);
     SWM_LAUNCH(ctx, "msm_seg_order", msm_seg_order, dim3((unsigned)((nseg_max + ORD2_THREADS * ORD2_U - 1) / (ORD2_THREADS * ORD2_U))),
-               dim3(ORD2_THREADS), 0, seg_len, seg_space, SEG,
-               len_hist, order);
+               dim3(ORD2_THREADS), 0, seg_len, seg_space, SEG, (const uint32_t*)len_hist, len_cursor, nseg_live, order);
     unsigned acc_grid = (unsigned)((nseg_max + 255) / 256);
     const dim3 big_grid(std::min<unsigned>((pl.NB + (RED_BLOCK >> log_g) - 1) / (RED_BLOCK >> log_g), lat ? 2048 : 512));
     if (te) {
@@ -2556,7 +2596,8 @@ static void msm_tail_shape(MsmJob* j, bool wide) {
 // products per addition and its lane exchanges cost more than the idle lanes of the tree steps; (ii) the second operand of every step
 // in registers, the partial sum of a lane's NEXT walk step requested from HBM while the current addition runs (the three flat-load
 // waits per "run += partial" step gone, 240 VGPRs): 524 instead of 467 us — the lone wave's cycles without an issue are not its
-// operand loads.
+// operand loads (with typed loads of the whole operand up front, one wait instead of three and nothing else changed: 462.8 vs 463.3 us).
+// What those cycles WERE: LDS bank conflicts and barriers — see RedSlot and the walk's wave-level vote (msm_bucket_reduce).
 int msm_launch_lazy_tail(swm_ctx* ctx, bool wide) {
     MsmJob* j = ctx->lazy_tail;
     if (!j) return SWM_OK;
@@ -2603,7 +2644,7 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
     }
     const bool te = jobs[0]->te;  // every job of a launch has the same point form (msm_flush_tails groups them)
     if (jobs[0]->quad) {
-        const size_t lds = (3 * (size_t)jobs[0]->rb + 1) * sizeof(G1XYZZ);
+        const size_t lds = (3 * (size_t)jobs[0]->rb + 1) * sizeof(PlainSlot);
         const dim3 grid(max_red, max_win, (unsigned)k);
         if (jobs[0]->rb == 256) {
             SWM_TRY(allow_big_lds(ctx, 8, (const void*)msm_bucket_reduce<256, FormTEQuad>, lds));
@@ -2614,15 +2655,15 @@ int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k) {
         }
     } else if (te && jobs[0]->low) {
         SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce_low<256>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
-                   (RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+                   (RED_BLOCK + 1) * sizeof(RedSlot), batch);
     } else if (te) {
-        SWM_TRY(allow_big_lds(ctx, 7, (const void*)msm_bucket_reduce<256, FormTE>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+        SWM_TRY(allow_big_lds(ctx, 7, (const void*)msm_bucket_reduce<256, FormTE>, (3 * RED_BLOCK + 1) * sizeof(RedSlot)));
         SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormTE>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
-                   (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+                   (3 * RED_BLOCK + 1) * sizeof(RedSlot), batch);
     } else {
-        SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce<256, FormXYZZ>, (3 * RED_BLOCK + 1) * sizeof(G1XYZZ)));
+        SWM_TRY(allow_big_lds(ctx, 2, (const void*)msm_bucket_reduce<256, FormXYZZ>, (3 * RED_BLOCK + 1) * sizeof(RedSlot)));
         SWM_LAUNCH(ctx, "msm_bucket_reduce", (msm_bucket_reduce<256, FormXYZZ>), dim3(max_red, max_win, (unsigned)k), dim3(RED_BLOCK),
-                   (3 * RED_BLOCK + 1) * sizeof(G1XYZZ), batch);
+                   (3 * RED_BLOCK + 1) * sizeof(RedSlot), batch);
     }
     for (int i = 0; i < k; i++) {
         SWM_HIP(ctx, hipEventRecord(jobs[i]->done, st));
