@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --steps 10 --warmup 2 > $out/bench_prove.json 2> $out/bench_prove.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in > $out/bench_prove_driver_flags.json 2>> $out/bench_prove.err   # the driver's flags
 python3 bench.py --log-n 22 --steps 4 --warmup 1 --no-cpu-baseline --no-drop-in > $out/bench_prove_2p22.json 2>> $out/bench_prove.err
-python3 bench.py --circuit merkle --steps 10 --warmup 2 > $out/bench_merkle.json 2> $out/bench_merkle.err
+python3 bench.py --circuit merkle --steps 10 --warmup 2 --overlap 4 > $out/bench_merkle.json 2> $out/bench_merkle.err   # (+ four contexts on ONE shared key)
 python3 bench.py --workload msm --steps 12 --warmup 2 > $out/bench_msm.json 2> $out/bench_msm.err
 python3 bench.py --workload msm --log-n 22 --steps 8 --warmup 2 --cpu-log-n 18 > $out/bench_msm_2p22.json 2> $out/bench_msm22.err
 SWM_PROOF_MARKS=1 rocprofv3 --kernel-trace --stats -d $out/prof_prove -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-drop-in > $out/prof_prove.log 2>&1
@@ -39,6 +39,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-include-regex ntt_pass -d $out/pmc_ntt_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex ntt_pass -d $out/pmc_ntt_write -o run --output-format csv -- python3 tools/ubench/ntt_one.py 22 5 > $out/pmc_ntt_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex spmv -d $out/pmc_spmv_fetch -o run --output-format csv -- python3 tools/ubench/spmv_one.py 20 5 > $out/pmc_spmv_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex spmv -d $out/pmc_spmv_write -o run --output-format csv -- python3 tools/ubench/spmv_one.py 20 5 > $out/pmc_spmv_write.log 2>&1
+# r06: LDS bank conflicts and wait shares of every kernel of a proof (what found the 192-byte slots of the bucket stage and the
+# LDS-resident scalar of msm_digits)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS -d $out/pmc_lds -o run --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-drop-in > $out/pmc_lds.log 2>&1
+python3 tools/pmc_lds.py $(ls $out/pmc_lds/*counter_collection.csv | head -1) > $out/lds_conflicts.txt 2>&1
+rm -rf $out/pmc_lds
 python3 tools/ubench/ntt_one.py 22 10 > $out/ntt_one.json 2> $out/ntt_one.err
 python3 tools/ubench/spmv_one.py 20 10 > $out/spmv_one.json 2> $out/spmv_one.err
 python3 tools/ubench/ntt_time.py > $out/ntt_time.log 2>&1

@@ -12,7 +12,7 @@ for src, dst in (("bench_prove.json", "bench_prove.json"), ("bench_msm.json", "b
                  ("prof_merkle/run_kernel_stats.csv", "prove_merkle_kernel_stats.csv"),
                  ("prof_msm/run_kernel_stats.csv", "msm_2p20_kernel_stats.csv"),
                  ("bench_prove_driver_flags.json", "bench_prove_default_flags.json"), ("bench_prove_2p22.json", "bench_prove_2p22.json"),
-                 ("prio_ab.log", "prio_ab.log"), ("mid_sweep.log", "mid_sweep.log"),
+                 ("prio_ab.log", "prio_ab.log"), ("mid_sweep.log", "mid_sweep.log"), ("lds_conflicts.txt", "lds_conflicts.txt"),
                  ("ntt_time.log", "ntt_standalone.log"), ("small_proofs.log", "small_proofs.log"),
                  ("merkle_build.json", "merkle_build_2p18.json"), ("shard_emulate.jsonl", "shard_emulate.jsonl"), ("ntt_sharded_one.jsonl", "ntt_sharded_one.jsonl"),
                  ("prof_merkle_build/run_kernel_stats.csv", "merkle_build_2p18_kernel_stats.csv")):
