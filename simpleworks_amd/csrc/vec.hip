@@ -98,7 +98,9 @@ int batch_inverse_run(swm_ctx* ctx, void* d, size_t n) {
     // (r05: up to 2^20 elements — the inversions of proofs up to 2^18 constraints: a lane's chain is 29 instead of 65 products beside the
     // one inversion every workgroup waits for; 2^16 proofs 7.1 -> 6.9 ms, 2^14 4.15 -> 4.05, 2^18 unchanged; r04: 65 536)
     // (the kernel on the transform's 29-bit multiplier; the 8 x 32-bit Comba kernel of r01 - r04 is gone: r06)
-    static constexpr size_t small_below = 1048576;
+    // r06: measured alone over n (tools/ubench/binv_time.py): 4-element chunks 109 / 142 / 248 us at n = 2^18 / 2^19 / 2^20, 16-element
+    // chunks 129 / 132 / 136 us — the bound is 2^18 (r05 had 2^20: the inversions of a 2^18-constraint proof took 248 instead of 136 us)
+    static constexpr size_t small_below = 262144;
     if (n <= small_below) {
         const size_t threads = (n + BINV_CHUNK_SMALL - 1) / BINV_CHUNK_SMALL;
         const dim3 grid((unsigned)((threads + BINV_THREADS - 1) / BINV_THREADS));

@@ -6,7 +6,7 @@ import simpleworks_amd as swm
 from pyref.prng import fr_array
 ctx = swm.Context(0)
 base = fr_array(1 << 20, 5)
-for n in (16, 4096, 1 << 16, 1 << 20, 3 << 20):
+for n in (16, 4096, 1 << 14, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 22):
     x = np.ascontiguousarray(np.tile(base, ((n + (1 << 20) - 1) >> 20, 1))[:n])
     d = ctx.to_device(x)
     for _ in range(3): ctx.batch_inverse_fr_dev(d, n)
