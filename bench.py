@@ -149,28 +149,52 @@ def _run_sharded_children(args, sizes, rank, world, device_index, dist, torch, c
     import queue
     import subprocess
     import threading
-    from simpleworks_amd._lib import rccl_unique_id
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SWM_BENCH_FORCE_DIST")}
+
+    def spawn(id_arg):
+        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", id_arg, "--child-rank", str(rank), "--child-world", str(world),
+               "--child-device", str(device_index), "--sharded-log-n", ",".join(str(x) for x in sizes), "--circuit", args.circuit]
+        if args.r1cs:
+            cmd += ["--r1cs", args.r1cs]
+        c = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, text=True)
+        q = queue.Queue()
+
+        def reader():  # (reads a pipe: no GPU, no collective — safe to leave behind)
+            for line in c.stdout:
+                q.put(line)
+            q.put(None)
+        threading.Thread(target=reader, daemon=True).start()
+        return c, q
+    # The ncclUniqueId is created by rank 0's CHILD — the process (and the librccl: the children do not import torch, so theirs is
+    # the loader's copy, not torch's) that will also call ncclCommInitRank with it — and travels child -> parent -> torch broadcast
+    # -> the other parents -> their children's command lines.  (An id made by this process would come from torch's RCCL build.)
+    child, lines, id_hex, err = None, None, "", None
+    if rank == 0:  # (whatever happens here, rank 0 takes part in the broadcast below: zeros tell the others that there is no id)
+        try:
+            child, lines = spawn("create")
+            first = lines.get(timeout=float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "300")))
+            rec = json.loads(first) if first else {}
+            id_hex = rec.get("id", "")
+            if not id_hex:
+                err = rec.get("error", "rank 0's child produced no ncclUniqueId")
+        except Exception as e:  # noqa: BLE001
+            err = "unique id: %r" % (e,)
     try:
         idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).to(coll_dev)
+        if rank == 0 and len(id_hex) == 256:
+            idt = torch.frombuffer(bytearray(bytes.fromhex(id_hex)), dtype=torch.uint8).to(coll_dev)
         dist.broadcast(idt, 0)
         id_hex = bytes(idt.cpu().numpy().tobytes()).hex()
+        if not any(idt.cpu().numpy().tolist()):
+            raise RuntimeError("rank 0's child produced no ncclUniqueId")
+        if rank != 0:
+            child, lines = spawn(id_hex)
     except Exception as e:  # noqa: BLE001
-        return [{"error": "unique id: %r" % (e,)}]
-    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", id_hex, "--child-rank", str(rank), "--child-world", str(world),
-           "--child-device", str(device_index), "--sharded-log-n", ",".join(str(x) for x in sizes), "--circuit", args.circuit]
-    if args.r1cs:
-        cmd += ["--r1cs", args.r1cs]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SWM_BENCH_FORCE_DIST")}
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, text=True)
-    lines = queue.Queue()
-
-    def reader():  # (reads a pipe: no GPU, no collective — safe to leave behind)
-        for line in child.stdout:
-            lines.put(line)
-        lines.put(None)
-    threading.Thread(target=reader, daemon=True).start()
+        err = err or "unique id: %r" % (e,)
+    if err:
+        if child is not None and child.poll() is None:
+            child.kill()
+        return [{"error": err}]
     out = []
     for lg_s in sizes:
         budget = float(os.environ.get("SWM_BENCH_SHARDED_TIMEOUT", "300" if lg_s <= 20 else "480"))
@@ -217,7 +241,13 @@ def sharded_child(args):
     try:
         ctx = swm.Context(args.child_device)
         M.set_default_context(ctx)
-        ctx.rccl_init(bytes.fromhex(args.sharded_child), rank, world)
+        if args.sharded_child == "create":  # rank 0: the id comes from THIS process's librccl and goes to the parent first
+            from simpleworks_amd._lib import rccl_unique_id
+            uid = rccl_unique_id()
+            emit({"id": uid.hex()})
+        else:
+            uid = bytes.fromhex(args.sharded_child)
+        ctx.rccl_init(uid, rank, world)
     except Exception as e:  # noqa: BLE001
         emit({"error": "rank %d: %r [%s]" % (rank, e, rccl_info()[1])})
         return 1
