@@ -61,7 +61,7 @@ pub struct PackedR1cs {
 
 /// What the PROVER needs from a live constraint system: the two assignment vectors and the shape — nothing else
 /// (`swm_generate_proof` reads num_instance, num_witness, num_constraints, instance, witness; the matrices are the key's, as
-/// in ark-marlin, whose `prover_init` never calls `to_matrices()` either).  No `finalize()` / `to_matrices()` / CSR copies
+/// in ark-marlin, whose `prover_init` never calls `to_matrices()` either).  No `to_matrices()` / CSR copies
 /// per proof: at 2^20 constraints those were 3 x 2^20 `Vec` clones plus ~100 MB of copies on one host thread, more than
 /// the 49-ms GPU proof they fed.
 ///
@@ -91,6 +91,11 @@ pub fn fr_view_is_sound() -> bool {
 
 impl<'a> AssignmentOnly<'a> {
     pub fn from_cs(cs: &'a ConstraintSystemRef<Fr>) -> Result<Self, SynthesisError> {
+        // `finalize()` stays: with OptimizationGoal::Weight it OUTLINES linear combinations into new witness variables and
+        // constraints — the system the key was indexed from went through it (`PackedR1cs::from_cs`), so the assignment and the
+        // constraint count have to as well (ark-marlin's own prover calls it at the same point).  It is part of synthesis, not of
+        // what this crate adds; what is gone is `to_matrices()` and the three CSR copies.
+        cs.finalize();
         let num_constraints = cs.num_constraints();
         let borrow = cs.borrow().ok_or(SynthesisError::MissingCS)?;
         let copies = if fr_view_is_sound() {

@@ -451,7 +451,7 @@ pub fn generate_proof(
 }
 
 fn prove<R: RngCore + 'static>(pk: &ProvingKey, cs: ConstraintSystemRef, rng: &mut R) -> std::result::Result<MarlinProof, SwmError> {
-    // assignment only: no finalize() / to_matrices() / CSR copies at prove time (the matrices are the key's)
+    // assignment only: finalize() as ark-marlin's prover does, then no to_matrices() / CSR copies (the matrices are the key's)
     let packed = AssignmentOnly::from_cs(&cs).map_err(|e| SwmError { code: -1, what: "ConstraintSystemRef::borrow", detail: format!("{:?}", e) })?;
     with_state(|st| {
         let ctx = st.ctx;
