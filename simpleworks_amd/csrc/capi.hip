@@ -52,6 +52,8 @@ void drain_streams(swm_ctx* ctx) {
     ctx->pending_tails.clear();
     ctx->lazy_tail = nullptr;
     for (auto& e : ctx->set_acc_event) e = nullptr;
+    for (auto& e : ctx->lane_copy_event) e = nullptr;
+    ctx->twin_sorted_event = nullptr;
     ctx->msm_since_wait = 0;
 }
 
@@ -468,6 +470,8 @@ void swm_destroy(swm_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->sort_event)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : ctx->twin_copy_event)
+        if (e) (void)hipEventDestroy(e);
     rccl_release(ctx);
     if (ctx->rccl_send) (void)hipFree(ctx->rccl_send);
     if (ctx->rccl_recv) (void)hipFree(ctx->rccl_recv);
@@ -835,7 +839,7 @@ int swm_profile_reset(swm_ctx* ctx) {
     prof_flush(ctx);
     ctx->prof.clear();
     ctx->stat_msm_calls = ctx->stat_msm_points = ctx->stat_msm_digits = ctx->stat_ntt_calls = ctx->stat_ntt_elems = 0;
-    ctx->stat_spmv_calls = ctx->stat_spmv_rows = ctx->stat_spmv_nnz = ctx->stat_msm_adds = ctx->stat_msm_zero_points = 0;
+    ctx->stat_spmv_calls = ctx->stat_spmv_rows = ctx->stat_spmv_nnz = ctx->stat_msm_adds = ctx->stat_msm_zero_points = ctx->stat_msm_twins = 0;
     ctx->call_log.clear();
     return SWM_OK;
 }
@@ -855,11 +859,11 @@ int swm_profile_json(swm_ctx* ctx, char* buf, size_t buflen) {
     }
     char tail[512];
     snprintf(tail, sizeof(tail),
-             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"msm_digits\":%llu,\"msm_adds\":%llu,\"msm_zero_points\":%llu,\"ntt_calls\":%llu,"
+             "],\"work\":{\"msm_calls\":%llu,\"msm_points\":%llu,\"msm_digits\":%llu,\"msm_adds\":%llu,\"msm_zero_points\":%llu,\"msm_twins\":%llu,\"ntt_calls\":%llu,"
              "\"ntt_elements\":%llu,\"spmv_calls\":%llu,\"spmv_rows\":%llu,\"spmv_nnz\":%llu}}",
              (unsigned long long)ctx->stat_msm_calls, (unsigned long long)ctx->stat_msm_points,
              (unsigned long long)ctx->stat_msm_digits, (unsigned long long)ctx->stat_msm_adds,
-             (unsigned long long)ctx->stat_msm_zero_points, (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
+             (unsigned long long)ctx->stat_msm_zero_points, (unsigned long long)ctx->stat_msm_twins, (unsigned long long)ctx->stat_ntt_calls, (unsigned long long)ctx->stat_ntt_elems,
              (unsigned long long)ctx->stat_spmv_calls, (unsigned long long)ctx->stat_spmv_rows,
              (unsigned long long)ctx->stat_spmv_nnz);
     s += tail;

@@ -63,12 +63,18 @@ struct swm_ctx {
     hipEvent_t acc_event[MSM_SLOTS] = {nullptr};  // "partial sums ready" per slot (stage A -> stage T, deferred bucket stages)
     hipEvent_t sort_event[MSM_SLOTS] = {nullptr};  // "sorted" per slot (stage S -> stage A)
     hipEvent_t set_acc_event[4] = {nullptr, nullptr, nullptr, nullptr};  // accumulation that last read each per-lane scratch set (not owned)
+    // twin jobs (msm.h): the follower's copy that last read a lane's segment descriptors, the accumulation that last read the
+    // second sorted array (neither owned), and the "copied" events per result slot (owned)
+    hipEvent_t lane_copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t twin_sorted_event = nullptr;
+    hipEvent_t twin_copy_event[MSM_SLOTS] = {nullptr};
     std::vector<swm::MsmJob*> pending_tails;      // jobs whose bucket stage waits for msm_flush_tails
     swm::MsmJob* lazy_tail = nullptr;             // large job whose bucket stage is shaped by what follows it (msm.hip, msm_tail_shape)
     int next_slot = 0;
     std::multimap<size_t, void*> pool;  // freed device blocks by capacity (stream-ordered reuse)
     // work log since the last swm_profile_reset (the prove() byte count is the sum over logged calls)
     uint64_t stat_msm_digits = 0;  // points x windows (zero digits included)
+    uint64_t stat_msm_twins = 0;   // jobs that took the sort of their twin (msm.h: MsmTwin)
     uint64_t stat_msm_adds = 0;    // NON-ZERO digits = bucket entries = the mixed additions msm_accumulate performs (counted by
                                    // the sort on the device; collected in msm_finish)
     uint64_t stat_msm_zero_points = 0;  // MSM points with a zero scalar or an identity base (nothing but their scalar is read)

@@ -447,7 +447,11 @@ struct AsyncMsm {
     bool have_result = false;  // set by commit_gather (the exchange of a whole round) before commit_wait is reached
     G1XYZZ result;
 };
-void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out) {
+// twin_offset / twin_lead (msm.h: MsmTwin): this commitment is followed by one of the SAME coefficients against the powers from
+// *twin_offset on / follows the commitment twin_lead of the same coefficients — the degree-shifted commitment of a bounded
+// polynomial beside its plain one; the second job then takes the first one's sort.
+void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, const Fr* coeffs, size_t n, AsyncMsm* out,
+                    const size_t* twin_offset = nullptr, AsyncMsm* twin_lead = nullptr) {
     const G1Affine *b = nullptr, *b28 = nullptr;
     MsmTable tab;
     if (n) pk.bases_at(offset, n, &b, &b28, &tab);
@@ -524,8 +528,20 @@ void commit_enqueue(swm_ctx* ctx, int* lane, const swm_pk& pk, size_t offset, co
         return;
     }
     tab.offset += lo;
+    MsmTwin tw;
+    if (!out->sharded && n) {
+        if (twin_offset) {
+            const G1Affine *b2 = nullptr, *b282 = nullptr;
+            pk.bases_at(*twin_offset, n, &b2, &b282, &tw.tab2);
+            tw.role = MsmTwin::LEAD;
+        } else if (twin_lead && !twin_lead->sharded) {
+            tw.role = MsmTwin::FOLLOW;
+            tw.lead = &twin_lead->job;
+        }
+    }
     rc_check(ctx, msm_enqueue(ctx, (*lane)++, b + lo, b28 + lo, coeffs + lo, hi - lo, 1, &out->job, MsmInfMask(),
-                              (long)(hi - lo) <= batch_below, tab));
+                              (long)(hi - lo) <= batch_below, tab, tw));
+    if (out->job.twin_kept_lane) (*lane)--;  // a follower leaves its lane's scratch set to the next job
 }
 // The same for coefficients that are ALREADY distributed: this rank holds coefficient rank + G j at local[j] (the CYCLIC
 // layout a sharded inverse transform leaves, ntt.hip) and commits to them where they are — the table rows of its scalars
@@ -635,8 +651,9 @@ void pc_commit_begin(swm_ctx* ctx, const swm_pk& pk, int* lane, const Fr* coeffs
                      bool hiding, CommitJob* job) {
     job->has_bound = has_bound;
     job->hiding = hiding;
-    commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain);
-    if (has_bound) commit_enqueue(ctx, lane, pk, pk.srs_max_degree - bound, coeffs, n, &job->shifted);
+    const size_t shift = has_bound ? pk.srs_max_degree - bound : 0;
+    commit_enqueue(ctx, lane, pk, 0, coeffs, n, &job->plain, has_bound ? &shift : nullptr);
+    if (has_bound) commit_enqueue(ctx, lane, pk, shift, coeffs, n, &job->shifted, nullptr, &job->plain);
 }
 // The blinding half of pc_commit_end: the draws (plain first, then shifted) and the hiding terms sum_j r_j gamma^j G —
 // host work (~70 us per term) that depends on the generator only, not on the MSM: the prover calls it for the round's

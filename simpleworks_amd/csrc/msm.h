@@ -77,8 +77,39 @@ hipError_t msm_create_stream(hipStream_t* out);
 // strided layout have to know: only that schedule maps scalars to bases through MsmTable::blk_log / bstride)
 bool msm_flat_applies(const MsmTable& tab, size_t n);
 
+// Twin jobs (r06).  The plain and the degree-shifted commitment of one polynomial are MSMs of the SAME scalars over two base sets
+// whose tables have the same width: digits, coarse histogram, partition and bin sort of the second job would repeat the first
+// one's work entry for entry — only the table ROW of an entry differs (w * stride + offset + i of the other table).  The first
+// job (LEAD) therefore writes a second sorted array with the rows of the second table from its bin sort, and the second job
+// (FOLLOW) copies the bucket / segment descriptors (~12 MB) instead of sorting.  Either side falls back to the ordinary
+// schedule when the shapes do not match (different width, a job below the table schedule, a sharded split, SWM_MSM_TWIN=0).
+struct MsmJob;
+struct MsmTwin {
+    enum Role { NONE = 0, LEAD = 1, FOLLOW = 2 };
+    Role role = NONE;
+    MsmTable tab2;           // LEAD: the table (with the offset) of the job that follows
+    MsmJob* lead = nullptr;  // FOLLOW: the job whose sort this one takes over
+};
+// what a LEAD leaves for its follower
+struct MsmTwinSrc {
+    bool ready = false;
+    const void* scalars = nullptr;
+    int mont = 0, lane = -1;
+    unsigned c = 0;
+    const G1TE* te2 = nullptr;
+    size_t stride2 = 0, offset2 = 0;
+    // the lead's device arrays and the geometry they were built with (the follower's must be the same)
+    const uint32_t *block = nullptr, *seg_start = nullptr, *seg_off = nullptr, *big_list = nullptr;
+    size_t zero_words = 0, nseg_max = 0;
+    uint32_t SEG = 0, big_nseg = 0, flat_bins = 0;
+    hipEvent_t sorted = nullptr;  // recorded after the lead's bin sort
+};
+
 struct MsmJob {
     bool active = false;
+    MsmTwinSrc twin;                    // LEAD only
+    bool twin_kept_lane = false;        // FOLLOW: the job did not use its lane's scratch set, the next job may take the same lane
+    hipEvent_t twin_copied = nullptr;   // LEAD: the follower's copy of this job's descriptors (msm_finish waits for it before the slot is released)
     size_t n = 0;
     WinLayout pl;
     unsigned big_nseg = 16;  // buckets with more segments than this were folded into their first partial sum
@@ -118,7 +149,8 @@ struct MsmInfMask {
 // defer_tail: stop after the bucket folds and leave the bucket stage (the latency-bound tail) to msm_flush_tails, which
 // runs the tails of every job enqueued so far in one launch.  The MsmJob must stay at its address until msm_finish.
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false, MsmTable tab = MsmTable());
+                int mont, MsmJob* job, MsmInfMask inf = MsmInfMask(), bool defer_tail = false, MsmTable tab = MsmTable(),
+                MsmTwin twin = MsmTwin());
 int msm_launch_tails(swm_ctx* ctx, MsmJob** jobs, int k);
 int msm_launch_lazy_tail(swm_ctx* ctx, bool wide);  // the held-back bucket stage of ctx->lazy_tail, if any
 int msm_flush_tails(swm_ctx* ctx);

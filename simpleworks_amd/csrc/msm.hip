@@ -636,11 +636,22 @@ __device__ __forceinline__ void flat_seg_write(const FlatSegOut& o, uint32_t c, 
         atomicAdd(&lh[o.SEG - (ke - ks)], 1u);
     }
 }
+// A twin's second sorted array (MsmTwin): the same entries with the rows of the follower's table — an entry's window is
+// row / tstride (the rows of a window are tstride apart and offset + i < tstride), its row there row + w * dstride + doff
+// (mod 2^31: the sign of the digit stays in bit 31).
+struct TwinOut {
+    uint32_t* sorted2;  // null: no follower
+    uint32_t tstride, dstride, doff;
+    __device__ __forceinline__ uint32_t map(uint32_t e) const {
+        const uint32_t row = e & 0x7fffffffu, w = row / tstride;
+        return (e & 0x80000000u) | ((row + w * dstride + doff) & 0x7fffffffu);
+    }
+};
 template <int BT>
 __global__ void __launch_bounds__(BT) msm_flat_bin_sort(const uint2* __restrict__ tmp, unsigned fb, uint32_t NB,
                                                                  const uint32_t* __restrict__ bin_off,
                                                                  const uint32_t* __restrict__ bin_seg_off, FlatSegOut o,
-                                                                 uint32_t* __restrict__ sorted) {
+                                                                 uint32_t* __restrict__ sorted, TwinOut tw) {
     SWM_LIGHT_KERNEL();
     extern __shared__ uint32_t stage32[];  // fc[nf] | fo[nf] | FLAT_BIN_CAP entries
     __shared__ uint32_t wsum[2][BT / 64];
@@ -736,12 +747,29 @@ __global__ void __launch_bounds__(BT) msm_flat_bin_sort(const uint2* __restrict_
         }
         __syncthreads();
         for (uint32_t i = t; i < cnt; i += BT) sorted[lo + i] = stage[i];
+        if (tw.sorted2)
+            for (uint32_t i = t; i < cnt; i += BT) tw.sorted2[lo + i] = tw.map(stage[i]);
     } else {  // oversized bin (many equal digits): scattered 4-byte stores, correct for any size
         for (uint32_t i = t; i < cnt; i += BT) {
             uint2 e = tmp[lo + i];
-            sorted[lo + atomicAdd(&fo[e.y & fmask], 1u)] = e.x;
+            const uint32_t at = lo + atomicAdd(&fo[e.y & fmask], 1u);
+            sorted[at] = e.x;
+            if (tw.sorted2) tw.sorted2[at] = tw.map(e.x);
         }
     }
+}
+// The follower of a twin pair takes the lead's bucket and segment descriptors: up to eight word ranges, one launch.
+struct TwinCopy {
+    const uint32_t* src[8];
+    uint32_t* dst[8];
+    uint32_t words[8];
+    int k;
+};
+__global__ void __launch_bounds__(256) msm_twin_copy(TwinCopy c) {
+    SWM_LIGHT_KERNEL();
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+    for (int r = 0; r < c.k; r++)
+        for (uint32_t i = gid; i < c.words[r]; i += step) c.dst[r][i] = c.src[r][i];
 }
 
 // ---- table construction: out[i] = 2^k in[i] as XYZZ (k doublings), then batch normalisation back to affine
@@ -2055,10 +2083,13 @@ bool msm_flat_applies(const MsmTable& tab, size_t n) {
            (uint64_t)tab.stride * msm_table_windows(tab.c) < (1ull << 31);
 }
 int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine* d_bases28, const void* d_scalars, size_t n,
-                int mont, MsmJob* job, MsmInfMask inf, bool defer_tail, MsmTable tab) {
+                int mont, MsmJob* job, MsmInfMask inf, bool defer_tail, MsmTable tab, MsmTwin twin) {
     job->active = false;
     job->tail_pending = false;
     job->n = n;
+    job->twin = MsmTwinSrc();
+    job->twin_copied = nullptr;
+    job->twin_kept_lane = false;
     if (n == 0) return SWM_OK;
     if (n >= (1ull << 31)) return set_err(ctx, SWM_ERR_INVALID_ARG, "msm: n must be < 2^31");
     ctx->stat_msm_calls++;
@@ -2076,6 +2107,20 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     const bool flat = msm_flat_applies(tab, n);
     const bool te = flat && tab.te != nullptr;  // twisted Edwards rows: accumulation and bucket stage run in that form
     job->te = te;
+    // Twin jobs (msm.h): LEAD writes the follower's sorted array beside its own, FOLLOW copies the lead's descriptors.  Any
+    // mismatch of the shapes leaves both on the ordinary schedule.  SWM_MSM_TWIN=0: never.
+    static const bool twin_on = env_switch("SWM_MSM_TWIN", 1, 0, 1) != 0;
+    // (from 2^15 points: below, a proof is a chain of launches and the follower's wait for the lead's sort costs more than its own
+    // sort beside it — 2^14 constraints 3.88 -> 4.0 ms, 2^16 6.58 -> 6.49 ms, r06)
+    static constexpr size_t twin_min = 32768;
+    const bool twin_shape = twin_on && n >= twin_min && lane >= 0 && flat && te && tab.contiguous() && tab.scalar_stride == 1 && tab.shard_world <= 1 && !inf.mask;
+    const bool lead = twin_shape && twin.role == MsmTwin::LEAD && twin.tab2.te && twin.tab2.c == tab.c && twin.tab2.contiguous() &&
+                      twin.tab2.scalar_stride == 1 && twin.tab2.shard_world <= 1 && msm_flat_applies(twin.tab2, n) &&
+                      twin.tab2.offset + n <= twin.tab2.stride && tab.offset + n <= tab.stride;
+    MsmJob* const tsrc = twin_shape && twin.role == MsmTwin::FOLLOW ? twin.lead : nullptr;
+    bool follow = tsrc && tsrc != job && tsrc->active && tsrc->twin.ready && tsrc->twin.scalars == d_scalars && tsrc->n == n &&
+                  tsrc->twin.mont == mont && tsrc->twin.c == tab.c && tsrc->twin.te2 == tab.te && tsrc->twin.stride2 == tab.stride &&
+                  tsrc->twin.offset2 == tab.offset;
     if (!tab.contiguous() && !flat)
         return set_err(ctx, SWM_ERR_INTERNAL, "msm: a strided base layout needs the precomputed-window schedule");
     // low-latency schedule (flat MSMs below ~2^18 points, where a proof is a chain of dependent additions rather than
@@ -2233,9 +2278,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         if (!ctx->fork_event) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         SWM_HIP(ctx, hipEventRecord(ctx->fork_event, main_stream));
         SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->fork_event, 0));  // the scalars are ready
-        // the scratch set of this lane was last read by the accumulation of the job two back
-        // (single-stream jobs too: their stream is not necessarily the one the set's previous reader ran on)
-        if (ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
+        // (the waits for the previous readers of this lane's scratch set: below, once it is known whether the job uses the set)
     }
     hipStream_t st = st_sort;
     const size_t slot_bytes = (size_t)MAX_WIN * 32 * sizeof(G1XYZZ) + 64;  // up to 1024 (A, R) pairs + status words
@@ -2398,6 +2441,23 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     size_t zero_words = 2 * (size_t)(pl.NB + 1) + 4 + 2 * (size_t)(SEG_MAX + 1) * LEN_STRIDE + MAX_WIN + (size_t)pl.nwin * maxbins +
                               (flat ? (2 + 3 * (size_t)FLAT_CUR_STRIDE) * FLAT_MAX_BINS + 4 + 32 : 0);
     zero_words = (zero_words + 63) & ~(size_t)63;  // whole 256-byte lines: the runtime then clears them with one kernel, not two
+    // the follower's arrays must have the geometry of the lead's
+    follow = follow && tsrc->twin.zero_words == zero_words && tsrc->twin.nseg_max == nseg_max && tsrc->twin.SEG == SEG &&
+             tsrc->twin.big_nseg == big_nseg && tsrc->twin.flat_bins == flat_bins;
+    if (follow) {
+        // A follower touches nothing of its lane's scratch set — its sorted array and its segment descriptors live in the pair's own
+        // buffers, free once the previous pair's follower has accumulated (the lead waited for that before its bin sort) — so the
+        // NEXT job may take this lane's set: the caller gets the lane back (pipelined form: job->twin_kept_lane), and that job's sort
+        // runs beside the lead's accumulation instead of waiting for it (two sets: the sort of job k + 2 waits for accumulation k).
+        snprintf(nm[1], sizeof(nm[1]), "msmT.segs");
+        job->twin_kept_lane = !one_stream;
+    } else if (lane >= 0) {
+        // the scratch set of this lane was last read by the accumulation of the job two back
+        // (single-stream jobs too: their stream is not necessarily the one the set's previous reader ran on)
+        if (ctx->set_acc_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->set_acc_event[lane], 0));
+        // ... and, when that job led a twin pair, copied by its follower
+        if (ctx->lane_copy_event[lane]) SWM_HIP(ctx, hipStreamWaitEvent(st_sort, ctx->lane_copy_event[lane], 0));
+    }
     SWM_TRY(scratch(ctx, nm[0], slot_scratch(0, zero_words * 4), (void**)&hist));
     cursor = hist + pl.NB + 1;
     big_count = cursor + pl.NB + 1;
@@ -2441,6 +2501,35 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     SWM_HIP(ctx, zero_fill_async(hist, zero_words * 4, ctx->stream));  // (a kernel with issue priority, not the runtime's fill: fill.cuh)
     const Fr* sc = reinterpret_cast<const Fr*>(d_scalars);
     unsigned grid_n = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    if (follow) {
+        // the second sorted array the lead's bin sort wrote; the descriptors: counts, first segments, the list of oversized buckets,
+        // status words, length histogram, the bins' entry and segment totals, the segments.  Not the cursors and the count of live
+        // segments, which the lead's msm_seg_order may be advancing at this moment: this job's own stay zero for its own.
+        SWM_TRY(scratch(ctx, "msmT.sorted", total * 4, (void**)&sorted));
+        SWM_HIP(ctx, hipStreamWaitEvent(ctx->stream, tsrc->twin.sorted, 0));
+        const uint32_t* a = tsrc->twin.block;
+        TwinCopy tc;
+        memset(&tc, 0, sizeof(tc));
+        auto range = [&](const uint32_t* from, uint32_t* to, size_t words) {
+            tc.src[tc.k] = from;
+            tc.dst[tc.k] = to;
+            tc.words[tc.k] = (uint32_t)words;
+            tc.k++;
+        };
+        range(a, hist, pl.NB + 1);
+        range(a + (big_count - hist), big_count, 3);
+        range(a + (len_hist - hist), len_hist, (size_t)(SEG_MAX + 1) * LEN_STRIDE);
+        range(a + (flat_off - hist), flat_off, 2 * (size_t)FLAT_MAX_BINS + 4);
+        range(tsrc->twin.seg_off, seg_off, pl.NB + 1);
+        range(tsrc->twin.big_list, big_list, pl.NB);
+        range(tsrc->twin.seg_start, seg_start, 2 * nseg_max);  // seg_start | seg_len
+        SWM_LAUNCH(ctx, "msm_twin_copy", msm_twin_copy, dim3(1024), dim3(256), 0, tc);
+        if (!ctx->twin_copy_event[slot]) SWM_HIP(ctx, hipEventCreateWithFlags(&ctx->twin_copy_event[slot], hipEventDisableTiming));
+        SWM_HIP(ctx, hipEventRecord(ctx->twin_copy_event[slot], ctx->stream));
+        tsrc->twin_copied = ctx->twin_copy_event[slot];
+        if (tsrc->twin.lane >= 0) ctx->lane_copy_event[tsrc->twin.lane] = ctx->twin_copy_event[slot];
+        ctx->stat_msm_twins++;
+    } else {
     SWM_LAUNCH(ctx, "msm_digits", msm_digits, dim3(grid_n), dim3(256), 0, sc, n, mont, pl, digits, inf.mask, inf.first,
                big_count + 1 /* zeroed with the histogram */, dshard, tab.scalar_stride != 1 ? tab.blk_log : 31u,
                tab.scalar_stride != 1 ? tab.bstride : (size_t)0);
@@ -2484,8 +2573,39 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         // (bucket / segment offsets, segment descriptors, the length histogram and the list of oversized buckets come out of
         // the bin sort: no scans over the bucket histogram, no msm_seg_desc)
         const FlatSegOut fso{hist, bucket_off, seg_off, seg_start, seg_len, len_hist, big_count, big_list, SEG, big_nseg, te ? 1u : 0u};
+        TwinOut two{nullptr, 1u, 0u, 0u};
+        if (lead) {
+            // (the array is read by the accumulation of the previous pair's follower)
+            SWM_TRY(scratch(ctx, "msmT.sorted", total * 4, (void**)&two.sorted2));
+            if (ctx->twin_sorted_event) SWM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->twin_sorted_event, 0));
+            two.tstride = (uint32_t)tab.stride;
+            two.dstride = (uint32_t)twin.tab2.stride - (uint32_t)tab.stride;
+            two.doff = (uint32_t)twin.tab2.offset - (uint32_t)tab.offset;
+        }
         SWM_LAUNCH(ctx, "msm_flat_bin_sort", msm_flat_bin_sort<BIN_THREADS>, dim3(flat_bins), dim3(BIN_THREADS), lds_bin,
-                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted);
+                   (const uint2*)pairs, flat_fb, pl.NB, flat_off, flat_seg_off, fso, sorted, two);
+        if (lead) {
+            MsmTwinSrc& t = job->twin;
+            t.scalars = d_scalars;
+            t.mont = mont;
+            t.lane = lane;
+            t.c = tab.c;
+            t.te2 = twin.tab2.te;
+            t.stride2 = twin.tab2.stride;
+            t.offset2 = twin.tab2.offset;
+            t.block = hist;
+            t.seg_start = seg_start;
+            t.seg_off = seg_off;
+            t.big_list = big_list;
+            t.zero_words = zero_words;
+            t.nseg_max = nseg_max;
+            t.SEG = SEG;
+            t.big_nseg = big_nseg;
+            t.flat_bins = flat_bins;
+            t.sorted = ctx->sort_event[slot];
+            SWM_HIP(ctx, hipEventRecord(t.sorted, ctx->stream));
+            t.ready = true;
+        }
     } else {
         // tile size: flat between 2^15 and 2^18 on MI355X (the scatter is bound by its 4-byte scattered writes: 73 G digits/s)
         const uint32_t SORT_TILE = SORT_TILE_MIN;
@@ -2511,6 +2631,7 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
         SWM_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(tiles, pl.nwin), dim3(SORT_THREADS), lds_sort, digits, n, pl,
                    SORT_TILE, bucket_off, cursor, sorted, two_level ? (const uint32_t*)two_level_bad : (const uint32_t*)nullptr);
     }
+    }  // (!follow)
     // ---- stage A
     if (st_acc != st_sort) {
         SWM_HIP(ctx, hipEventRecord(ctx->sort_event[slot], st_sort));
@@ -2559,7 +2680,8 @@ int msm_enqueue(swm_ctx* ctx, int lane, const G1Affine* d_bases, const G1Affine*
     ctx->slot_busy[slot] = true;
     if (lane >= 0 || defer_tail) {
         SWM_HIP(ctx, hipEventRecord(job->acc_done, ctx->stream));
-        if (lane >= 0) ctx->set_acc_event[lane] = job->acc_done;
+        if (lane >= 0 && !follow) ctx->set_acc_event[lane] = job->acc_done;
+        if (follow) ctx->twin_sorted_event = job->acc_done;
     }
     job->joint_tail = defer_tail;
     if (defer_tail) {  // the bucket stage runs with the other jobs of the round (msm_flush_tails)
@@ -2720,6 +2842,10 @@ int msm_flush_tails(swm_ctx* ctx) {
 // Waits for a job's download, releases its slot and checks the status words.
 static int msm_finish_wait(swm_ctx* ctx, MsmJob* job) {
     if (job->tail_pending) SWM_TRY(msm_flush_tails(ctx));  // awaited before its round was flushed
+    // a twin's follower copies this job's descriptors out of the slot's arrays: the slot is not handed on before that
+    if (job->twin_copied) (void)hipEventSynchronize(job->twin_copied);
+    job->twin_copied = nullptr;
+    job->twin.ready = false;
     const hipError_t werr = hipEventSynchronize(job->done);
     job->active = false;
     ctx->slot_busy[job->slot] = false;  // released whatever the wait returned: the slot must not stay blocked for good

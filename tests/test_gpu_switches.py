@@ -21,7 +21,7 @@ cs = W.synthetic_circuit(case["num_constraints"], int(case["a"], 16), int(case["
 pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
 proof = M.generate_proof(cs, pk, rng)
 assert S.serialize_proof(proof).hex() == case["proof"], "golden proof bytes"
-for lg in (12, 17):
+for lg in (12, 17) + ((20,) if os.environ.get("SWM_TEST_ALSO_2P20") else ()):
     n = 1 << lg
     rng = M.generate_rand()
     srs = M.generate_universal_srs(n, n, n, rng)
@@ -36,14 +36,19 @@ for lg in (12, 17):
     assert c == a, "callback rng, same proof"
     assert M.verify_proof(vk, public, S.deserialize_proof(a), M.generate_rand())
     print("sha", lg, __import__("hashlib").sha256(a).hexdigest())
+ctx = M.default_context()
+ctx.profile()
+print("twins", ctx.last_work["msm_twins"])
 """
 
 
-def _run(env_extra):
+def _run(env_extra, twins=None):
     env = dict(os.environ)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    if twins is not None:
+        twins.append(int([l for l in out.stdout.splitlines() if l.startswith("twins ")][0].split()[1]))
     return [l for l in out.stdout.splitlines() if l.startswith("sha ")]
 
 
@@ -55,6 +60,7 @@ SETTINGS = (
     {"SWM_MSM_TE": "0"},                                        # XYZZ tables (what sets outside the prime-order subgroup get)
     {"SWM_MSM_TABLE_C": "15"},                                  # narrower window tables (what a rank of a sharded proof takes)
     {"SWM_MSM_TABLE_C": "18", "SWM_MSM_BATCH_BELOW": "0"},      # ... wider ones; every job with a bucket stage of its own
+    {"SWM_MSM_TABLE_C": "18", "SWM_MSM_TWIN": "0"},             # ... and every job with a sort of its own (test_twin_jobs below)
     {"SWM_MSM_BATCH_BELOW": "4000000"},                         # every job in the round's joint bucket stage
     {"SWM_MSM_LOW": "1"}, {"SWM_MSM_LOW": "0"},                 # the low-LDS bucket stage everywhere / nowhere (default: joint stages)
     {"SWM_MSM_QUAD": "0"},                                      # small MSMs: one lane per chain / per segment
@@ -76,3 +82,23 @@ def test_switches_select_equivalent_paths():
     assert len(ref) == 2
     for env in SETTINGS:
         assert _run(env) == ref, env
+
+
+@pytest.mark.gpu
+def test_twin_jobs_share_one_sort():
+    """The plain and the shifted commitment of a bounded polynomial are MSMs of the same scalars: when the two tables have the
+    same width the second job takes the first one's sort (msm.h: MsmTwin).  The path must have run (the context counts the jobs
+    that took it), and not with SWM_MSM_TWIN=0 — same bytes: with one width forced for every table, and with the default widths
+    up to 2^20 constraints."""
+    on, off = [], []
+    a = _run({"SWM_MSM_TABLE_C": "18"}, on)
+    b = _run({"SWM_MSM_TABLE_C": "18", "SWM_MSM_TWIN": "0"}, off)
+    assert a == b and len(a) == 2
+    assert on[0] == 6, on   # two bounded polynomials (g_1, g_2) in each of the three 2^17 proofs (the 2^12 proofs' jobs are too small)
+    assert off[0] == 0, off
+    # default widths (g_1 and g_2 of each of the three proofs per size: the tables of the synthetic circuits agree in width)
+    on, off = [], []
+    a = _run({"SWM_TEST_ALSO_2P20": "1"}, on)
+    b = _run({"SWM_TEST_ALSO_2P20": "1", "SWM_MSM_TWIN": "0"}, off)
+    assert a == b and len(a) == 3
+    assert on[0] == 12 and off[0] == 0, (on, off)
