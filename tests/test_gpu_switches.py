@@ -96,7 +96,8 @@ def test_twin_jobs_share_one_sort():
     assert a == b and len(a) == 2
     assert on[0] == 6, on   # two bounded polynomials (g_1, g_2) in each of the three 2^17 proofs (the 2^12 proofs' jobs are too small)
     assert off[0] == 0, off
-    # default widths (g_1 and g_2 of each of the three proofs per size: the tables of the synthetic circuits agree in width)
+    # default widths (g_1 and g_2 of each of the three proofs per size: the SRS has the circuit's own degree, so the shifted powers
+    # are a sub-range of the powers and both jobs of a pair read the one table)
     on, off = [], []
     a = _run({"SWM_TEST_ALSO_2P20": "1"}, on)
     b = _run({"SWM_TEST_ALSO_2P20": "1", "SWM_MSM_TWIN": "0"}, off)
