@@ -964,7 +964,12 @@ void install_committer_key(swm_ctx* ctx, swm_pk& pk, const G1Affine* powers, siz
     // (narrower tables over prefixes of the powers for the |H|-size commitments of mid-size keys: measured in r05 — 2^18 17.4 ->
     // 17.6 ms, Merkle circuit 14.9 -> 17.4 ms: the widest bucket set IS the low-latency choice for jobs that do not fill the
     // chip, CHANGELOG.md — and removed in r06)
-    if (n_shifted) {
+    // With an SRS of exactly the key's degree (srs_max_degree + 1 == n_powers: what generate_universal_srs(n, n, n) of the tests,
+    // the bench and the reference's own examples gives) the shifted powers are the TOP of the powers themselves, and bases_at serves
+    // every shifted range from the powers' table: a scaled copy and a table of their own would never be read (r06: 2.1 GB of HBM and
+    // a table build per 2^20-constraint key).  The affine copy stays: it is what the key's serialisation writes.
+    const bool shifted_inside = pk.shift_base + n_shifted <= n_powers;
+    if (n_shifted && !shifted_inside) {
         rc_check(ctx, msm_install_bases(ctx, pk.d_shifted, n_shifted, in_subgroup, &pk.d_shifted28, &pk.d_shifted_te, &pk.shtab_c));
     } else {
         hip_check(ctx, hipMalloc((void**)&pk.d_shifted28, sizeof(G1Affine)), "hipMalloc(pk shifted28)");
