@@ -103,3 +103,54 @@ def test_twin_jobs_share_one_sort():
     b = _run({"SWM_TEST_ALSO_2P20": "1", "SWM_MSM_TWIN": "0"}, off)
     assert a == b and len(a) == 3
     assert on[0] == 12 and off[0] == 0, (on, off)
+
+
+SCRIPT_LARGE_SRS = r"""
+import json, os, sys, hashlib
+sys.path.insert(0, %r)
+from simpleworks_amd import marlin as M, workloads as W, serialization as S
+n = 1 << 16
+rng = M.generate_rand()
+srs = M.generate_universal_srs(2 * n, 2 * n, 2 * n, rng)     # a universal SRS larger than the circuit needs
+cs, public = W.synthetic_r1cs(n, 19, 5)
+pk, vk = M.generate_proving_and_verifying_keys(srs, cs)
+a = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
+b = S.serialize_proof(M.generate_proof(cs, pk, M.generate_rand()))
+assert a == b
+assert M.verify_proof(vk, public, S.deserialize_proof(a), M.generate_rand())
+bad = list(public); bad[0] = (bad[0] + 1) %% M.R_MODULUS
+assert not M.verify_proof(vk, bad, S.deserialize_proof(a), M.generate_rand())
+# the key survives its codec with both tables rebuilt
+pk2 = S.deserialize_proving_key(S.serialize_proving_key(pk))
+assert S.serialize_proof(M.generate_proof(cs, pk2, M.generate_rand())) == a
+print("sha", hashlib.sha256(a).hexdigest())
+ctx = M.default_context()
+ctx.profile()
+print("twins", ctx.last_work["msm_twins"])
+"""
+
+
+@pytest.mark.gpu
+def test_larger_universal_srs_uses_the_shifted_powers_table():
+    """Under a universal SRS larger than the key's degree the shifted powers are NOT a sub-range of the powers: the key keeps a
+    scaled copy and a window table of their own (install_committer_key), the shifted commitments of g_1 / g_2 read THAT table, and
+    a twin pair spans two tables (different strides) when their widths agree.  Every other test generates the SRS for the
+    circuit's own degree, where all of that is bypassed.  Proofs must verify, a wrong input must not, and the bytes must not depend
+    on the table widths or on whether the shifted job sorted for itself."""
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        env["SWM_TRACE"] = "1"
+        out = subprocess.run([sys.executable, "-c", SCRIPT_LARGE_SRS % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        sha = [l for l in out.stdout.splitlines() if l.startswith("sha ")]
+        twins = int([l for l in out.stdout.splitlines() if l.startswith("twins ")][0].split()[1])
+        widths = sorted(set(l.split("base set of ")[1] for l in out.stderr.splitlines() if "base set of" in l))
+        return sha, twins, widths
+    sha0, tw0, w0 = run({})
+    assert any(w.startswith("65535 points") for w in w0), w0           # the shifted set got a table of its own ...
+    assert tw0 == 0, tw0                                               # ... narrower than the powers': no twin jobs
+    sha1, tw1, w1 = run({"SWM_MSM_TABLE_C": "18"})
+    assert sha1 == sha0 and tw1 == 6, (tw1, w1)                        # one width: g_1, g_2 of three proofs pair up across two tables
+    sha2, tw2, _ = run({"SWM_MSM_TABLE_C": "18", "SWM_MSM_TWIN": "0"})
+    assert sha2 == sha0 and tw2 == 0
